@@ -1,0 +1,28 @@
+# Build libclipk.so (gfx950 HIP kernels + C ABI) in-tree, and the oracle's C pieces.
+#   make            -> clip_dplm_amd/lib/libclipk.so
+#   make probes     -> tools/probes/probe_layouts (hardware layout probes, run on the GPU box)
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wno-unused-value -Iinclude
+SRC := $(wildcard clip_dplm_amd/csrc/*.hip)
+OBJ := $(patsubst clip_dplm_amd/csrc/%.hip,build/%.o,$(SRC))
+LIB := clip_dplm_amd/lib/libclipk.so
+
+all: $(LIB)
+
+build/%.o: clip_dplm_amd/csrc/%.hip clip_dplm_amd/csrc/common.h include/clipk.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJ)
+	@mkdir -p clip_dplm_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ)
+
+probes: tools/probes/probe_layouts
+tools/probes/probe_layouts: tools/probes/probe_layouts.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -o $@ $<
+
+clean:
+	rm -rf build $(LIB) tools/probes/probe_layouts
+
+.PHONY: all clean probes

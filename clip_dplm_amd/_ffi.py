@@ -1,0 +1,111 @@
+"""ctypes binding of libclipk.so (the C ABI declared in include/clipk.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a kernel returns a
+non-zero status this module raises.  PyTorch is used by the callers only for device memory, streams
+and torch.distributed.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libclipk.so")
+
+BF16, F32 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+ACT = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU}
+
+
+class ClipkError(RuntimeError):
+    pass
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("lda", C.c_int64),
+        ("B", C.c_void_p), ("ldb", C.c_int64),
+        ("C", C.c_void_p), ("ldc", C.c_int64), ("c_dtype", C.c_int),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("bias", C.c_void_p),
+        ("act", C.c_int),
+        ("out_preact", C.c_void_p), ("ldp", C.c_int64),
+        ("dact_aux", C.c_void_p), ("ldd", C.c_int64),
+        ("dact", C.c_int),
+        ("residual", C.c_void_p), ("ldr", C.c_int64), ("r_dtype", C.c_int),
+        ("alpha", C.c_float),
+    ]
+
+
+_vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/clipk.h declares
+SIGNATURES = {
+    "clipk_version": (_i, []),
+    "clipk_arch": (C.c_char_p, []),
+    "clipk_status_string": (C.c_char_p, [_i]),
+    "clipk_gemm_nt": (_i, [C.POINTER(GemmArgs), _vp]),
+    "clipk_gemm_wgrad_workspace": (_sz, [_i, _i, _i]),
+    "clipk_gemm_wgrad": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "clipk_simce_workspace": (_sz, [_i, _i, _i]),
+    "clipk_simce_lse": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "clipk_simce_grad": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _sz, _vp]),
+    "clipk_sim_logits": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i64, _vp]),
+    "clipk_layernorm_fwd": (_i, [_vp, _i, _i64, _vp, _vp, _f, _i, _vp, _vp, _i64, _vp, _vp, _i, _i, _vp]),
+    "clipk_layernorm_bwd_workspace": (_sz, [_i, _i]),
+    "clipk_layernorm_bwd": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i64,
+                                 _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "clipk_l2norm_fwd": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
+    "clipk_l2norm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "clipk_cast_f32_to_bf16": (_i, [_vp, _vp, _i64, _vp]),
+    "clipk_cast_bf16_to_f32": (_i, [_vp, _vp, _i64, _vp]),
+    "clipk_cast_transpose": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "clipk_act_fwd": (_i, [_vp, _vp, _i, _i64, _vp]),
+    "clipk_act_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _vp]),
+    "clipk_axpby_dev": (_i, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "clipk_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "clipk_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "clipk_embed_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
+    "clipk_embed_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "clipk_pool_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "clipk_pool_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "clipk_sumsq_workspace": (_sz, [_i64]),
+    "clipk_sumsq": (_i, [_vp, _i64, _vp, _vp, _sz, _vp]),
+    "clipk_adamw_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libclipk.so once; raise loudly (no fallback) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ClipkError(
+            f"{LIB_PATH} not found: the HIP extension is mandatory (there is no CPU fallback). "
+            "Build it with `make` or `python -c 'import __graft_entry__ as g; g.build()'`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().clipk_status_string(status).decode()
+        raise ClipkError(f"{what} failed: {msg} (status {status})")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_handle():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

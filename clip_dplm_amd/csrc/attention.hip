@@ -1,0 +1,639 @@
+// attention.hip — flash-style multi-head self-attention forward / backward for the two encoders.
+//
+// Reference arithmetic replaced: nn.MultiheadAttention inside nn.TransformerEncoderLayer
+// (current/rna_clip_codes.ipynb:1915; key-padding mask -> -inf) and the third-party EsmSelfAttention
+// (transformers modeling_esm.py:362-384: q *= hd^-1/2, rotate-half RoPE on q,k :48-52,74-79, softmax :306-314).
+//
+// gfx950 design:
+//   * the L x L score matrix never leaves registers; 16x16x32 bf16 MFMA everywhere, f32 softmax;
+//   * "swapped" products: S^T = K·Q^T puts keys on accumulator rows and queries on lanes, so the
+//     online-softmax row statistics are in-register reductions + two lane exchanges, and the P^T
+//     accumulator registers ARE the B operand of O^T += V^T·P^T (no LDS round trip for P);
+//   * V^T / K^T / Q^T / dO^T operands come from row-major LDS tiles through ds_read_b64_tr_b16
+//     (CDNA4 transposed read); tiles use a (2*DP+32)-byte row stride that tools/lds_conflicts.py shows
+//     conflict-free for both the b128 row reads and the transposed reads;
+//   * head dims that are not a multiple of 32 (ESM-2-35M: 24) are zero-padded to DP in LDS only;
+//   * RoPE is applied in LDS on the staged q / k rows (f32 math), its transpose on dq / dk before the
+//     store, so q/k are read once from HBM and no rotated copy is ever written;
+//   * backward = a dQ kernel (one workgroup per 128 queries, sweeping keys) and a dK/dV kernel (one
+//     workgroup per 128 or 64 keys, sweeping queries): 7 MFMA products instead of 5, but no float atomics
+//     and bitwise-reproducible gradients.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+struct AP {
+  const unsigned short* qkv; const uint8_t* key_mask; const float* cosT; const float* sinT;
+  unsigned short* out; float* lse;
+  const unsigned short* dout; const float* delta_in; float* delta; unsigned short* dqkv;
+  int B, L, H, D;
+  float scale;
+};
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+template <int DP> struct Geo {
+  static constexpr int RS = DP * 2 + 32;     // LDS row stride in bytes
+  static constexpr int KS = DP / 32;         // contraction steps over the head dim
+  static constexpr int DT = DP / 16;         // 16-wide d tiles
+};
+
+// stage `nrows` token rows (16-byte chunks of the D real columns) into an LDS tile
+__device__ __forceinline__ void stage_rows(char* tile, int RS, const unsigned short* base, long tokstride,
+                                           int pos0, int nrows, int L, int D, int tid) {
+  const int cpr = D >> 3;
+  for (int c = tid; c < nrows * cpr; c += 256) {
+    const int r = c / cpr, ch = c - r * cpr;
+    int pos = pos0 + r; pos = pos < L ? pos : L - 1;
+    *reinterpret_cast<u32x4*>(tile + r * RS + ch * 16) =
+        *reinterpret_cast<const u32x4*>(base + (long)pos * tokstride + ch * 8);
+  }
+}
+
+// rotate-half RoPE in place on an LDS tile of bf16 rows; dir = +1 forward, -1 transpose (for gradients)
+__device__ __forceinline__ void rope_rows(char* tile, int RS, int pos0, int nrows, int L, int D,
+                                          const float* cosT, const float* sinT, float dir, int tid) {
+  const int half = D >> 1;
+  for (int i = tid; i < nrows * half; i += 256) {
+    const int r = i / half, j = i - r * half;
+    int pos = pos0 + r; pos = pos < L ? pos : L - 1;
+    const float c = cosT[(long)pos * half + j], s = sinT[(long)pos * half + j] * dir;
+    unsigned short* row = reinterpret_cast<unsigned short*>(tile + r * RS);
+    const float x1 = bf16_to_f32(row[j]), x2 = bf16_to_f32(row[j + half]);
+    row[j] = f32_to_bf16(x1 * c - x2 * s);
+    row[j + half] = f32_to_bf16(x2 * c + x1 * s);
+  }
+}
+
+__device__ __forceinline__ bf16x8 row_frag(const char* tile, int RS, int row, int ks, int lane) {
+  return *reinterpret_cast<const bf16x8*>(tile + row * RS + ks * 64 + (lane >> 4) * 16);
+}
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int RS, int row0, int colbyte) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (s16x4 __attribute__((address_space(3)))*)(tile + row0 * RS + colbyte));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (s16x4 __attribute__((address_space(3)))*)(tile + (row0 + 16) * RS + colbyte));
+  bf16x8 f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
+__device__ __forceinline__ bf16x8 pack_acc_pair(const f32x4 a, const f32x4 b) {
+  bf16x8 f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { f[r] = (short)f32_to_bf16(a[r]); f[4 + r] = (short)f32_to_bf16(b[r]); }
+  return f;
+}
+__device__ __forceinline__ float group_max(float v) {   // across the 4 lane groups sharing lane&15
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// =================================================================================================
+// forward: one workgroup = 128 queries of one (batch, head); 4 waves x 32 queries; 64-key tiles
+// =================================================================================================
+template <int DP, bool ROPE>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AP p) {
+  constexpr int RS = Geo<DP>::RS, KS = Geo<DP>::KS, DT = Geo<DP>::DT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ktile = smem;
+  char* vtile = smem + 64 * RS;
+  unsigned char* mask_l = reinterpret_cast<unsigned char*>(smem + 128 * RS);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int D = p.D, L = p.L, H = p.H;
+  const long tokstride = 3L * H * D;
+  const unsigned short* qbase = p.qkv + (long)b * L * tokstride + (long)h * D;
+  const unsigned short* kbase = qbase + (long)H * D;
+  const unsigned short* vbase = qbase + 2L * H * D;
+  const int q0 = qb * 128;
+  const int dtv = (D + 15) >> 4;
+  const float c2 = p.scale * LOG2E;
+
+  for (int i = tid; i < (128 * RS) / 16; i += 256) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+  stage_rows(smem, RS, qbase, tokstride, q0, 128, L, D, tid);
+  __syncthreads();
+  if (ROPE) { rope_rows(smem, RS, q0, 128, L, D, p.cosT, p.sinT, 1.f, tid); __syncthreads(); }
+  bf16x8 qf[2][KS];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[qt][ks] = row_frag(smem, RS, wid * 32 + qt * 16 + li, ks, lane);
+  __syncthreads();
+
+  f32x4 o[DT][2];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) { o[dt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o[dt][1] = o[dt][0]; }
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  const int trow = 4 * g + (li >> 2), tcolb = 8 * (li & 3);
+
+  const int nkb = (L + 63) >> 6;
+  for (int kb = 0; kb < nkb; ++kb) {
+    stage_rows(ktile, RS, kbase, tokstride, kb * 64, 64, L, D, tid);
+    stage_rows(vtile, RS, vbase, tokstride, kb * 64, 64, L, D, tid);
+    if (tid < 64) {
+      const int pos = kb * 64 + tid;
+      mask_l[tid] = (pos < L && (!p.key_mask || p.key_mask[(long)b * L + pos])) ? 1 : 0;
+    }
+    __syncthreads();
+    if (ROPE) { rope_rows(ktile, RS, kb * 64, 64, L, D, p.cosT, p.sinT, 1.f, tid); __syncthreads(); }
+
+    f32x4 s[4][2];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) { s[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[kt][1] = s[kt][0]; }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const bf16x8 kf = row_frag(ktile, RS, kt * 16 + li, ks, lane);
+        s[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[kt][0], 0, 0, 0);
+        s[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[kt][1], 0, 0, 0);
+      }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const unsigned int mk = *reinterpret_cast<const unsigned int*>(mask_l + kt * 16 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (!((mk >> (8 * r)) & 0xffu)) { s[kt][0][r] = -INFINITY; s[kt][1][r] = -INFINITY; }
+    }
+    bf16x8 pb[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
+      mx = group_max(mx);
+      const float m_new = fmaxf(m_run[qt], mx);
+      const bool dead = (m_new == -INFINITY);
+      const float alpha = dead ? 1.f : exp2f((m_run[qt] - m_new) * c2);
+      float ls = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = dead ? 0.f : exp2f((s[kt][qt][r] - m_new) * c2);
+          s[kt][qt][r] = pv;
+          ls += pv;
+        }
+      l_run[qt] = l_run[qt] * alpha + ls;
+      m_run[qt] = m_new;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) o[dt][qt] *= alpha;
+      pb[qt][0] = pack_acc_pair(s[0][qt], s[1][qt]);
+      pb[qt][1] = pack_acc_pair(s[2][qt], s[3][qt]);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+        if (dt < dtv) {
+          const bf16x8 vf = tr_frag(vtile, RS, 32 * s2 + trow, dt * 32 + tcolb);
+          o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[0][s2], o[dt][0], 0, 0, 0);
+          o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[1][s2], o[dt][1], 0, 0, 0);
+        }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const float lt = group_sum(l_run[qt]);
+    const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+    const int q = q0 + wid * 32 + qt * 16 + li;
+    if (q < L) {
+      if (g == 0) p.lse[((long)b * H + h) * L + q] = lt > 0.f ? m_run[qt] * p.scale + logf(lt) : -INFINITY;
+      unsigned short* orow = p.out + ((long)b * L + q) * ((long)H * D) + (long)h * D;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int d = dt * 16 + 4 * g;
+        if (d < D) {
+          u32x2 w;
+          w[0] = pack_bf16x2(o[dt][qt][0] * inv, o[dt][qt][1] * inv);
+          w[1] = pack_bf16x2(o[dt][qt][2] * inv, o[dt][qt][3] * inv);
+          *reinterpret_cast<u32x2*>(orow + d) = w;
+        }
+      }
+    }
+  }
+}
+
+// delta[b,h,q] = sum_d dout[q,d] * out[q,d]
+__global__ __launch_bounds__(256) void attn_delta_kernel(const AP p) {
+  const long total = (long)p.B * p.L * p.H;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long tok = i / p.H; const int h = (int)(i - tok * p.H);
+  const int b = (int)(tok / p.L), q = (int)(tok - (long)b * p.L);
+  const unsigned short* o = p.out + tok * ((long)p.H * p.D) + (long)h * p.D;
+  const unsigned short* d_ = p.dout + tok * ((long)p.H * p.D) + (long)h * p.D;
+  float acc = 0.f;
+  for (int c = 0; c < p.D; c += 8) {
+    const u32x4 a = *reinterpret_cast<const u32x4*>(o + c), bb = *reinterpret_cast<const u32x4*>(d_ + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc += bf16_to_f32(a[e] & 0xffffu) * bf16_to_f32(bb[e] & 0xffffu);
+      acc += bf16_to_f32(a[e] >> 16) * bf16_to_f32(bb[e] >> 16);
+    }
+  }
+  p.delta[((long)b * p.H + h) * p.L + q] = acc;
+}
+
+// write an f32 [rows][DP+4] LDS image (gradient w.r.t. rotated q/k) as bf16 rows of dqkv, applying the
+// RoPE transpose on the way when ROPE
+template <bool ROPE>
+__device__ __forceinline__ void store_grad_rows(const float* img, int ILD, unsigned short* base, long tokstride,
+                                                int pos0, int nrows, int L, int D, const float* cosT,
+                                                const float* sinT, int tid) {
+  const int cpr = D >> 3, half = D >> 1;
+  for (int c = tid; c < nrows * cpr; c += 256) {
+    const int r = c / cpr, ch = c - r * cpr;
+    const int pos = pos0 + r;
+    if (pos >= L) continue;
+    const float* row = img + r * ILD;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int d = ch * 8 + e;
+      float x = row[d];
+      if (ROPE) {
+        const bool lo = d < half;
+        const int j = lo ? d : d - half;
+        const float cs = cosT[(long)pos * half + j], sn = sinT[(long)pos * half + j];
+        const float other = row[lo ? d + half : d - half];
+        x = lo ? (x * cs + other * sn) : (x * cs - other * sn);
+      }
+      v[e] = x;
+    }
+    u32x4 w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+    *reinterpret_cast<u32x4*>(base + (long)pos * tokstride + ch * 8) = w;
+  }
+}
+
+// =================================================================================================
+// backward dQ: one workgroup = 128 queries, sweeps 64-key tiles
+// =================================================================================================
+template <int DP, bool ROPE>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AP p) {
+  constexpr int RS = Geo<DP>::RS, KS = Geo<DP>::KS, DT = Geo<DP>::DT, ILD = DP + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ktile = smem;
+  char* vtile = smem + 64 * RS;
+  unsigned char* mask_l = reinterpret_cast<unsigned char*>(smem + 128 * RS);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int D = p.D, L = p.L, H = p.H;
+  const long tokstride = 3L * H * D, ostride = (long)H * D;
+  const unsigned short* qbase = p.qkv + (long)b * L * tokstride + (long)h * D;
+  const unsigned short* kbase = qbase + (long)H * D;
+  const unsigned short* vbase = qbase + 2L * H * D;
+  const unsigned short* dobase = p.dout + (long)b * L * ostride + (long)h * D;
+  const int q0 = qb * 128;
+  const int dtv = (D + 15) >> 4;
+  const float c2 = p.scale * LOG2E;
+
+  for (int i = tid; i < (128 * RS) / 16; i += 256) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+  stage_rows(smem, RS, qbase, tokstride, q0, 128, L, D, tid);
+  __syncthreads();
+  if (ROPE) { rope_rows(smem, RS, q0, 128, L, D, p.cosT, p.sinT, 1.f, tid); __syncthreads(); }
+  bf16x8 qf[2][KS], dof[2][KS];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[qt][ks] = row_frag(smem, RS, wid * 32 + qt * 16 + li, ks, lane);
+  __syncthreads();
+  stage_rows(smem, RS, dobase, ostride, q0, 128, L, D, tid);
+  __syncthreads();
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) dof[qt][ks] = row_frag(smem, RS, wid * 32 + qt * 16 + li, ks, lane);
+  __syncthreads();
+
+  float lse2[2], dl[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    int q = q0 + wid * 32 + qt * 16 + li; q = q < L ? q : L - 1;
+    lse2[qt] = p.lse[((long)b * H + h) * L + q] * LOG2E;
+    dl[qt] = p.delta_in[((long)b * H + h) * L + q];
+  }
+  f32x4 dq[DT][2];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) { dq[dt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dq[dt][1] = dq[dt][0]; }
+  const int trow = 4 * g + (li >> 2), tcolb = 8 * (li & 3);
+
+  const int nkb = (L + 63) >> 6;
+  for (int kb = 0; kb < nkb; ++kb) {
+    stage_rows(ktile, RS, kbase, tokstride, kb * 64, 64, L, D, tid);
+    stage_rows(vtile, RS, vbase, tokstride, kb * 64, 64, L, D, tid);
+    if (tid < 64) {
+      const int pos = kb * 64 + tid;
+      mask_l[tid] = (pos < L && (!p.key_mask || p.key_mask[(long)b * L + pos])) ? 1 : 0;
+    }
+    __syncthreads();
+    if (ROPE) { rope_rows(ktile, RS, kb * 64, 64, L, D, p.cosT, p.sinT, 1.f, tid); __syncthreads(); }
+
+    f32x4 s[4][2], dp[4][2];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) { s[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[kt][1] = s[kt][0]; dp[kt][0] = s[kt][0]; dp[kt][1] = s[kt][0]; }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const bf16x8 kf = row_frag(ktile, RS, kt * 16 + li, ks, lane);
+        const bf16x8 vf = row_frag(vtile, RS, kt * 16 + li, ks, lane);
+        s[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[kt][0], 0, 0, 0);
+        s[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[kt][1], 0, 0, 0);
+        dp[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[0][ks], dp[kt][0], 0, 0, 0);
+        dp[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[1][ks], dp[kt][1], 0, 0, 0);
+      }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const unsigned int mk = *reinterpret_cast<const unsigned int*>(mask_l + kt * 16 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = ((mk >> (8 * r)) & 0xffu) != 0;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          const float pv = ok ? exp2f(s[kt][qt][r] * c2 - lse2[qt]) : 0.f;
+          s[kt][qt][r] = pv * (dp[kt][qt][r] - dl[qt]);          // dS^T (w.r.t. the scaled score)
+        }
+      }
+    }
+    bf16x8 db[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      db[qt][0] = pack_acc_pair(s[0][qt], s[1][qt]);
+      db[qt][1] = pack_acc_pair(s[2][qt], s[3][qt]);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+        if (dt < dtv) {
+          const bf16x8 kt_f = tr_frag(ktile, RS, 32 * s2 + trow, dt * 32 + tcolb);
+          dq[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_f, db[0][s2], dq[dt][0], 0, 0, 0);
+          dq[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_f, db[1][s2], dq[dt][1], 0, 0, 0);
+        }
+    __syncthreads();
+  }
+
+  // dq~ (gradient w.r.t. the rotated q) -> f32 LDS image [128][DP+4] -> RoPE^T -> bf16 rows of dqkv
+  float* img = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        img[(wid * 32 + qt * 16 + li) * ILD + dt * 16 + 4 * g + r] = dq[dt][qt][r] * p.scale;
+  __syncthreads();
+  store_grad_rows<ROPE>(img, ILD, p.dqkv + (long)b * L * tokstride + (long)h * D, tokstride, q0, 128, L, D,
+                        p.cosT, p.sinT, tid);
+}
+
+// =================================================================================================
+// backward dK/dV: one workgroup = 4 waves x (16*KTW) keys, sweeps 64-query tiles
+// =================================================================================================
+template <int DP, bool ROPE, int KTW>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AP p) {
+  constexpr int RS = Geo<DP>::RS, KS = Geo<DP>::KS, DT = Geo<DP>::DT, ILD = DP + 4;
+  constexpr int KPW = 16 * KTW, KPB = 4 * KPW;            // keys per wave / per workgroup
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* qtile = smem;                                     // [64 q][RS]   (also the staging area for K/V blocks)
+  char* dotile = smem + 64 * RS;                          // [64 q][RS]
+  float* lse_l = reinterpret_cast<float*>(smem + 128 * RS);      // [64]
+  float* dl_l = lse_l + 64;                                      // [64]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int kbk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int D = p.D, L = p.L, H = p.H;
+  const long tokstride = 3L * H * D, ostride = (long)H * D;
+  const unsigned short* qbase = p.qkv + (long)b * L * tokstride + (long)h * D;
+  const unsigned short* kbase = qbase + (long)H * D;
+  const unsigned short* vbase = qbase + 2L * H * D;
+  const unsigned short* dobase = p.dout + (long)b * L * ostride + (long)h * D;
+  const int k0 = kbk * KPB;
+  const int dtv = (D + 15) >> 4;
+  const float c2 = p.scale * LOG2E;
+
+  for (int i = tid; i < (128 * RS) / 16; i += 256) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+  // this workgroup's keys: K (rotated) and V as B fragments B[k = d][col = key] kept in registers
+  bf16x8 kf[KTW][KS], vf[KTW][KS];
+  stage_rows(smem, RS, kbase, tokstride, k0, KPB, L, D, tid);
+  __syncthreads();
+  if (ROPE) { rope_rows(smem, RS, k0, KPB, L, D, p.cosT, p.sinT, 1.f, tid); __syncthreads(); }
+#pragma unroll
+  for (int kt = 0; kt < KTW; ++kt)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kf[kt][ks] = row_frag(smem, RS, wid * KPW + kt * 16 + li, ks, lane);
+  __syncthreads();
+  stage_rows(smem, RS, vbase, tokstride, k0, KPB, L, D, tid);
+  __syncthreads();
+#pragma unroll
+  for (int kt = 0; kt < KTW; ++kt)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) vf[kt][ks] = row_frag(smem, RS, wid * KPW + kt * 16 + li, ks, lane);
+  __syncthreads();
+  bool kvalid[KTW];
+#pragma unroll
+  for (int kt = 0; kt < KTW; ++kt) {
+    const int key = k0 + wid * KPW + kt * 16 + li;
+    kvalid[kt] = key < L && (!p.key_mask || p.key_mask[(long)b * L + key]);
+  }
+
+  f32x4 dk[DT][KTW], dv[DT][KTW];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int kt = 0; kt < KTW; ++kt) { dk[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt][kt] = dk[dt][kt]; }
+  const int trow = 4 * g + (li >> 2), tcolb = 8 * (li & 3);
+
+  const int nqb = (L + 63) >> 6;
+  for (int qb = 0; qb < nqb; ++qb) {
+    stage_rows(qtile, RS, qbase, tokstride, qb * 64, 64, L, D, tid);
+    stage_rows(dotile, RS, dobase, ostride, qb * 64, 64, L, D, tid);
+    if (tid < 64) {
+      const int q = qb * 64 + tid;
+      const bool ok = q < L;
+      // queries past the end: lse = +inf makes p = exp2(-inf) = 0
+      lse_l[tid] = ok ? p.lse[((long)b * H + h) * L + q] * LOG2E : INFINITY;
+      dl_l[tid] = ok ? p.delta_in[((long)b * H + h) * L + q] : 0.f;
+    }
+    __syncthreads();
+    if (ROPE) { rope_rows(qtile, RS, qb * 64, 64, L, D, p.cosT, p.sinT, 1.f, tid); __syncthreads(); }
+
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {                       // 32 queries at a time
+      f32x4 s[2][KTW], dp[2][KTW];
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+        for (int kt = 0; kt < KTW; ++kt) { s[qq][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qq][kt] = s[qq][kt]; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+          const int row = (2 * s2 + qq) * 16 + li;
+          const bf16x8 qa = row_frag(qtile, RS, row, ks, lane);
+          const bf16x8 da = row_frag(dotile, RS, row, ks, lane);
+#pragma unroll
+          for (int kt = 0; kt < KTW; ++kt) {
+            s[qq][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kt][ks], s[qq][kt], 0, 0, 0);
+            dp[qq][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kt][ks], dp[qq][kt], 0, 0, 0);
+          }
+        }
+      // rows of the accumulators are queries (4g+r), columns are this lane's key
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const f32x4 ls = *reinterpret_cast<const f32x4*>(lse_l + (2 * s2 + qq) * 16 + 4 * g);
+        const f32x4 dd = *reinterpret_cast<const f32x4*>(dl_l + (2 * s2 + qq) * 16 + 4 * g);
+#pragma unroll
+        for (int kt = 0; kt < KTW; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = kvalid[kt] ? exp2f(s[qq][kt][r] * c2 - ls[r]) : 0.f;
+            s[qq][kt][r] = pv;                                  // P
+            dp[qq][kt][r] = pv * (dp[qq][kt][r] - dd[r]);       // dS
+          }
+      }
+#pragma unroll
+      for (int kt = 0; kt < KTW; ++kt) {
+        const bf16x8 pbf = pack_acc_pair(s[0][kt], s[1][kt]);
+        const bf16x8 dsf = pack_acc_pair(dp[0][kt], dp[1][kt]);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+          if (dt < dtv) {
+            const bf16x8 dot_f = tr_frag(dotile, RS, 32 * s2 + trow, dt * 32 + tcolb);   // dO^T
+            const bf16x8 qt_f = tr_frag(qtile, RS, 32 * s2 + trow, dt * 32 + tcolb);     // Q~^T
+            dv[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_f, pbf, dv[dt][kt], 0, 0, 0);
+            dk[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_f, dsf, dk[dt][kt], 0, 0, 0);
+          }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- dK~ / dV -> f32 LDS images -> (RoPE^T for dK) -> bf16 rows of dqkv
+  float* img = reinterpret_cast<float*>(smem);
+  unsigned short* dkbase = p.dqkv + (long)b * L * tokstride + (long)H * D + (long)h * D;
+  unsigned short* dvbase = p.dqkv + (long)b * L * tokstride + 2L * H * D + (long)h * D;
+#pragma unroll
+  for (int kt = 0; kt < KTW; ++kt)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        img[(wid * KPW + kt * 16 + li) * ILD + dt * 16 + 4 * g + r] = dk[dt][kt][r] * p.scale;
+  __syncthreads();
+  store_grad_rows<ROPE>(img, ILD, dkbase, tokstride, k0, KPB, L, D, p.cosT, p.sinT, tid);
+  __syncthreads();
+#pragma unroll
+  for (int kt = 0; kt < KTW; ++kt)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        img[(wid * KPW + kt * 16 + li) * ILD + dt * 16 + 4 * g + r] = dv[dt][kt][r];
+  __syncthreads();
+  store_grad_rows<false>(img, ILD, dvbase, tokstride, k0, KPB, L, D, p.cosT, p.sinT, tid);
+}
+
+template <int DP> constexpr size_t lds_bytes() {
+  const size_t tiles = 128 * (size_t)Geo<DP>::RS + 512;
+  const size_t img = 128 * (size_t)(DP + 4) * 4;
+  return tiles > img ? tiles : img;
+}
+
+template <int DP, bool ROPE>
+int launch_fwd(const AP& p, hipStream_t st) {
+  const size_t lds = lds_bytes<DP>();
+  if (lds > 65536)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<DP, ROPE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  dim3 grid((p.L + 127) / 128, p.H, p.B);
+  hipLaunchKernelGGL((attn_fwd_kernel<DP, ROPE>), grid, dim3(256), lds, st, p);
+  return clipk_check_launch();
+}
+
+template <int DP, bool ROPE>
+int launch_bwd(const AP& p, hipStream_t st) {
+  constexpr int KTW = (DP > 96) ? 1 : 2;
+  const size_t lds = lds_bytes<DP>();
+  if (lds > 65536) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<DP, ROPE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<DP, ROPE, KTW>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
+  const long total = (long)p.B * p.L * p.H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+  dim3 gq((p.L + 127) / 128, p.H, p.B);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<DP, ROPE>), gq, dim3(256), lds, st, p);
+  constexpr int KPB = 64 * KTW;
+  dim3 gk((p.L + KPB - 1) / KPB, p.H, p.B);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, ROPE, KTW>), gk, dim3(256), lds, st, p);
+  return clipk_check_launch();
+}
+
+int check_common(const void* qkv, int B, int L, int H, int D) {
+  if (!qkv || B <= 0 || L <= 0 || H <= 0 || D <= 0) return CLIPK_ERR_BAD_ARG;
+  if ((D & 7) || D > 160) return CLIPK_ERR_UNSUPPORTED;
+  if (!aligned16(qkv)) return CLIPK_ERR_BAD_ARG;
+  return CLIPK_OK;
+}
+
+}  // namespace
+
+#define ATTN_DISPATCH(FN, D, ROPE, P, ST)                                 \
+  do {                                                                    \
+    if ((D) <= 32) return (ROPE) ? FN<32, true>(P, ST) : FN<32, false>(P, ST);    \
+    if ((D) <= 64) return (ROPE) ? FN<64, true>(P, ST) : FN<64, false>(P, ST);    \
+    if ((D) <= 96) return (ROPE) ? FN<96, true>(P, ST) : FN<96, false>(P, ST);    \
+    if ((D) <= 128) return (ROPE) ? FN<128, true>(P, ST) : FN<128, false>(P, ST); \
+    return (ROPE) ? FN<160, true>(P, ST) : FN<160, false>(P, ST);                 \
+  } while (0)
+
+extern "C" int clipk_attn_fwd(const void* qkv, const uint8_t* key_mask, const float* rope_cos, const float* rope_sin,
+                              void* out, float* lse, int B, int L, int H, int D, float q_scale, void* stream) {
+  int rc = check_common(qkv, B, L, H, D);
+  if (rc) return rc;
+  if (!out || !lse || !aligned16(out)) return CLIPK_ERR_BAD_ARG;
+  if ((rope_cos == nullptr) != (rope_sin == nullptr)) return CLIPK_ERR_BAD_ARG;
+  AP p{};
+  p.qkv = (const unsigned short*)qkv; p.key_mask = key_mask; p.cosT = rope_cos; p.sinT = rope_sin;
+  p.out = (unsigned short*)out; p.lse = lse; p.B = B; p.L = L; p.H = H; p.D = D; p.scale = q_scale;
+  const bool rope = rope_cos != nullptr;
+  ATTN_DISPATCH(launch_fwd, D, rope, p, (hipStream_t)stream);
+}
+
+extern "C" int clipk_attn_bwd(const void* qkv, const uint8_t* key_mask, const float* rope_cos, const float* rope_sin,
+                              const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                              int B, int L, int H, int D, float q_scale, void* stream) {
+  int rc = check_common(qkv, B, L, H, D);
+  if (rc) return rc;
+  if (!out || !dout || !lse || !delta || !dqkv) return CLIPK_ERR_BAD_ARG;
+  if (!aligned16(out) || !aligned16(dout) || !aligned16(dqkv)) return CLIPK_ERR_BAD_ARG;
+  if ((rope_cos == nullptr) != (rope_sin == nullptr)) return CLIPK_ERR_BAD_ARG;
+  AP p{};
+  p.qkv = (const unsigned short*)qkv; p.key_mask = key_mask; p.cosT = rope_cos; p.sinT = rope_sin;
+  p.out = (unsigned short*)out; p.lse = const_cast<float*>(lse);
+  p.dout = (const unsigned short*)dout; p.delta_in = delta; p.delta = delta; p.dqkv = (unsigned short*)dqkv;
+  p.B = B; p.L = L; p.H = H; p.D = D; p.scale = q_scale;
+  const bool rope = rope_cos != nullptr;
+  ATTN_DISPATCH(launch_bwd, D, rope, p, (hipStream_t)stream);
+}

@@ -1,0 +1,74 @@
+// common.h — shared device helpers for the gfx950 (CDNA4) kernels of libclipk.
+// Wave = 64 lanes everywhere; no other architecture is targeted.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/clipk.h"
+
+#define CLIPK_ABI_VERSION 1
+#define WAVE 64
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;     // 8 bf16 = one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;     // 4 bf16 = one ds_read_b64_tr_b16 result
+typedef __attribute__((ext_vector_type(4))) float f32x4;      // 16x16 MFMA accumulator
+typedef __attribute__((ext_vector_type(16))) float f32x16;    // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) {
+  return __uint_as_float(((unsigned int)h) << 16);
+}
+// round-to-nearest-even; a plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+  return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {          // transformers modeling_esm.py:82-86 / nn.GELU()
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+__device__ __forceinline__ float act_apply(float x, int act) {
+  if (act == CLIPK_ACT_RELU) return x > 0.f ? x : 0.f;
+  if (act == CLIPK_ACT_GELU) return gelu_erf(x);
+  return x;
+}
+__device__ __forceinline__ float act_grad(float x, int act) {
+  if (act == CLIPK_ACT_RELU) return x > 0.f ? 1.f : 0.f;
+  if (act == CLIPK_ACT_GELU) return gelu_erf_grad(x);
+  return 1.f;
+}
+
+// wave-wide reductions over 64 lanes
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// XCD-aware bijective remap of a 1-D block id: blocks b and b+8 share an XCD (observed round-robin
+// dispatch, MI355X_MICROARCH.md §Workgroup dispatch), so give each XCD a contiguous chunk of the tile
+// order.  Speed only — any placement is correct.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+static inline int clipk_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? CLIPK_OK : CLIPK_ERR_LAUNCH;
+}
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }

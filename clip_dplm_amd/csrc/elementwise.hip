@@ -1,0 +1,304 @@
+// elementwise.hip — HBM-bound elementwise / gather / optimiser kernels (16-byte accesses, grid-stride).
+// Reference ops: dtype casts done by autocast (old/clip_opt.py:163), F.relu / nn.GELU (old/clip.py:16,29),
+// skip + layer_scale * projected (old/clip_opt.py:41-44), EsmEmbeddings (modeling_esm.py:203-270),
+// position-0 / mean pooling (rna_clip_codes.ipynb:1948; configuration_hybrid_clip.py:109),
+// AdamW + clip_grad_norm_ (rna_clip_codes.ipynb:2033,2076; old/clip_opt.py:168-171).
+#include "common.h"
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+inline int ew_blocks(long n_items) {
+  long b = (n_items + EW_THREADS - 1) / EW_THREADS;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+__global__ void cast_f32_bf16_kernel(const float* x, unsigned short* y, long n) {
+  const long n8 = n >> 3;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += stride) {
+    const f32x4 a = reinterpret_cast<const f32x4*>(x)[2 * i], b = reinterpret_cast<const f32x4*>(x)[2 * i + 1];
+    u32x4 o = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
+    reinterpret_cast<u32x4*>(y)[i] = o;
+  }
+  for (long i = (n8 << 3) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) y[i] = f32_to_bf16(x[i]);
+}
+
+__global__ void cast_bf16_f32_kernel(const unsigned short* x, float* y, long n) {
+  const long n8 = n >> 3;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += stride) {
+    const u32x4 a = reinterpret_cast<const u32x4*>(x)[i];
+    f32x4 lo, hi;
+    lo[0] = bf16_to_f32(a[0] & 0xffffu); lo[1] = bf16_to_f32(a[0] >> 16);
+    lo[2] = bf16_to_f32(a[1] & 0xffffu); lo[3] = bf16_to_f32(a[1] >> 16);
+    hi[0] = bf16_to_f32(a[2] & 0xffffu); hi[1] = bf16_to_f32(a[2] >> 16);
+    hi[2] = bf16_to_f32(a[3] & 0xffffu); hi[3] = bf16_to_f32(a[3] >> 16);
+    reinterpret_cast<f32x4*>(y)[2 * i] = lo;
+    reinterpret_cast<f32x4*>(y)[2 * i + 1] = hi;
+  }
+  for (long i = (n8 << 3) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) y[i] = bf16_to_f32(x[i]);
+}
+
+// 64x64 tile through LDS: coalesced f32 reads along cols, coalesced bf16 writes along rows of W^T
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* w, unsigned short* wb, unsigned short* wt,
+                                                             int rows, int cols) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (r < rows && c < cols) {
+      v = w[(long)r * cols + c];
+      if (wb) wb[(long)r * cols + c] = f32_to_bf16(v);
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  if (wt) {
+    for (int i = ty; i < 64; i += 4) {
+      const int c = c0 + i, r = r0 + tx;
+      if (r < rows && c < cols) wt[(long)c * rows + r] = f32_to_bf16(tile[tx][i]);
+    }
+  }
+}
+
+__global__ void act_fwd_kernel(const float* x, float* y, int act, long n) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) y[i] = act_apply(x[i], act);
+}
+__global__ void act_bwd_kernel(const float* dy, const float* x, float* dx, int act, long n) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) dx[i] = dy[i] * act_grad(x[i], act);
+}
+__global__ void axpby_dev_kernel(const float* a, const float* b, const float* s, float* y, long n) {
+  const float sc = s[0];
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) y[i] = a[i] + sc * b[i];
+}
+
+// ---- embedding ----------------------------------------------------------------------------------
+__global__ void embed_fwd_kernel(const int64_t* ids, const float* table, const float* row_scale, const uint8_t* mask,
+                                 int mask_token_id, float* x, int B, int L, int d) {
+  const int nch = d >> 2;
+  const long total = (long)B * L * nch;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long t = i / nch; const int c = (int)(i - t * nch);
+    const int64_t id = ids[t];
+    float sc = row_scale ? row_scale[t / L] : 1.0f;
+    if (mask && !mask[t]) sc = 0.f;
+    if ((int)id == mask_token_id) sc = 0.f;
+    f32x4 v = *reinterpret_cast<const f32x4*>(table + id * d + 4 * c);
+    *reinterpret_cast<f32x4*>(x + t * d + 4 * c) = v * sc;
+  }
+}
+
+// dtable[v,:] += sum over tokens with ids == v.  Per-block private [V][d] table in LDS (ds_add_f32),
+// then one global atomic per (block, v, column) — V*d*4 bytes must fit the LDS budget.
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* ids, const float* dx, const float* row_scale,
+                                                        const uint8_t* mask, int mask_token_id, float* dtable,
+                                                        int B, int L, int d, int V) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tab = reinterpret_cast<float*>(smem);
+  for (int i = threadIdx.x; i < V * d; i += blockDim.x) tab[i] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  const long T = (long)B * L;
+  for (long t = wave; t < T; t += nwaves) {
+    const int id = (int)ids[t];
+    float sc = row_scale ? row_scale[t / L] : 1.0f;
+    if (mask && !mask[t]) sc = 0.f;
+    if (id == mask_token_id) sc = 0.f;
+    if (sc == 0.f) continue;
+    for (int c = lane; c < d; c += 64) atomicAdd(&tab[id * d + c], dx[t * d + c] * sc);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < V * d; i += blockDim.x) {
+    const float v = tab[i];
+    if (v != 0.f) atomicAdd(&dtable[i], v);
+  }
+}
+
+// ---- pooling ------------------------------------------------------------------------------------
+__global__ void pool_fwd_kernel(const float* x, const uint8_t* mask, float* y, int B, int L, int d, int mode) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  if (mode == 0) { y[(long)b * d + c] = x[((long)b * L) * d + c]; return; }
+  float s = 0.f; int n = 0;
+  for (int l = 0; l < L; ++l) {
+    const bool ok = mask ? mask[(long)b * L + l] != 0 : true;
+    if (ok) { s += x[((long)b * L + l) * d + c]; ++n; }
+  }
+  y[(long)b * d + c] = n > 0 ? s / (float)n : 0.f;
+}
+__global__ void pool_bwd_kernel(const float* dy, const uint8_t* mask, float* dx, int B, int L, int d, int mode) {
+  const int nch = d >> 2;
+  const long total = (long)B * L * nch;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long t = i / nch; const int c = (int)(i - t * nch);
+    const int b = (int)(t / L), l = (int)(t - (long)b * L);
+    float sc;
+    if (mode == 0) sc = (l == 0) ? 1.f : 0.f;
+    else {
+      // valid-token count of this sequence (L is small; recomputed per thread from the L1-resident mask)
+      int n = L;
+      if (mask) { n = 0; for (int k = 0; k < L; ++k) n += mask[(long)b * L + k] != 0; }
+      const bool ok = mask ? mask[t] != 0 : true;
+      sc = (ok && n > 0) ? 1.0f / (float)n : 0.f;
+    }
+    f32x4 v = *reinterpret_cast<const f32x4*>(dy + (long)b * d + 4 * c);
+    *reinterpret_cast<f32x4*>(dx + t * d + 4 * c) = v * sc;
+  }
+}
+
+// ---- optimiser ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* g, long n, float* part) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const long n4 = n >> 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(g)[i];
+    s += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+  for (long i = (n4 << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) s += g[i] * g[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* part, int nparts, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += part[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void adamw_kernel(float* w, const float* g, float* m, float* v, unsigned short* wb, long n, float lr,
+                             float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt,
+                             const float* gnsq, float max_norm, float grad_scale) {
+  float clip = grad_scale;
+  if (gnsq) {
+    // torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
+    const float norm = sqrtf(gnsq[0]) * grad_scale;
+    const float coef = max_norm / (norm + 1e-6f);
+    clip *= coef < 1.0f ? coef : 1.0f;
+  }
+  const long stride = (long)gridDim.x * blockDim.x;
+  const float step = lr / bc1;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gi = g[i] * clip;
+    float wi = w[i] * (1.0f - lr * wd);
+    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    wi -= step * (mi / denom);
+    w[i] = wi;
+    if (wb) wb[i] = f32_to_bf16(wi);
+  }
+}
+
+}  // namespace
+
+extern "C" int clipk_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) {
+  if (!x || !y || n <= 0 || !aligned16(x) || !aligned16(y)) return CLIPK_ERR_BAD_ARG;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(ew_blocks(n / 8 + 1)), dim3(EW_THREADS), 0, (hipStream_t)stream, x,
+                     (unsigned short*)y, (long)n);
+  return clipk_check_launch();
+}
+extern "C" int clipk_cast_bf16_to_f32(const void* x, float* y, int64_t n, void* stream) {
+  if (!x || !y || n <= 0 || !aligned16(x) || !aligned16(y)) return CLIPK_ERR_BAD_ARG;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(ew_blocks(n / 8 + 1)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                     (const unsigned short*)x, y, (long)n);
+  return clipk_check_launch();
+}
+extern "C" int clipk_cast_transpose(const float* w, void* w_bf16, void* wt_bf16, int rows, int cols, void* stream) {
+  if (!w || rows <= 0 || cols <= 0 || (!w_bf16 && !wt_bf16)) return CLIPK_ERR_BAD_ARG;
+  hipLaunchKernelGGL(cast_transpose_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                     w, (unsigned short*)w_bf16, (unsigned short*)wt_bf16, rows, cols);
+  return clipk_check_launch();
+}
+extern "C" int clipk_act_fwd(const float* x, float* y, int act, int64_t n, void* stream) {
+  if (!x || !y || n <= 0) return CLIPK_ERR_BAD_ARG;
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, x, y, act, (long)n);
+  return clipk_check_launch();
+}
+extern "C" int clipk_act_bwd(const float* dy, const float* x, float* dx, int act, int64_t n, void* stream) {
+  if (!dy || !x || !dx || n <= 0) return CLIPK_ERR_BAD_ARG;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, dy, x, dx, act, (long)n);
+  return clipk_check_launch();
+}
+extern "C" int clipk_axpby_dev(const float* a, const float* b, const float* s, float* y, int64_t n, void* stream) {
+  if (!a || !b || !s || !y || n <= 0) return CLIPK_ERR_BAD_ARG;
+  hipLaunchKernelGGL(axpby_dev_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, a, b, s, y, (long)n);
+  return clipk_check_launch();
+}
+
+extern "C" int clipk_embed_fwd(const int64_t* ids, const float* table, const float* row_scale, const uint8_t* mask,
+                               int mask_token_id, float* x, int B, int L, int d, void* stream) {
+  if (!ids || !table || !x || B <= 0 || L <= 0 || d <= 0) return CLIPK_ERR_BAD_ARG;
+  if (d & 3) return CLIPK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(ew_blocks((long)B * L * (d / 4))), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                     ids, table, row_scale, mask, mask_token_id, x, B, L, d);
+  return clipk_check_launch();
+}
+extern "C" int clipk_embed_bwd(const int64_t* ids, const float* dx, const float* row_scale, const uint8_t* mask,
+                               int mask_token_id, float* dtable, int B, int L, int d, int V, void* stream) {
+  if (!ids || !dx || !dtable || B <= 0 || L <= 0 || d <= 0 || V <= 0) return CLIPK_ERR_BAD_ARG;
+  const size_t lds = (size_t)V * d * sizeof(float);
+  if (lds > 144 * 1024) return CLIPK_ERR_UNSUPPORTED;
+  if (lds > 65536)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+  long waves = (long)B * L;
+  int blocks = (int)((waves + 3) / 4); if (blocks > 256) blocks = 256; if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, ids, dx, row_scale, mask,
+                     mask_token_id, dtable, B, L, d, V);
+  return clipk_check_launch();
+}
+
+extern "C" int clipk_pool_fwd(const float* x, const uint8_t* mask, float* y, int B, int L, int d, int mode, void* stream) {
+  if (!x || !y || B <= 0 || L <= 0 || d <= 0) return CLIPK_ERR_BAD_ARG;
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3((d + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, mask, y, B, L, d, mode);
+  return clipk_check_launch();
+}
+extern "C" int clipk_pool_bwd(const float* dy, const uint8_t* mask, float* dx, int B, int L, int d, int mode, void* stream) {
+  if (!dy || !dx || B <= 0 || L <= 0 || d <= 0) return CLIPK_ERR_BAD_ARG;
+  if (d & 3) return CLIPK_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_blocks((long)B * L * (d / 4))), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                     dy, mask, dx, B, L, d, mode);
+  return clipk_check_launch();
+}
+
+extern "C" size_t clipk_sumsq_workspace(int64_t n) { return (size_t)ew_blocks(n / 4 + 1) * sizeof(float); }
+extern "C" int clipk_sumsq(const float* g, int64_t n, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!g || !out || !workspace || n <= 0 || !aligned16(g)) return CLIPK_ERR_BAD_ARG;
+  const int blocks = ew_blocks(n / 4 + 1);
+  if (workspace_bytes < (size_t)blocks * sizeof(float)) return CLIPK_ERR_BAD_ARG;
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, (long)n, (float*)workspace);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, blocks, out);
+  return clipk_check_launch();
+}
+extern "C" int clipk_adamw_step(float* w, const float* g, float* m, float* v, void* w_bf16, int64_t n, float lr,
+                                float beta1, float beta2, float eps, float weight_decay, int step,
+                                const float* grad_norm_sq, float max_norm, float grad_scale, void* stream) {
+  if (!w || !g || !m || !v || n <= 0 || step < 1) return CLIPK_ERR_BAD_ARG;
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, w, g, m, v,
+                     (unsigned short*)w_bf16, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2),
+                     grad_norm_sq, max_norm, grad_scale);
+  return clipk_check_launch();
+}

@@ -1,0 +1,356 @@
+// rowwise.hip — HBM-bound row kernels: LayerNorm fwd/bwd (+fused activation), L2-normalise fwd/bwd.
+// One wave (64 lanes) per row, whole row held in registers as 4-element chunks (16-byte f32 loads,
+// 8-byte bf16 loads), f32 statistics with wave-shuffle reductions — no LDS, no re-reads.
+// Reference ops: nn.LayerNorm at old/clip.py:12,28,32, the LayerNorms inside nn.TransformerEncoderLayer
+// (rna_clip_codes.ipynb:1915-1916) and EsmLayer (modeling_esm.py:429-438,552-553); F.normalize at
+// old/clip.py:63-64.
+#include "common.h"
+
+namespace {
+
+template <bool BF16>
+__device__ __forceinline__ f32x4 load4(const void* base, long off) {
+  if (BF16) {
+    const u32x2 r = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(base) + off);
+    return f32x4{bf16_to_f32((unsigned short)(r[0] & 0xffffu)), bf16_to_f32((unsigned short)(r[0] >> 16)),
+                 bf16_to_f32((unsigned short)(r[1] & 0xffffu)), bf16_to_f32((unsigned short)(r[1] >> 16))};
+  } else {
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + off);
+  }
+}
+__device__ __forceinline__ void store4_bf16(void* base, long off, f32x4 v) {
+  u32x2 o;
+  o[0] = pack_bf16x2(v[0], v[1]);
+  o[1] = pack_bf16x2(v[2], v[3]);
+  *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(base) + off) = o;
+}
+
+struct LnFwd {
+  const void* x; long ldx;
+  const float* gamma; const float* beta; float eps; int act;
+  float* y_f32; void* y_bf16; long ldy;
+  float* mean; float* rstd; int rows, cols;
+};
+
+template <int VPL, bool XBF16>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwd p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int nch = p.cols >> 2;
+  f32x4 g[VPL], b[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    const int c = lane + 64 * v;
+    g[v] = f32x4{0.f, 0.f, 0.f, 0.f}; b[v] = g[v];
+    if (c < nch) {
+      g[v] = *reinterpret_cast<const f32x4*>(p.gamma + 4 * c);
+      b[v] = *reinterpret_cast<const f32x4*>(p.beta + 4 * c);
+    }
+  }
+  const float inv_n = 1.0f / (float)p.cols;
+  for (int row = wave; row < p.rows; row += nwaves) {
+    f32x4 x[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int c = lane + 64 * v;
+      x[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < nch) x[v] = load4<XBF16>(p.x, (long)row * p.ldx + 4 * c);
+      s += (x[v][0] + x[v][1]) + (x[v][2] + x[v][3]);
+    }
+    const float mean = wave_sum(s) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int c = lane + 64 * v;
+      if (c < nch) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = x[v][e] - mean; q += d * d; }
+      }
+    }
+    const float var = wave_sum(q) * inv_n;
+    const float rstd = rsqrtf(var + p.eps);
+    if (lane == 0) {
+      if (p.mean) p.mean[row] = mean;
+      if (p.rstd) p.rstd[row] = rstd;
+    }
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int c = lane + 64 * v;
+      if (c < nch) {
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = act_apply((x[v][e] - mean) * rstd * g[v][e] + b[v][e], p.act);
+        if (p.y_f32) *reinterpret_cast<f32x4*>(p.y_f32 + (long)row * p.ldy + 4 * c) = y;
+        if (p.y_bf16) store4_bf16(p.y_bf16, (long)row * p.ldy + 4 * c, y);
+      }
+    }
+  }
+}
+
+struct LnBwd {
+  const void* dy; long lddy;
+  const void* x; long ldx;
+  const float* gamma; const float* beta; const float* mean; const float* rstd; int act;
+  const float* dx_add; float* dx_f32; void* dx_bf16; long lddx;
+  float* part;   // [nblocks][2][cols]
+  int rows, cols;
+};
+
+template <int VPL, bool DYBF16, bool XBF16>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int nch = p.cols >> 2;
+  f32x4 g[VPL], b[VPL], dg[VPL], db[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    const int c = lane + 64 * v;
+    g[v] = f32x4{0.f, 0.f, 0.f, 0.f}; b[v] = g[v]; dg[v] = g[v]; db[v] = g[v];
+    if (c < nch) {
+      g[v] = *reinterpret_cast<const f32x4*>(p.gamma + 4 * c);
+      if (p.act != CLIPK_ACT_NONE) b[v] = *reinterpret_cast<const f32x4*>(p.beta + 4 * c);
+    }
+  }
+  const float inv_n = 1.0f / (float)p.cols;
+  for (int row = wave; row < p.rows; row += nwaves) {
+    const float mean = p.mean[row], rstd = p.rstd[row];
+    f32x4 xh[VPL], gy[VPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int c = lane + 64 * v;
+      xh[v] = f32x4{0.f, 0.f, 0.f, 0.f}; gy[v] = xh[v];
+      if (c < nch) {
+        const f32x4 xv = load4<XBF16>(p.x, (long)row * p.ldx + 4 * c);
+        f32x4 dyv = load4<DYBF16>(p.dy, (long)row * p.lddy + 4 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xhat = (xv[e] - mean) * rstd;
+          if (p.act != CLIPK_ACT_NONE) dyv[e] *= act_grad(xhat * g[v][e] + b[v][e], p.act);
+          xh[v][e] = xhat;
+          dg[v][e] += dyv[e] * xhat;
+          db[v][e] += dyv[e];
+          const float gg = dyv[e] * g[v][e];
+          gy[v][e] = gg;
+          s1 += gg; s2 += gg * xhat;
+        }
+      }
+    }
+    const float c1 = wave_sum(s1) * inv_n, c2 = wave_sum(s2) * inv_n;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int c = lane + 64 * v;
+      if (c < nch) {
+        f32x4 dx;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dx[e] = rstd * (gy[v][e] - c1 - xh[v][e] * c2);
+        if (p.dx_add) dx += *reinterpret_cast<const f32x4*>(p.dx_add + (long)row * p.lddx + 4 * c);
+        if (p.dx_f32) *reinterpret_cast<f32x4*>(p.dx_f32 + (long)row * p.lddx + 4 * c) = dx;
+        if (p.dx_bf16) store4_bf16(p.dx_bf16, (long)row * p.lddx + 4 * c, dx);
+      }
+    }
+  }
+  // block-level combine of the 4 waves' dgamma/dbeta partials through LDS, then one partial row / block
+  float* sm = reinterpret_cast<float*>(smem);          // [4][2][cols]
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    const int c = lane + 64 * v;
+    if (c < nch) {
+      *reinterpret_cast<f32x4*>(sm + (wid * 2 + 0) * p.cols + 4 * c) = dg[v];
+      *reinterpret_cast<f32x4*>(sm + (wid * 2 + 1) * p.cols + 4 * c) = db[v];
+    }
+  }
+  __syncthreads();
+  const int nw = blockDim.x >> 6;
+  for (int i = threadIdx.x; i < 2 * p.cols; i += blockDim.x) {
+    float a = 0.f;
+    for (int w = 0; w < nw; ++w) a += sm[w * 2 * p.cols + i];
+    p.part[(long)blockIdx.x * 2 * p.cols + i] = a;
+  }
+}
+
+__global__ void colreduce_kernel(const float* part, int nparts, int ncols, float* out0, float* out1, int cols,
+                                 int accumulate) {
+  // part: [nparts][ncols] with ncols = 2*cols ([dgamma | dbeta]); fixed summation order
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ncols) return;
+  float a = 0.f;
+  for (int s = 0; s < nparts; ++s) a += part[(long)s * ncols + i];
+  float* o = (i < cols) ? (out0 ? out0 + i : nullptr) : (out1 ? out1 + (i - cols) : nullptr);
+  if (o) *o = accumulate ? (*o + a) : a;
+}
+
+// ---- L2 normalise -------------------------------------------------------------------------------
+template <int VPL>
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* x, float* y, float* norm, int rows, int cols,
+                                                         float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= rows) return;
+  const int nch = cols >> 2;
+  f32x4 xv[VPL];
+  float s = 0.f;
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    const int c = lane + 64 * v;
+    xv[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < nch) xv[v] = *reinterpret_cast<const f32x4*>(x + (long)row * cols + 4 * c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s += xv[v][e] * xv[v][e];
+  }
+  const float n = sqrtf(wave_sum(s));
+  const float inv = 1.0f / fmaxf(n, eps);
+  if (lane == 0 && norm) norm[row] = n;
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    const int c = lane + 64 * v;
+    if (c < nch) *reinterpret_cast<f32x4*>(y + (long)row * cols + 4 * c) = xv[v] * inv;
+  }
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* dy, const float* y, const float* norm, float* dx,
+                                                         int rows, int cols, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= rows) return;
+  const int nch = cols >> 2;
+  f32x4 yv[VPL], dv[VPL];
+  float s = 0.f;
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    const int c = lane + 64 * v;
+    yv[v] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[v] = yv[v];
+    if (c < nch) {
+      yv[v] = *reinterpret_cast<const f32x4*>(y + (long)row * cols + 4 * c);
+      dv[v] = *reinterpret_cast<const f32x4*>(dy + (long)row * cols + 4 * c);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s += yv[v][e] * dv[v][e];
+  }
+  const float dot = wave_sum(s);
+  const float n = norm[row];
+  // y = x / max(n, eps): for n >= eps, dx = (dy - y*(y.dy)) / n ; below eps the clamp is constant: dx = dy/eps
+  const bool clamped = n < eps;
+  const float inv = 1.0f / fmaxf(n, eps);
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    const int c = lane + 64 * v;
+    if (c < nch) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = clamped ? dv[v][e] * inv : (dv[v][e] - yv[v][e] * dot) * inv;
+      *reinterpret_cast<f32x4*>(dx + (long)row * cols + 4 * c) = o;
+    }
+  }
+}
+
+int ln_blocks(int rows) {
+  int b = (rows + 3) / 4;
+  if (b > 512) b = 512;
+  if (b < 1) b = 1;
+  return b;
+}
+
+template <int VPL, bool DYBF16, bool XBF16>
+void launch_ln_bwd(const LnBwd& p, int blocks, size_t lds, hipStream_t st) {
+  if (lds > 65536)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_kernel<VPL, DYBF16, XBF16>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((ln_bwd_kernel<VPL, DYBF16, XBF16>), dim3(blocks), dim3(256), lds, st, p);
+}
+
+}  // namespace
+
+#define LN_DISPATCH_VPL(cols, CALL)                      \
+  do {                                                   \
+    const int nch_ = (cols) >> 2;                        \
+    if (nch_ <= 64 * 2) { CALL(2); }                     \
+    else if (nch_ <= 64 * 4) { CALL(4); }                \
+    else if (nch_ <= 64 * 8) { CALL(8); }                \
+    else if (nch_ <= 64 * 20) { CALL(20); }              \
+    else return CLIPK_ERR_UNSUPPORTED;                   \
+  } while (0)
+
+extern "C" int clipk_layernorm_fwd(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta,
+                                   float eps, int act, float* y_f32, void* y_bf16, int64_t ldy,
+                                   float* mean, float* rstd, int rows, int cols, void* stream) {
+  if (!x || !gamma || !beta || rows <= 0 || cols <= 0 || (!y_f32 && !y_bf16)) return CLIPK_ERR_BAD_ARG;
+  if ((cols & 3) || (ldx & 3) || (ldy & 3)) return CLIPK_ERR_UNSUPPORTED;
+  if (!aligned16(gamma) || !aligned16(beta)) return CLIPK_ERR_BAD_ARG;
+  LnFwd p{x, (long)ldx, gamma, beta, eps, act, y_f32, y_bf16, (long)ldy, mean, rstd, rows, cols};
+  const int blocks = ln_blocks(rows);
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(V)                                                                                   \
+  if (x_dtype == CLIPK_BF16) hipLaunchKernelGGL((ln_fwd_kernel<V, true>), dim3(blocks), dim3(256), 0, st, p); \
+  else hipLaunchKernelGGL((ln_fwd_kernel<V, false>), dim3(blocks), dim3(256), 0, st, p)
+  LN_DISPATCH_VPL(cols, CALL);
+#undef CALL
+  return clipk_check_launch();
+}
+
+extern "C" size_t clipk_layernorm_bwd_workspace(int rows, int cols) {
+  return (size_t)ln_blocks(rows) * 2 * cols * sizeof(float);
+}
+
+extern "C" int clipk_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, const void* x, int x_dtype, int64_t ldx,
+                                   const float* gamma, const float* beta, const float* mean, const float* rstd, int act,
+                                   const float* dx_add, float* dx_f32, void* dx_bf16, int64_t lddx,
+                                   float* dgamma, float* dbeta, int accumulate,
+                                   int rows, int cols, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || rows <= 0 || cols <= 0 || !workspace) return CLIPK_ERR_BAD_ARG;
+  if (act != CLIPK_ACT_NONE && !beta) return CLIPK_ERR_BAD_ARG;
+  if ((cols & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3)) return CLIPK_ERR_UNSUPPORTED;
+  const int blocks = ln_blocks(rows);
+  if (workspace_bytes < (size_t)blocks * 2 * cols * sizeof(float)) return CLIPK_ERR_BAD_ARG;
+  LnBwd p{dy, (long)lddy, x, (long)ldx, gamma, beta, mean, rstd, act, dx_add, dx_f32, dx_bf16, (long)lddx,
+          (float*)workspace, rows, cols};
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)4 * 2 * cols * sizeof(float);
+#define CALL(V)                                                                                                   \
+  do {                                                                                                            \
+    if (dy_dtype == CLIPK_BF16 && x_dtype == CLIPK_BF16)                                                          \
+      launch_ln_bwd<V, true, true>(p, blocks, lds, st);                                                           \
+    else if (dy_dtype == CLIPK_BF16)                                                                              \
+      launch_ln_bwd<V, true, false>(p, blocks, lds, st);                                                          \
+    else if (x_dtype == CLIPK_BF16)                                                                               \
+      launch_ln_bwd<V, false, true>(p, blocks, lds, st);                                                          \
+    else                                                                                                          \
+      launch_ln_bwd<V, false, false>(p, blocks, lds, st);                                                         \
+  } while (0)
+  LN_DISPATCH_VPL(cols, CALL);
+#undef CALL
+  int rc = clipk_check_launch();
+  if (rc) return rc;
+  if (dgamma || dbeta) {
+    hipLaunchKernelGGL(colreduce_kernel, dim3((2 * cols + 255) / 256), dim3(256), 0, st, (const float*)workspace,
+                       blocks, 2 * cols, dgamma, dbeta, cols, accumulate);
+    rc = clipk_check_launch();
+  }
+  return rc;
+}
+
+extern "C" int clipk_l2norm_fwd(const float* x, float* y, float* norm, int rows, int cols, float eps, void* stream) {
+  if (!x || !y || rows <= 0 || cols <= 0) return CLIPK_ERR_BAD_ARG;
+  if ((cols & 3) || cols > 64 * 4 * 8) return CLIPK_ERR_UNSUPPORTED;
+  const int blocks = (rows + 3) / 4;
+  hipStream_t st = (hipStream_t)stream;
+  if (cols <= 512) hipLaunchKernelGGL((l2norm_fwd_kernel<2>), dim3(blocks), dim3(256), 0, st, x, y, norm, rows, cols, eps);
+  else hipLaunchKernelGGL((l2norm_fwd_kernel<8>), dim3(blocks), dim3(256), 0, st, x, y, norm, rows, cols, eps);
+  return clipk_check_launch();
+}
+
+extern "C" int clipk_l2norm_bwd(const float* dy, const float* y, const float* norm, float* dx,
+                                int rows, int cols, float eps, void* stream) {
+  if (!dy || !y || !norm || !dx || rows <= 0 || cols <= 0) return CLIPK_ERR_BAD_ARG;
+  if ((cols & 3) || cols > 64 * 4 * 8) return CLIPK_ERR_UNSUPPORTED;
+  const int blocks = (rows + 3) / 4;
+  hipStream_t st = (hipStream_t)stream;
+  if (cols <= 512) hipLaunchKernelGGL((l2norm_bwd_kernel<2>), dim3(blocks), dim3(256), 0, st, dy, y, norm, dx, rows, cols, eps);
+  else hipLaunchKernelGGL((l2norm_bwd_kernel<8>), dim3(blocks), dim3(256), 0, st, dy, y, norm, dx, rows, cols, eps);
+  return clipk_check_launch();
+}

@@ -1,0 +1,369 @@
+// simce.hip — fused similarity + cross-entropy for the CLIP loss; the B x B logits never reach HBM.
+//
+// Reference arithmetic replaced (see include/clipk.h): old/clip.py:66-67 (scaled A·B^T),
+// old/ablation.py:16 / rna_clip_codes.ipynb:1952-1953 (row / column cross-entropy on the diagonal),
+// old/clip_opt.py:115-121,130-151 (extra cache columns in the row direction).
+//
+// gfx950 design:
+//   * exact-f32 matrix cores: v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain, bit-for-bit f32), so
+//     the loss meets the 1e-3 parity bar without a bf16 rounding of the unit-norm embeddings;
+//   * "swapped" product S^T = Y·X^T: keys on the accumulator rows (registers), queries on the lanes,
+//     so the per-query softmax statistics are in-register reductions plus one lane^32 exchange;
+//   * one workgroup = 32 queries x a contiguous range of 32-key tiles; its NW = P/128 waves split the
+//     contraction dimension P, each wave keeps its slice of the query block in registers as MFMA B
+//     fragments and its slice of the key tile in a wave-private LDS region (coalesced 512-B row
+//     segments from HBM/L2), partial S tiles are summed through LDS;
+//   * backward: G = dL/dS is formed in the accumulator layout and is directly the B operand of the
+//     second product dX^T += Y^T·G^T (same key tile, still in LDS) — no LDS round trip for G;
+//   * key-range splits write f32 partials (online-softmax pairs / dX slabs) that a tiny finalize
+//     kernel merges in a fixed order: deterministic, no float atomics.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int QB = 32;          // queries per workgroup
+constexpr int KT = 32;          // keys per tile
+constexpr int PWMAX = 128;      // contraction slice per wave
+constexpr int MAXW = 8;         // P <= 1024
+
+enum { MODE_LSE = 0, MODE_GRAD = 1, MODE_LOGITS = 2 };
+
+struct SP {
+  const float* X; int Mx;
+  const float* Y; int Ny;
+  const float* Yc; int Nc;
+  int P, Pw, NW;
+  const float* scale;
+  int label_offset;
+  // LSE outputs
+  float* part_ml;      // [ksplit][Mx][2]
+  float* pos;          // [Mx]
+  // grad
+  const float* lse_x; const float* lse_y;
+  float w_row, w_col, inv_bg;
+  float* slab;         // [ksplit][Mx][P]
+  float* dsc_part;     // [ksplit][Mx]
+  // logits
+  float* S; long lds_out;
+  int ksplit, tiles_per_split, ntiles;
+};
+
+__device__ __forceinline__ int keyrow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <int MODE>
+__global__ __launch_bounds__(512) void simce_kernel(const SP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int NW = p.NW, Pw = p.Pw, P = p.P;
+  const int YLD = Pw + 4;
+  const int q = lane & 31, h = lane >> 5;
+  const int q0 = blockIdx.x * QB, ks = blockIdx.y;
+  const int Nkeys = p.Ny + p.Nc;
+  float* ylds = reinterpret_cast<float*>(smem) + w * KT * YLD;
+  float* red = reinterpret_cast<float*>(smem) + NW * KT * YLD;     // [NW][16*64]
+  const int pbeg = w * Pw;
+  const float scale = p.scale[0];
+
+  // ---- this wave's slice of the query block, as B fragments of S^T = Y·X^T (kept in registers)
+  f32x4 xf[PWMAX / 8];
+  {
+    int qi = q0 + q; qi = qi < p.Mx ? qi : p.Mx - 1;
+    const float* xr = p.X + (long)qi * P;
+#pragma unroll
+    for (int t = 0; t < PWMAX / 8; ++t) {
+      xf[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t * 8 < Pw) {
+        const int pp = pbeg + t * 8 + 4 * h;
+        if (pp < P) xf[t] = *reinterpret_cast<const f32x4*>(xr + pp);
+      }
+    }
+  }
+
+  const int qg = q0 + q;                        // global query row within X
+  const int label = p.label_offset + qg;        // its positive key
+  float m_run = -INFINITY, l_run = 0.f, pos_v = 0.f;
+  bool pos_hit = false;
+  float lse_xi = 0.f, dsc = 0.f;
+  f32x16 dx[PWMAX / 32];
+  if (MODE == MODE_GRAD) {
+    lse_xi = p.lse_x[qg < p.Mx ? qg : p.Mx - 1];
+#pragma unroll
+    for (int t = 0; t < PWMAX / 32; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dx[t][r] = 0.f;
+  }
+
+  const int t_beg = ks * p.tiles_per_split;
+  int t_end = t_beg + p.tiles_per_split; t_end = t_end < p.ntiles ? t_end : p.ntiles;
+  const int c4_per_row = Pw >> 2;               // float4 per key row of this wave's slice
+  const int n_it = (KT * c4_per_row) >> 6;      // = Pw/8 passes of 64 lanes
+
+  for (int kt = t_beg; kt < t_end; ++kt) {
+    const int j0 = kt * KT;
+    __syncthreads();                            // previous tile fully consumed (red[] and ylds reuse)
+    // ---- stage this wave's [32 keys][Pw] slice of the key tile: whole row segments, 16 B per lane
+    for (int it = 0; it < n_it; ++it) {
+      const int idx = lane + 64 * it;
+      const int row = idx / c4_per_row, c4 = idx - row * c4_per_row;
+      int j = j0 + row; j = j < Nkeys ? j : Nkeys - 1;
+      const float* yr = (j < p.Ny) ? p.Y + (long)j * P : p.Yc + (long)(j - p.Ny) * P;
+      const int pp = pbeg + c4 * 4;
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (pp < P) v = *reinterpret_cast<const f32x4*>(yr + pp);
+      *reinterpret_cast<f32x4*>(ylds + row * YLD + c4 * 4) = v;
+    }
+    // wave-private region: a wave's own LDS writes are visible to its later reads in program order
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < PWMAX / 8; ++t) {
+      if (t * 8 < Pw) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(ylds + q * YLD + t * 8 + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], xf[t][e], s, 0, 0, 0);
+      }
+    }
+    if (NW > 1) {                               // sum the per-wave partial tiles (fixed order)
+      float* mine = red + w * 1024;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mine[r * 64 + lane] = s[r];
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float a = 0.f;
+        for (int ww = 0; ww < NW; ++ww) a += red[ww * 1024 + r * 64 + lane];
+        s[r] = a;
+      }
+    }
+
+    if (MODE == MODE_LSE) {
+      if (w == 0) {
+        float tmax = -INFINITY;
+        float sv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = j0 + keyrow(r, h);
+          sv[r] = key < Nkeys ? scale * s[r] : -INFINITY;
+          tmax = fmaxf(tmax, sv[r]);
+          if (key == label && key < p.Ny) { pos_v = sv[r]; pos_hit = true; }
+        }
+        if (tmax > -INFINITY) {
+          const float m_new = fmaxf(m_run, tmax);
+          float acc = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc += expf(sv[r] - m_new);   // exp(-inf) = 0 for masked keys
+          l_run = l_run * expf(m_run - m_new) + acc;
+          m_run = m_new;
+        }
+      }
+    } else if (MODE == MODE_GRAD) {
+      f32x16 g;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = j0 + keyrow(r, h);
+        const float sv = scale * s[r];
+        float gv = 0.f;
+        if (key < Nkeys) {
+          gv = p.w_row * expf(sv - lse_xi);
+          if (key < p.Ny) {
+            gv += p.w_col * expf(sv - p.lse_y[key]);
+            if (key == label) gv -= (p.w_row + p.w_col);
+          }
+          gv *= p.inv_bg;
+        }
+        g[r] = gv;
+        dsc += gv * s[r];
+      }
+      // dX^T[p][q] += sum_key Y[key][p] * G^T[key][q]; G registers are the B operand as they stand
+#pragma unroll
+      for (int tt = 0; tt < PWMAX / 32; ++tt) {
+        if (tt * 32 < Pw) {
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            const float a = ylds[keyrow(u, h) * YLD + tt * 32 + q];
+            dx[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, g[u], dx[tt], 0, 0, 0);
+          }
+        }
+      }
+    } else {  // MODE_LOGITS: roles are swapped by the host (queries = Y rows of the caller)
+      if (w == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = j0 + keyrow(r, h);
+          if (key < Nkeys && qg < p.Mx) p.S[(long)key * p.lds_out + qg] = scale * s[r];
+        }
+      }
+    }
+  }
+
+  if (MODE == MODE_LSE) {
+    if (w == 0) {
+      // merge the two lane halves (keys 4h.. interleaved) of each query
+      const float m_o = __shfl_xor(m_run, 32, 64), l_o = __shfl_xor(l_run, 32, 64);
+      const float m_n = fmaxf(m_run, m_o);
+      float l_n = 0.f;
+      if (m_n > -INFINITY) l_n = l_run * expf(m_run - m_n) + l_o * expf(m_o - m_n);
+      if (qg < p.Mx) {
+        if (h == 0) {
+          float* o = p.part_ml + ((long)ks * p.Mx + qg) * 2;
+          o[0] = m_n; o[1] = l_n;
+        }
+        if (pos_hit) p.pos[qg] = pos_v;
+      }
+    }
+  } else if (MODE == MODE_GRAD) {
+    // stage dX^T tiles as [q][p] rows in this wave's LDS region, then write whole row segments
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < PWMAX / 32; ++tt)
+      if (tt * 32 < Pw)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ylds[q * YLD + tt * 32 + keyrow(r, h)] = dx[tt][r];
+    for (int it = 0; it < n_it; ++it) {
+      const int idx = lane + 64 * it;
+      const int row = idx / c4_per_row, c4 = idx - row * c4_per_row;
+      const int pp = pbeg + c4 * 4;
+      if (q0 + row < p.Mx && pp < P) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ylds + row * YLD + c4 * 4);
+        *reinterpret_cast<f32x4*>(p.slab + ((long)ks * p.Mx + q0 + row) * P + pp) = v;
+      }
+    }
+    if (w == 0) {
+      const float d = dsc + __shfl_xor(dsc, 32, 64);
+      if (h == 0 && qg < p.Mx) p.dsc_part[(long)ks * p.Mx + qg] = d;
+    }
+  }
+}
+
+__global__ void simce_lse_finalize(const float* part_ml, int ksplit, int Mx, float* lse) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Mx) return;
+  float m = -INFINITY;
+  for (int s = 0; s < ksplit; ++s) m = fmaxf(m, part_ml[((long)s * Mx + i) * 2]);
+  float l = 0.f;
+  for (int s = 0; s < ksplit; ++s) {
+    const float ms = part_ml[((long)s * Mx + i) * 2], ls = part_ml[((long)s * Mx + i) * 2 + 1];
+    if (ms > -INFINITY) l += ls * expf(ms - m);
+  }
+  lse[i] = m + logf(l);
+}
+
+__global__ void simce_grad_finalize(const float* slab, const float* dsc_part, int ksplit, int Mx, int P,
+                                    const float* scale, float* dX, float* dscale_partial) {
+  const long n4 = (long)Mx * P / 4;
+  const float sc = scale[0];
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < ksplit; ++s) a += reinterpret_cast<const f32x4*>(slab + (long)s * Mx * P)[i];
+    reinterpret_cast<f32x4*>(dX)[i] = a * sc;
+  }
+  if (dscale_partial) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < Mx; i += (long)gridDim.x * blockDim.x) {
+      float a = 0.f;
+      for (int s = 0; s < ksplit; ++s) a += dsc_part[(long)s * Mx + i];
+      dscale_partial[i] = a;
+    }
+  }
+}
+
+struct Plan { int NW, Pw, nqb, ntiles, ksplit, tps; size_t lds; };
+
+bool make_plan(int Mx, int Nkeys, int P, Plan* pl) {
+  if (Mx <= 0 || Nkeys <= 0 || P <= 0 || (P & 3) || P > PWMAX * MAXW) return false;
+  int nw = 1;
+  while (nw < MAXW && (P + nw - 1) / nw > PWMAX) nw <<= 1;
+  int pw = (P + nw - 1) / nw; pw = (pw + 7) & ~7;
+  pl->NW = nw; pl->Pw = pw;
+  pl->nqb = (Mx + QB - 1) / QB;
+  pl->ntiles = (Nkeys + KT - 1) / KT;
+  int ks = (512 + pl->nqb - 1) / pl->nqb;
+  if (ks > pl->ntiles) ks = pl->ntiles;
+  if (ks < 1) ks = 1;
+  pl->tps = (pl->ntiles + ks - 1) / ks;
+  pl->ksplit = (pl->ntiles + pl->tps - 1) / pl->tps;
+  pl->lds = (size_t)nw * KT * (pw + 4) * 4 + (size_t)nw * 1024 * 4;
+  if (pl->lds > 160 * 1024) return false;
+  return true;
+}
+
+template <int MODE>
+int launch(const SP& sp, const Plan& pl, hipStream_t st) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(simce_kernel<MODE>),
+                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+  hipLaunchKernelGGL(simce_kernel<MODE>, dim3(pl.nqb, pl.ksplit), dim3(pl.NW * 64), pl.lds, st, sp);
+  return clipk_check_launch();
+}
+
+}  // namespace
+
+extern "C" size_t clipk_simce_workspace(int Mx, int Nkeys, int P) {
+  Plan pl;
+  if (!make_plan(Mx, Nkeys, P, &pl)) return 0;
+  return (size_t)pl.ksplit * Mx * ((size_t)P + 2) * sizeof(float);
+}
+
+extern "C" int clipk_simce_lse(const float* X, int Mx, const float* Y, int Ny, const float* Yc, int Nc,
+                               int P, const float* scale, int label_offset, float* lse, float* pos,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  if (!X || !Y || !scale || !lse || !pos || !workspace || Nc < 0 || (Nc > 0 && !Yc)) return CLIPK_ERR_BAD_ARG;
+  Plan pl;
+  if (!make_plan(Mx, Ny + Nc, P, &pl)) return CLIPK_ERR_UNSUPPORTED;
+  if (!aligned16(X) || !aligned16(Y) || (Yc && !aligned16(Yc))) return CLIPK_ERR_BAD_ARG;
+  if (workspace_bytes < (size_t)pl.ksplit * Mx * 2 * sizeof(float)) return CLIPK_ERR_BAD_ARG;
+  SP sp{};
+  sp.X = X; sp.Mx = Mx; sp.Y = Y; sp.Ny = Ny; sp.Yc = Yc ? Yc : Y; sp.Nc = Nc;
+  sp.P = P; sp.Pw = pl.Pw; sp.NW = pl.NW; sp.scale = scale; sp.label_offset = label_offset;
+  sp.part_ml = (float*)workspace; sp.pos = pos;
+  sp.ksplit = pl.ksplit; sp.tiles_per_split = pl.tps; sp.ntiles = pl.ntiles;
+  int rc = launch<MODE_LSE>(sp, pl, (hipStream_t)stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(simce_lse_finalize, dim3((Mx + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)workspace, pl.ksplit, Mx, lse);
+  return clipk_check_launch();
+}
+
+extern "C" int clipk_simce_grad(const float* X, int Mx, const float* Y, int Ny, const float* Yc, int Nc,
+                                int P, const float* scale, int label_offset,
+                                const float* lse_x, const float* lse_y, float w_row, float w_col, float inv_bg,
+                                float* dX, float* dscale_partial,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  if (!X || !Y || !scale || !lse_x || !lse_y || !dX || !workspace || Nc < 0 || (Nc > 0 && !Yc))
+    return CLIPK_ERR_BAD_ARG;
+  Plan pl;
+  if (!make_plan(Mx, Ny + Nc, P, &pl)) return CLIPK_ERR_UNSUPPORTED;
+  if (!aligned16(X) || !aligned16(Y) || (Yc && !aligned16(Yc)) || !aligned16(dX) || !aligned16(workspace))
+    return CLIPK_ERR_BAD_ARG;
+  const size_t need = (size_t)pl.ksplit * Mx * ((size_t)P + 1) * sizeof(float);
+  if (workspace_bytes < need) return CLIPK_ERR_BAD_ARG;
+  SP sp{};
+  sp.X = X; sp.Mx = Mx; sp.Y = Y; sp.Ny = Ny; sp.Yc = Yc ? Yc : Y; sp.Nc = Nc;
+  sp.P = P; sp.Pw = pl.Pw; sp.NW = pl.NW; sp.scale = scale; sp.label_offset = label_offset;
+  sp.lse_x = lse_x; sp.lse_y = lse_y; sp.w_row = w_row; sp.w_col = w_col; sp.inv_bg = inv_bg;
+  sp.slab = (float*)workspace; sp.dsc_part = (float*)workspace + (size_t)pl.ksplit * Mx * P;
+  sp.ksplit = pl.ksplit; sp.tiles_per_split = pl.tps; sp.ntiles = pl.ntiles;
+  int rc = launch<MODE_GRAD>(sp, pl, (hipStream_t)stream);
+  if (rc) return rc;
+  long n4 = (long)Mx * P / 4;
+  int blocks = (int)((n4 + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(simce_grad_finalize, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)sp.slab, (const float*)sp.dsc_part, pl.ksplit, Mx, P, scale, dX,
+                     dscale_partial);
+  return clipk_check_launch();
+}
+
+extern "C" int clipk_sim_logits(const float* X, int Mx, const float* Y, int Ny, int P, const float* scale,
+                                float* S, int64_t lds, void* stream) {
+  if (!X || !Y || !scale || !S) return CLIPK_ERR_BAD_ARG;
+  // swapped roles: the kernel's "queries" (lanes) are the columns of S so stores are row-contiguous
+  Plan pl;
+  if (!make_plan(Ny, Mx, P, &pl)) return CLIPK_ERR_UNSUPPORTED;
+  if (!aligned16(X) || !aligned16(Y)) return CLIPK_ERR_BAD_ARG;
+  SP sp{};
+  sp.X = Y; sp.Mx = Ny; sp.Y = X; sp.Ny = Mx; sp.Yc = X; sp.Nc = 0;
+  sp.P = P; sp.Pw = pl.Pw; sp.NW = pl.NW; sp.scale = scale; sp.label_offset = 0;
+  sp.S = S; sp.lds_out = lds;
+  sp.ksplit = pl.ksplit; sp.tiles_per_split = pl.tps; sp.ntiles = pl.ntiles;
+  return launch<MODE_LOGITS>(sp, pl, (hipStream_t)stream);
+}

@@ -1,0 +1,319 @@
+"""Thin tensor-level wrappers over the libclipk C ABI (no autograd here, no fallbacks).
+
+Every function enqueues HIP kernels on torch's current stream and returns torch tensors that own the
+output memory.  Inputs must live on a CUDA(HIP) device; anything else raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _ffi
+from ._ffi import ACT, BF16, F32, GemmArgs, check, ptr
+
+_WS: dict = {}
+
+
+def _lib():
+    return _ffi.load()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _ffi.ClipkError("libclipk kernels need device tensors (there is no CPU fallback)")
+
+
+def workspace(nbytes: int, device, tag: str = "ws") -> torch.Tensor:
+    """Grow-only per-(device, stream, tag) scratch buffer (kernels never allocate)."""
+    key = (str(device), _stream(), tag)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+# --------------------------------------------------------------------------------------------------
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, act=None,
+            out_dtype=torch.bfloat16, residual: Optional[torch.Tensor] = None, out_preact: bool = False,
+            dact_aux: Optional[torch.Tensor] = None, dact=None, alpha: float = 1.0,
+            out: Optional[torch.Tensor] = None):
+    """C = epilogue(a[M,K] @ b[N,K]^T) with a, b bf16.  Returns C (and the bf16 pre-activation if asked)."""
+    _need_cuda(a, b, bias, residual, dact_aux)
+    assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
+    assert a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[1]
+    assert a.stride(1) == 1 and b.stride(1) == 1
+    M, K = a.shape
+    N = b.shape[0]
+    c = out if out is not None else torch.empty((M, N), dtype=out_dtype, device=a.device)
+    pre = torch.empty((M, N), dtype=torch.bfloat16, device=a.device) if out_preact else None
+    args = GemmArgs()
+    args.A, args.lda = a.data_ptr(), a.stride(0)
+    args.B, args.ldb = b.data_ptr(), b.stride(0)
+    args.C, args.ldc, args.c_dtype = c.data_ptr(), c.stride(0), _dt(c)
+    args.M, args.N, args.K = M, N, K
+    args.bias = ptr(bias)
+    args.act = ACT[act]
+    args.out_preact, args.ldp = ptr(pre), (pre.stride(0) if pre is not None else 0)
+    args.dact_aux, args.ldd = ptr(dact_aux), (dact_aux.stride(0) if dact_aux is not None else 0)
+    args.dact = ACT[dact]
+    if residual is not None:
+        args.residual, args.ldr, args.r_dtype = residual.data_ptr(), residual.stride(0), _dt(residual)
+    else:
+        args.residual, args.ldr, args.r_dtype = None, 0, 0
+    args.alpha = alpha
+    check(_lib().clipk_gemm_nt(C.byref(args), _stream()), "clipk_gemm_nt")
+    return (c, pre) if out_preact else c
+
+
+def gemm_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: Optional[torch.Tensor] = None,
+               dbias: Optional[torch.Tensor] = None, accumulate: bool = False, want_bias: bool = False):
+    """dW[N,K] (+)= dy[M,N]^T @ x[M,K] (f32), optionally db[N] = colsum(dy)."""
+    _need_cuda(dy, x)
+    assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
+    M, N = dy.shape
+    K = x.shape[1]
+    if dw is None:
+        dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+        accumulate = False
+    if want_bias and dbias is None:
+        dbias = torch.empty((N,), dtype=torch.float32, device=dy.device)
+    lib = _lib()
+    nbytes = lib.clipk_gemm_wgrad_workspace(M, N, K)
+    ws = workspace(nbytes, dy.device, "wgrad")
+    check(lib.clipk_gemm_wgrad(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(), dw.stride(0),
+                               ptr(dbias), M, N, K, int(accumulate), ws.data_ptr(), ws.numel(), _stream()),
+          "clipk_gemm_wgrad")
+    return dw, dbias
+
+
+# --------------------------------------------------------------------------------------------------
+def simce_lse(x, y, scale, label_offset=0, cache=None):
+    """lse[i] = logsumexp_j scale*<x_i, keys_j>, pos[i] = scale*<x_i, y_{label_offset+i}>."""
+    _need_cuda(x, y, scale, cache)
+    assert x.dtype == torch.float32 and y.dtype == torch.float32 and x.is_contiguous() and y.is_contiguous()
+    Mx, P = x.shape
+    Ny = y.shape[0]
+    Nc = 0 if cache is None else cache.shape[0]
+    lse = torch.empty(Mx, dtype=torch.float32, device=x.device)
+    pos = torch.zeros(Mx, dtype=torch.float32, device=x.device)
+    lib = _lib()
+    nbytes = lib.clipk_simce_workspace(Mx, Ny + Nc, P)
+    if nbytes == 0:
+        raise _ffi.ClipkError(f"simce: unsupported shape Mx={Mx} Nkeys={Ny + Nc} P={P}")
+    ws = workspace(nbytes, x.device, "simce")
+    check(lib.clipk_simce_lse(x.data_ptr(), Mx, y.data_ptr(), Ny, ptr(cache), Nc, P, scale.data_ptr(), label_offset,
+                              lse.data_ptr(), pos.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "clipk_simce_lse")
+    return lse, pos
+
+
+def simce_grad(x, y, scale, lse_x, lse_y, w_row, w_col, inv_bg, label_offset=0, cache=None):
+    _need_cuda(x, y, scale, lse_x, lse_y, cache)
+    Mx, P = x.shape
+    Ny = y.shape[0]
+    Nc = 0 if cache is None else cache.shape[0]
+    dx = torch.empty_like(x)
+    dsc = torch.empty(Mx, dtype=torch.float32, device=x.device)
+    lib = _lib()
+    nbytes = lib.clipk_simce_workspace(Mx, Ny + Nc, P)
+    ws = workspace(nbytes, x.device, "simce")
+    check(lib.clipk_simce_grad(x.data_ptr(), Mx, y.data_ptr(), Ny, ptr(cache), Nc, P, scale.data_ptr(), label_offset,
+                               lse_x.data_ptr(), lse_y.data_ptr(), float(w_row), float(w_col), float(inv_bg),
+                               dx.data_ptr(), dsc.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "clipk_simce_grad")
+    return dx, dsc
+
+
+def sim_logits(x, y, scale):
+    _need_cuda(x, y, scale)
+    Mx, P = x.shape
+    Ny = y.shape[0]
+    s = torch.empty((Mx, Ny), dtype=torch.float32, device=x.device)
+    check(_lib().clipk_sim_logits(x.data_ptr(), Mx, y.data_ptr(), Ny, P, scale.data_ptr(), s.data_ptr(), s.stride(0),
+                                  _stream()), "clipk_sim_logits")
+    return s
+
+
+# --------------------------------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, eps, act=None, want_f32=True, want_bf16=False, want_stats=True):
+    _need_cuda(x, gamma, beta)
+    rows, cols = x.shape
+    y32 = torch.empty((rows, cols), dtype=torch.float32, device=x.device) if want_f32 else None
+    y16 = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if want_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if want_stats else None
+    check(_lib().clipk_layernorm_fwd(x.data_ptr(), _dt(x), x.stride(0), gamma.data_ptr(), beta.data_ptr(), float(eps),
+                                     ACT[act], ptr(y32), ptr(y16), cols, ptr(mean), ptr(rstd), rows, cols, _stream()),
+          "clipk_layernorm_fwd")
+    return y32, y16, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=None, dx_add=None, want_f32=True, want_bf16=False,
+                  dgamma=None, dbeta=None, accumulate=False):
+    _need_cuda(dy, x, gamma, mean, rstd)
+    rows, cols = x.shape
+    dx32 = torch.empty((rows, cols), dtype=torch.float32, device=x.device) if want_f32 else None
+    dx16 = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    if dgamma is None:
+        dgamma = torch.empty(cols, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(cols, dtype=torch.float32, device=x.device)
+        accumulate = False
+    lib = _lib()
+    nbytes = lib.clipk_layernorm_bwd_workspace(rows, cols)
+    ws = workspace(nbytes, x.device, "ln")
+    check(lib.clipk_layernorm_bwd(dy.data_ptr(), _dt(dy), dy.stride(0), x.data_ptr(), _dt(x), x.stride(0),
+                                  gamma.data_ptr(), ptr(beta), mean.data_ptr(), rstd.data_ptr(), ACT[act], ptr(dx_add),
+                                  ptr(dx32), ptr(dx16), cols, dgamma.data_ptr(), dbeta.data_ptr(), int(accumulate),
+                                  rows, cols, ws.data_ptr(), ws.numel(), _stream()), "clipk_layernorm_bwd")
+    return dx32, dx16, dgamma, dbeta
+
+
+def l2norm_fwd(x, eps=1e-12):
+    _need_cuda(x)
+    rows, cols = x.shape
+    y = torch.empty_like(x)
+    n = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(_lib().clipk_l2norm_fwd(x.data_ptr(), y.data_ptr(), n.data_ptr(), rows, cols, eps, _stream()), "clipk_l2norm_fwd")
+    return y, n
+
+
+def l2norm_bwd(dy, y, n, eps=1e-12):
+    rows, cols = y.shape
+    dx = torch.empty_like(y)
+    check(_lib().clipk_l2norm_bwd(dy.data_ptr(), y.data_ptr(), n.data_ptr(), dx.data_ptr(), rows, cols, eps, _stream()),
+          "clipk_l2norm_bwd")
+    return dx
+
+
+# --------------------------------------------------------------------------------------------------
+def to_bf16(x: torch.Tensor) -> torch.Tensor:
+    _need_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(_lib().clipk_cast_f32_to_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "clipk_cast_f32_to_bf16")
+    return y
+
+
+def to_f32(x: torch.Tensor) -> torch.Tensor:
+    _need_cuda(x)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(_lib().clipk_cast_bf16_to_f32(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "clipk_cast_bf16_to_f32")
+    return y
+
+
+def cast_transpose(w: torch.Tensor, want_w=True, want_wt=True, w_out=None, wt_out=None):
+    _need_cuda(w)
+    rows, cols = w.shape
+    wb = w_out if w_out is not None else (torch.empty((rows, cols), dtype=torch.bfloat16, device=w.device) if want_w else None)
+    wt = wt_out if wt_out is not None else (torch.empty((cols, rows), dtype=torch.bfloat16, device=w.device) if want_wt else None)
+    check(_lib().clipk_cast_transpose(w.data_ptr(), ptr(wb), ptr(wt), rows, cols, _stream()), "clipk_cast_transpose")
+    return wb, wt
+
+
+def act_fwd(x, act):
+    y = torch.empty_like(x)
+    check(_lib().clipk_act_fwd(x.data_ptr(), y.data_ptr(), ACT[act], x.numel(), _stream()), "clipk_act_fwd")
+    return y
+
+
+def act_bwd(dy, x, act):
+    dx = torch.empty_like(x)
+    check(_lib().clipk_act_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), ACT[act], x.numel(), _stream()), "clipk_act_bwd")
+    return dx
+
+
+def axpby_dev(a, b, s):
+    y = torch.empty_like(a)
+    check(_lib().clipk_axpby_dev(a.data_ptr(), b.data_ptr(), s.data_ptr(), y.data_ptr(), a.numel(), _stream()),
+          "clipk_axpby_dev")
+    return y
+
+
+# --------------------------------------------------------------------------------------------------
+def attn_fwd(qkv, B, L, H, D, key_mask=None, rope=None, q_scale=1.0):
+    _need_cuda(qkv, key_mask)
+    assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous() and qkv.shape == (B * L, 3 * H * D)
+    out = torch.empty((B * L, H * D), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
+    cos, sin = rope if rope is not None else (None, None)
+    check(_lib().clipk_attn_fwd(qkv.data_ptr(), ptr(key_mask), ptr(cos), ptr(sin), out.data_ptr(), lse.data_ptr(),
+                                B, L, H, D, float(q_scale), _stream()), "clipk_attn_fwd")
+    return out, lse
+
+
+def attn_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=None, rope=None, q_scale=1.0):
+    _need_cuda(qkv, out, dout, lse)
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
+    cos, sin = rope if rope is not None else (None, None)
+    check(_lib().clipk_attn_bwd(qkv.data_ptr(), ptr(key_mask), ptr(cos), ptr(sin), out.data_ptr(), dout.data_ptr(),
+                                lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), B, L, H, D, float(q_scale), _stream()),
+          "clipk_attn_bwd")
+    return dqkv
+
+
+# --------------------------------------------------------------------------------------------------
+def embed_fwd(ids, table, row_scale=None, mask=None, mask_token_id=-1):
+    _need_cuda(ids, table)
+    B, L = ids.shape
+    d = table.shape[1]
+    x = torch.empty((B * L, d), dtype=torch.float32, device=table.device)
+    check(_lib().clipk_embed_fwd(ids.data_ptr(), table.data_ptr(), ptr(row_scale), ptr(mask), mask_token_id, x.data_ptr(),
+                                 B, L, d, _stream()), "clipk_embed_fwd")
+    return x
+
+
+def embed_bwd(ids, dx, dtable, row_scale=None, mask=None, mask_token_id=-1):
+    B, L = ids.shape
+    V, d = dtable.shape
+    check(_lib().clipk_embed_bwd(ids.data_ptr(), dx.data_ptr(), ptr(row_scale), ptr(mask), mask_token_id,
+                                 dtable.data_ptr(), B, L, d, V, _stream()), "clipk_embed_bwd")
+    return dtable
+
+
+def pool_fwd(x, B, L, mask=None, mode=1):
+    d = x.shape[-1]
+    y = torch.empty((B, d), dtype=torch.float32, device=x.device)
+    check(_lib().clipk_pool_fwd(x.data_ptr(), ptr(mask), y.data_ptr(), B, L, d, mode, _stream()), "clipk_pool_fwd")
+    return y
+
+
+def pool_bwd(dy, B, L, mask=None, mode=1):
+    d = dy.shape[-1]
+    dx = torch.empty((B * L, d), dtype=torch.float32, device=dy.device)
+    check(_lib().clipk_pool_bwd(dy.data_ptr(), ptr(mask), dx.data_ptr(), B, L, d, mode, _stream()), "clipk_pool_bwd")
+    return dx
+
+
+# --------------------------------------------------------------------------------------------------
+def sumsq(g: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _need_cuda(g)
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=g.device)
+    lib = _lib()
+    ws = workspace(lib.clipk_sumsq_workspace(g.numel()), g.device, "sumsq")
+    check(lib.clipk_sumsq(g.data_ptr(), g.numel(), out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "clipk_sumsq")
+    return out
+
+
+def adamw_step(w, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq=None, max_norm=0.0,
+               grad_scale=1.0, w_bf16=None):
+    _need_cuda(w, g, m, v)
+    check(_lib().clipk_adamw_step(w.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), ptr(w_bf16), w.numel(),
+                                  float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+                                  ptr(grad_norm_sq), float(max_norm), float(grad_scale), _stream()), "clipk_adamw_step")

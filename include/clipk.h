@@ -1,0 +1,204 @@
+/*
+ * clipk.h — C ABI of libclipk.so: the MI355X (gfx950 / CDNA4) kernels behind the CLIP-style
+ * dual-encoder contrastive path of SrikarK-code/clip-dplm.
+ *
+ * The reference has NO FFI / operator boundary of its own: its boundary is the Python
+ * nn.Module API of old/clip.py.  Each entry point below therefore cites the ATen call site(s) in the
+ * reference that it replaces; the Python mirror of the module API lives in clip_dplm_amd/ and binds these
+ * symbols through ctypes (clip_dplm_amd/_ffi.py).  INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions (every entry point):
+ *   - extern "C", plain device pointers + sizes, no torch types;
+ *   - returns CLIPK_OK (0) or a negative clipk_status; never throws, never allocates, never syncs;
+ *   - enqueues on the caller's hipStream_t (passed as void*), so ordering is the caller's stream order;
+ *   - every buffer (outputs, workspaces) is owned by the caller; workspace sizes come from
+ *     clipk_*_workspace() helpers; stateless and re-entrant;
+ *   - bf16 tensors are raw uint16 storage ("bf16"), f32 are float; row-major with explicit leading
+ *     dimensions in ELEMENTS.
+ */
+#ifndef CLIPK_H
+#define CLIPK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum clipk_status {
+  CLIPK_OK = 0,
+  CLIPK_ERR_BAD_ARG = -1,       /* null pointer / non-positive dim / misaligned pointer            */
+  CLIPK_ERR_UNSUPPORTED = -2,   /* shape outside what the kernels tile (see each entry point)       */
+  CLIPK_ERR_LAUNCH = -3         /* hipGetLastError() != hipSuccess after the launch                 */
+} clipk_status;
+
+typedef enum clipk_dtype { CLIPK_BF16 = 0, CLIPK_F32 = 1 } clipk_dtype;
+typedef enum clipk_act { CLIPK_ACT_NONE = 0, CLIPK_ACT_RELU = 1, CLIPK_ACT_GELU = 2 } clipk_act;
+
+int clipk_version(void);          /* ABI version, bumped on any signature change */
+const char* clipk_arch(void);     /* "gfx950" */
+const char* clipk_status_string(int status);
+
+/* ------------------------------------------------------------------------------------------------
+ * Linear (GEMM + fused epilogue), bf16 MFMA, f32 accumulate.
+ *   C[M,N] = epilogue( A[M,K] · B[N,K]^T )
+ *   epilogue(v) : v += bias[n];  if out_preact: out_preact = v (bf16);  v = act(v);
+ *                 if dact_aux: v *= act'(dact_aux[m,n]);  if residual: v += residual[m,n];  C = v
+ * Replaces nn.Linear (+ReLU/GELU, + residual add) at old/clip.py:11,16,27,29,31; the QKV / out-proj /
+ * FFN Linear layers of nn.TransformerEncoderLayer (current/rna_clip_codes.ipynb:1915) and of the
+ * third-party EsmLayer (transformers modeling_esm.py:362-374,517-521) called at
+ * triple_flow/3_esm_integration.py:118-119.  With B = W^T (a [K_out,N_in] copy) it is the input
+ * gradient dX = dY·W of the same layers.
+ * Requirements: K % 8 == 0, N % 8 == 0, lda/ldb/ldc/... % 8 == 0, pointers 16-byte aligned.
+ */
+typedef struct clipk_gemm_args {
+  const void* A; int64_t lda;          /* bf16 [M,K]                                       */
+  const void* B; int64_t ldb;          /* bf16 [N,K]  (nn.Linear weight layout)            */
+  void* C; int64_t ldc; int c_dtype;   /* bf16 or f32 [M,N]                                */
+  int M, N, K;
+  const float* bias;                   /* f32 [N] or NULL                                  */
+  int act;                             /* clipk_act applied after bias                     */
+  void* out_preact; int64_t ldp;       /* optional bf16 [M,N]: value before activation     */
+  const void* dact_aux; int64_t ldd;   /* optional bf16 [M,N]: multiply by act'(aux)       */
+  int dact;                            /* clipk_act whose derivative is applied to aux     */
+  const void* residual; int64_t ldr; int r_dtype; /* optional [M,N] bf16/f32, added last   */
+  float alpha;                         /* scale applied to the raw product before bias     */
+} clipk_gemm_args;
+int clipk_gemm_nt(const clipk_gemm_args* args, void* stream);
+
+/* Weight gradient: dW[N,K] (+)= dY[M,N]^T · X[M,K]   (contraction over the M tokens), f32 output.
+ * Replaces autograd's mm(dY^T, X) for every nn.Linear above.  Split over M with per-split f32 slabs in
+ * `workspace` followed by a deterministic reduce (no float atomics).  Also emits db[N] = colsum(dY)
+ * when dbias != NULL.  accumulate != 0 adds into dW/dbias instead of overwriting.
+ * Requirements: N % 8 == 0, K % 8 == 0. */
+size_t clipk_gemm_wgrad_workspace(int M, int N, int K);
+int clipk_gemm_wgrad(const void* dY, int64_t lddy, const void* X, int64_t ldx,
+                     float* dW, int64_t lddw, float* dbias,
+                     int M, int N, int K, int accumulate,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused similarity + cross-entropy ("simce"), exact-f32 MFMA (v_mfma_f32_32x32x2_f32), never
+ * materialises the logits.
+ *   S[i,j] = scale * <X[i,:], Y[j,:]>,  label(i) = label_offset + i
+ *   lse[i] = log sum_j exp(S[i,j])  over the Ny keys of Y plus the Nc keys of Yc (cache negatives)
+ *   pos[i] = S[i, label(i)]
+ * Replaces matmul(a, b.t()) * logit_scale + cross_entropy at old/clip.py:66-67 + old/ablation.py:16,
+ * current/rna_clip_codes.ipynb:1950-1953 (both directions: call twice with X/Y swapped) and
+ * old/clip_opt.py:115-121,130-151 (cache columns).  Rows of X are this rank's samples, Y holds the
+ * all-gathered batch (old/clip_opt.py:102-112).
+ * Requirements: P % 4 == 0, P <= 768.  workspace: clipk_simce_workspace(Mx, Ny + Nc, P) bytes (covers both
+ * clipk_simce_lse and clipk_simce_grad). */
+size_t clipk_simce_workspace(int Mx, int Nkeys, int P);
+int clipk_simce_lse(const float* X, int Mx, const float* Y, int Ny, const float* Yc, int Nc,
+                    int P, const float* scale /* device scalar = exp(logit_scale), clamped by caller */,
+                    int label_offset, float* lse /*[Mx]*/, float* pos /*[Mx]*/,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* Gradient of  L = (w_row * sum_i (lse_row[i] - pos[i]) + w_col * sum_j (lse_col[j] - pos[j])) / Bg
+ * with respect to X rows (this rank's rows of one modality):
+ *   G[i,j] = ( w_row * exp(S[i,j]-lse_x[i]) + w_col * exp(S[i,j]-lse_y[j]) - (w_row+w_col)*[j==label(i)] ) / Bg
+ *   dX[i,:] = scale * sum_j G[i,j] * Y[j,:]  (+ cache keys: only the w_row term, no positives)
+ *   dscale_partial[i] = sum_j G[i,j] * <X[i],Y[j]>       (d/d scale; caller multiplies by scale for
+ *                                                        d/d logit_scale and halves the double count)
+ * lse_x: [Mx] LSE of the rows of X over all keys;  lse_y: [Ny] LSE of each key over all queries
+ * (the other direction), all-gathered across ranks by the caller. */
+int clipk_simce_grad(const float* X, int Mx, const float* Y, int Ny, const float* Yc, int Nc,
+                     int P, const float* scale, int label_offset,
+                     const float* lse_x, const float* lse_y, float w_row, float w_col, float inv_bg,
+                     float* dX /*[Mx,P]*/, float* dscale_partial /*[Mx]*/,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* Materialised logits for the drop-in module API (old/clip.py:67 returns them):
+ *   S[Mx,Ny] = scale * X·Y^T, exact f32. */
+int clipk_sim_logits(const float* X, int Mx, const float* Y, int Ny, int P, const float* scale,
+                     float* S, int64_t lds, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row-wise normalisation kernels (one wave per row, f32 statistics).
+ * LayerNorm forward:  y = (x-mean)*rstd*gamma + beta, optional activation fused after it
+ * (old/clip.py:12,28-29,32; transformer / ESM LayerNorms).  x is f32 or bf16; writes any of
+ * y_f32 / y_bf16 (NULL to skip) and mean/rstd [rows] for the backward.
+ */
+int clipk_layernorm_fwd(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta,
+                        float eps, int act, float* y_f32, void* y_bf16, int64_t ldy,
+                        float* mean, float* rstd, int rows, int cols, void* stream);
+/* LayerNorm backward: dx (f32 and/or bf16), and per-block partial dgamma/dbeta in workspace followed
+ * by a deterministic column reduce into dgamma/dbeta (accumulate flag as above).  If act != NONE the
+ * incoming dy is first multiplied by act'(ln_out) where ln_out is recomputed from x, mean, rstd.
+ * dx_add: optional f32 [rows,cols] added to the result (residual-stream gradient). */
+size_t clipk_layernorm_bwd_workspace(int rows, int cols);
+int clipk_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, const void* x, int x_dtype, int64_t ldx,
+                        const float* gamma, const float* beta, const float* mean, const float* rstd, int act,
+                        const float* dx_add, float* dx_f32, void* dx_bf16, int64_t lddx,
+                        float* dgamma, float* dbeta, int accumulate,
+                        int rows, int cols, void* workspace, size_t workspace_bytes, void* stream);
+
+/* F.normalize(x, dim=-1) with eps=1e-12 (old/clip.py:63-64): y = x / max(||x||, eps); f32. */
+int clipk_l2norm_fwd(const float* x, float* y, float* norm, int rows, int cols, float eps, void* stream);
+int clipk_l2norm_bwd(const float* dy, const float* y, const float* norm, float* dx,
+                     int rows, int cols, float eps, void* stream);
+
+/* Elementwise helpers on f32/bf16 buffers (n elements, n % 8 == 0 not required). */
+int clipk_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
+int clipk_cast_bf16_to_f32(const void* x, float* y, int64_t n, void* stream);
+/* W f32 [rows,cols] -> bf16 copy and bf16 transposed copy [cols,rows] (either may be NULL). */
+int clipk_cast_transpose(const float* w, void* w_bf16, void* wt_bf16, int rows, int cols, void* stream);
+/* y = act(x) / dx = dy * act'(x) on f32. */
+int clipk_act_fwd(const float* x, float* y, int act, int64_t n, void* stream);
+int clipk_act_bwd(const float* dy, const float* x, float* dx, int act, int64_t n, void* stream);
+/* y = a + s[0] * b  (skip + layer_scale * projected, old/clip_opt.py:41-44), f32. */
+int clipk_axpby_dev(const float* a, const float* b, const float* s, float* y, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-head self-attention, flash style (no LxL matrix in HBM), bf16 MFMA, f32 softmax.
+ * qkv: bf16 [B*L, 3*H*D] rows = tokens (b-major), columns = [q heads | k heads | v heads];
+ * key_mask: uint8 [B, L], 1 = valid key, or NULL; rope_cos/sin: f32 [L, D/2] or NULL (ESM-2 rotary,
+ * rotate-half, applied to q and k after q *= q_scale — transformers modeling_esm.py:48-52,74-79,374);
+ * out: bf16 [B*L, H*D]; lse: f32 [B, H, L] (log-sum-exp of the scaled scores, saved for backward).
+ * Replaces nn.MultiheadAttention inside nn.TransformerEncoderLayer (rna_clip_codes.ipynb:1915) and
+ * EsmSelfAttention (modeling_esm.py:306-314,362-384).  D in {8..160}, D % 8 == 0.
+ */
+int clipk_attn_fwd(const void* qkv, const uint8_t* key_mask, const float* rope_cos, const float* rope_sin,
+                   void* out, float* lse, int B, int L, int H, int D, float q_scale, void* stream);
+/* Backward: dqkv bf16 [B*L, 3*H*D] from dout bf16 [B*L, H*D]; recomputes P from qkv + lse.
+ * delta: f32 [B,H,L] scratch (rowsum(dout*out)) provided by the caller. */
+int clipk_attn_bwd(const void* qkv, const uint8_t* key_mask, const float* rope_cos, const float* rope_sin,
+                   const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                   int B, int L, int H, int D, float q_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Token embedding (ESM-2): x[t,:] = table[ids[t],:] * scale[b] * mask[t], with the token-dropout
+ * rescale (modeling_esm.py:252-268) folded into row_scale[B] by the caller.  f32 out.
+ */
+int clipk_embed_fwd(const int64_t* ids, const float* table, const float* row_scale /*[B] or NULL*/,
+                    const uint8_t* mask /*[B*L] or NULL*/, int mask_token_id,
+                    float* x, int B, int L, int d, void* stream);
+int clipk_embed_bwd(const int64_t* ids, const float* dx, const float* row_scale, const uint8_t* mask,
+                    int mask_token_id, float* dtable /* [V,d], accumulated */, int B, int L, int d, int V,
+                    void* stream);
+
+/* Pooling over the sequence: mode 0 = position 0 (rna_clip_codes.ipynb:1948), 1 = masked mean
+ * (configuration_hybrid_clip.py:109 use_mean_pooling).  x f32 [B,L,d] -> y f32 [B,d]. */
+int clipk_pool_fwd(const float* x, const uint8_t* mask, float* y, int B, int L, int d, int mode, void* stream);
+int clipk_pool_bwd(const float* dy, const uint8_t* mask, float* dx, int B, int L, int d, int mode, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser step on flat f32 buffers: AdamW (decoupled weight decay, torch.optim.AdamW semantics,
+ * rna_clip_codes.ipynb:2033) with the global-norm clip of clip_grad_norm_ (ipynb:2076) folded in:
+ *   sumsq kernel -> grad_norm_sq[0] (device), then the update reads it to compute the clip factor.
+ * wd_mask: per-element 0/1 float or NULL (all decayed).  Also refreshes the bf16 weight copy.
+ */
+size_t clipk_sumsq_workspace(int64_t n);
+int clipk_sumsq(const float* g, int64_t n, float* out /* device scalar, overwritten */,
+                void* workspace, size_t workspace_bytes, void* stream);
+int clipk_adamw_step(float* w, const float* g, float* m, float* v, void* w_bf16 /* or NULL */,
+                     int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                     int step, const float* grad_norm_sq /* device scalar or NULL */, float max_norm,
+                     float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLIPK_H */
