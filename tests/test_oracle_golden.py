@@ -1,0 +1,121 @@
+"""CPU: the oracle (oracle/*.py) against the committed golden vectors generated from the reference
+(tools/make_golden.py).  This is what pins the oracle; the GPU parity tests then compare the HIP path
+with the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import clip_ref, encoder_ref
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(G, name))
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}
+    return z, sd
+
+
+def t(z, k):
+    return torch.from_numpy(z[k])
+
+
+def test_clip_c1_kat():
+    z, sd = load("clip_c1.npz")
+    o = clip_ref.rna_protein_clip_forward(sd, t(z, "rna"), t(z, "protein"))
+    logits = o["logits_per_rna_protein"]
+    assert torch.allclose(logits, t(z, "logits"), atol=2e-5)
+    assert torch.allclose(o["rna_embeds"], t(z, "rna_embeds"), atol=1e-6)
+    # known answers recorded in SURVEY.md §8c / BASELINE.md §2
+    assert abs(float(z["logit_scale_exp"]) - 14.28486) < 1e-4
+    assert abs(clip_ref.ce_diag(logits).item() - 5.915865) < 1e-5
+    assert abs(clip_ref.clip_loss_symmetric(logits).item() - 5.939782) < 1e-5
+    assert abs(clip_ref.ce_diag(logits).item() - float(z["loss_one_sided"])) < 1e-6
+    assert torch.allclose(o["rna_embeds"].norm(dim=-1), torch.ones(256), atol=1e-6)
+
+
+def test_clip_c1_param_grads():
+    z, sd = load("clip_c1.npz")
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    o = clip_ref.rna_protein_clip_forward(sd, t(z, "rna"), t(z, "protein"))
+    clip_ref.clip_loss_symmetric(o["logits_per_rna_protein"]).backward()
+    for k, v in sd.items():
+        ref = t(z, "g:" + k)
+        assert torch.allclose(v.grad, ref, rtol=1e-4, atol=1e-6), k
+
+
+def test_clip_diffmap():
+    z, sd = load("clip_diffmap.npz")
+    o = clip_ref.rna_protein_clip_forward(sd, t(z, "diffmap"), t(z, "protein"), a="diffmap", b="protein",
+                                          num_layers=(1, 3), eps=(1e-12, 1e-5))
+    assert torch.allclose(o["logits_per_diffmap_protein"], t(z, "logits"), atol=2e-5)
+
+
+def test_clip_opt_cache_loss():
+    z, sd = load("clip_opt.npz")
+    o = clip_ref.optimized_clip_forward(sd, t(z, "diffmap"), t(z, "protein"), t(z, "cache"))
+    assert torch.allclose(o["logits_per_diffmap_protein"], t(z, "logits"), atol=2e-5)
+    assert torch.allclose(o["logits_per_diffmap_cache"], t(z, "logits_cache"), atol=2e-5)
+    assert abs(clip_ref.optimized_clip_loss(o).item() - float(z["loss"])) < 1e-5
+
+
+@pytest.mark.parametrize("act", ["relu", "gelu"])
+def test_transformer_layer(act):
+    z, sd = load(f"tlayer_{act}.npz")
+    x = t(z, "x").requires_grad_(True)
+    valid = t(z, "valid")
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    y = encoder_ref.post_ln_layer(x, sdg, "l", 8, valid, act, 1e-12)
+    m = valid[..., None]
+    assert torch.allclose(y * m, t(z, "y") * m, atol=2e-5)
+    (y * t(z, "dy")).sum().backward()
+    assert torch.allclose(x.grad, t(z, "dx"), rtol=1e-4, atol=2e-5)
+    for k, v in sdg.items():
+        assert torch.allclose(v.grad, t(z, "g:" + k), rtol=1e-3, atol=5e-5), k
+
+
+def test_notebook_model_batch_axis_attention():
+    """The notebook's (B,L,D)-into-batch_first=False quirk reproduced by the oracle."""
+    z, sd = load("notebook_model.npz")
+
+    def enc(x, prefix):
+        valid = ~torch.isnan(x).any(-1)
+        xt = torch.nan_to_num(x, 0.0).transpose(0, 1)
+        y = encoder_ref.post_ln_encoder(xt, sd, prefix, 3, 8, valid.transpose(0, 1), "relu", 1e-5, 1e-5)
+        return y.transpose(0, 1)[:, 0]
+    a = clip_ref.l2_normalize(clip_ref.optimized_projection_head(enc(t(z, "rna"), "rna_encoder"), sd, "rna_projection"))
+    b = clip_ref.l2_normalize(clip_ref.optimized_projection_head(enc(t(z, "rbp"), "rbp_encoder"), sd, "rbp_projection"))
+    assert torch.allclose(a, t(z, "rna_embed"), atol=2e-5)
+    assert torch.allclose(b, t(z, "rbp_embed"), atol=2e-5)
+    loss = clip_ref.clip_loss_symmetric((a @ b.t()) * sd["logit_scale"].exp())
+    assert abs(loss.item() - float(z["loss"])) < 2e-5
+
+
+def test_esm_tiny_forward_and_grads():
+    z, sd = load("esm_tiny.npz")
+    ids, am = t(z, "ids"), t(z, "attention_mask")
+    sdg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    y = encoder_ref.esm_encoder(ids, am, sdg, 2, 4, 1e-5)
+    m = am[..., None].float()
+    assert torch.allclose(y * m, t(z, "last_hidden_state") * m, atol=3e-5)
+    zg = np.load(os.path.join(G, "esm_tiny_grads.npz"))
+    (y * torch.from_numpy(zg["dy"])).sum().backward()
+    checked = 0
+    for k, v in sdg.items():
+        if not v.is_floating_point() or ("g:" + k) not in zg.files or zg["g:" + k].size == 0:
+            continue
+        assert torch.allclose(v.grad, torch.from_numpy(zg["g:" + k]), rtol=2e-3, atol=2e-4), k
+        checked += 1
+    assert checked > 30
+
+
+def test_analytic_properties():
+    """Loss at random init ~ ln B; symmetric loss invariant under swapping modalities."""
+    g = torch.Generator().manual_seed(0)
+    a = clip_ref.l2_normalize(torch.randn(64, 32, generator=g))
+    b = clip_ref.l2_normalize(torch.randn(64, 32, generator=g))
+    s = (a @ b.t()) * 14.2849
+    assert abs(clip_ref.clip_loss_symmetric(s).item() - clip_ref.clip_loss_symmetric(s.t()).item()) < 1e-6
+    assert abs(clip_ref.clip_loss_symmetric(s * 0).item() - np.log(64)) < 1e-6

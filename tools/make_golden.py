@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE itself.
+
+Run only in the build container (needs /root/reference and the third-party `transformers` package the
+reference calls for ESM-2).  Nothing from the reference is copied: the fixtures are data — seeded weights,
+inputs and the reference's outputs — stored as .npz.  Import recipe: SURVEY.md Appendix B.
+
+    python tools/make_golden.py            # writes tests/golden/*.npz and checks the oracle against each
+"""
+from __future__ import annotations
+
+import importlib.util
+import json
+import os
+import sys
+from types import SimpleNamespace as NS
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(4)
+
+from oracle import clip_ref, encoder_ref  # noqa: E402
+
+
+def sd_np(module_or_sd, prefix="w:"):
+    sd = module_or_sd.state_dict() if hasattr(module_or_sd, "state_dict") else module_or_sd
+    return {prefix + k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def sub(h, n=2, eps=1e-12):
+    return NS(hidden_size=h, num_hidden_layers=n, layer_norm_eps=eps)
+
+
+def check(name, a, b, tol=1e-5):
+    err = (a - b).abs().max().item()
+    print(f"  oracle vs reference [{name}]: max abs err {err:.3e}")
+    assert err <= tol, (name, err)
+
+
+# ------------------------------------------------------------------------------------------------ old/clip.py
+def gen_clip_c1():
+    sys.path[:0] = [REF + "/run1", REF + "/old"]
+    import clip as refclip
+    cfg = NS(rna_config=sub(128), protein_config=sub(128), diffmap_config=sub(128), projection_dim=128,
+             logit_scale_init_value=2.6592, cache_size=8192)
+    torch.manual_seed(0)
+    m = refclip.RNAProteinCLIPModule(cfg).eval()
+    g = torch.Generator().manual_seed(1234)
+    a, b = torch.randn(256, 128, generator=g), torch.randn(256, 128, generator=g)
+    out = m(a, b)
+    logits = out["logits_per_rna_protein"]
+    lab = torch.arange(256)
+    l1 = F.cross_entropy(logits, lab)
+    l2 = 0.5 * (F.cross_entropy(logits, lab) + F.cross_entropy(logits.t(), lab))
+    grads = torch.autograd.grad(l2, list(m.parameters()))
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    o = clip_ref.rna_protein_clip_forward(sd, a, b)
+    check("C1 logits", o["logits_per_rna_protein"], logits.detach(), 2e-5)
+    check("C1 sym loss", clip_ref.clip_loss_symmetric(o["logits_per_rna_protein"]), l2.detach(), 1e-6)
+    arrays = sd_np(m)
+    arrays.update({"g:" + n: gr.numpy() for (n, _), gr in zip(m.named_parameters(), grads)})
+    save("clip_c1.npz", rna=a.numpy(), protein=b.numpy(), logits=logits.detach().numpy(),
+         rna_embeds=out["rna_embeds"].detach().numpy(), protein_embeds=out["protein_embeds"].detach().numpy(),
+         loss_one_sided=l1.item(), loss_symmetric=l2.item(), logit_scale_exp=m.logit_scale.exp().item(), **arrays)
+    # DiffMap pairing (old/clip.py:75-110), smaller
+    torch.manual_seed(1)
+    cfg2 = NS(rna_config=sub(64), protein_config=sub(96, 3, 1e-5), diffmap_config=sub(64, 1), projection_dim=32,
+              logit_scale_init_value=2.6592)
+    m2 = refclip.DiffMapProteinCLIPModule(cfg2).eval()
+    a2, b2 = torch.randn(40, 64, generator=g), torch.randn(40, 96, generator=g)
+    o2 = m2(a2, b2)
+    sd2 = {k: v.detach() for k, v in m2.state_dict().items()}
+    oo = clip_ref.rna_protein_clip_forward(sd2, a2, b2, a="diffmap", b="protein", num_layers=(1, 3), eps=(1e-12, 1e-5))
+    check("diffmap logits", oo["logits_per_diffmap_protein"], o2["logits_per_diffmap_protein"].detach(), 2e-5)
+    save("clip_diffmap.npz", diffmap=a2.numpy(), protein=b2.numpy(),
+         logits=o2["logits_per_diffmap_protein"].detach().numpy(), **sd_np(m2))
+    return refclip
+
+
+def gen_clip_opt(refclip):
+    import clip_opt as refopt
+    refopt.CLIPEncoder = refclip.CLIPEncoder            # App. A-4
+    cfg = NS(diffmap_config=sub(48), protein_config=sub(96), projection_dim=32, cache_size=256)
+    torch.manual_seed(0)
+    m = refopt.OptimizedCLIPModule(cfg).eval()
+    g = torch.Generator().manual_seed(7)
+    # two batches so the cache holds an earlier batch too
+    d0, p0 = torch.randn(32, 48, generator=g), torch.randn(32, 96, generator=g)
+    d1, p1 = torch.randn(32, 48, generator=g), torch.randn(32, 96, generator=g)
+    with torch.no_grad():
+        m(d0, p0, gather_distributed=False)
+        out = m(d1, p1, gather_distributed=False)
+        loss = refopt.optimized_clip_loss(out)
+    cache = m.protein_embedding_cache[: m.cache_ptr].clone()
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    o = clip_ref.optimized_clip_forward(sd, d1, p1, cache)
+    check("opt logits", o["logits_per_diffmap_protein"], out["logits_per_diffmap_protein"], 2e-5)
+    check("opt cache logits", o["logits_per_diffmap_cache"], out["logits_per_diffmap_cache"], 2e-5)
+    check("opt loss", clip_ref.optimized_clip_loss(o), loss, 1e-6)
+    save("clip_opt.npz", diffmap=d1.numpy(), protein=p1.numpy(), cache=cache.numpy(), cache_ptr=m.cache_ptr,
+         logits=out["logits_per_diffmap_protein"].numpy(), logits_cache=out["logits_per_diffmap_cache"].numpy(),
+         loss=loss.item(), **sd_np(m))
+
+
+# ------------------------------------------------------------------------------------------------ notebook
+def gen_notebook():
+    nb = json.load(open(REF + "/current/rna_clip_codes.ipynb"))
+    ns = {"torch": torch, "nn": nn, "F": F, "np": np}
+    for i in (24, 28):
+        exec("".join(nb["cells"][i]["source"]), ns)          # dataset/mask helpers, model classes
+    torch.manual_seed(0)
+    model = ns["RNARBPCLIPModel"](rna_dim=24, rbp_dim=64, projection_dim=32).eval()
+    g = torch.Generator().manual_seed(3)
+    B = 8
+    rna = torch.randn(B, 6, 24, generator=g)
+    rbp = torch.randn(B, 20, 64, generator=g)
+    for i, (lr, lp) in enumerate([(6, 20), (4, 20), (6, 11), (5, 17), (6, 20), (3, 9), (6, 14), (6, 20)]):
+        rna[i, lr:] = float("nan")
+        rbp[i, lp:] = float("nan")
+    with torch.no_grad():
+        ea, eb, loss = model(rna, rbp)
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+
+    # oracle: the notebook feeds (B, L, D) to batch_first=False layers, so attention runs over the batch
+    # axis per position (App. A-8): equivalent to per-"sequence" attention on the transposed tensor.
+    def enc(x, prefix):
+        valid = ~torch.isnan(x).any(-1)                      # [B, L]
+        xt = torch.nan_to_num(x, 0.0).transpose(0, 1)        # [L, B, D]: "batch" = position, "sequence" = sample
+        kv = valid.transpose(0, 1)                           # [L, B] keys = samples
+        y = encoder_ref.post_ln_encoder(xt, sd, prefix, 3, 8, kv, "relu", 1e-5, 1e-5)
+        return y.transpose(0, 1)[:, 0]                       # position 0
+    oa = clip_ref.l2_normalize(clip_ref.optimized_projection_head(enc(rna, "rna_encoder"), sd, "rna_projection"))
+    ob = clip_ref.l2_normalize(clip_ref.optimized_projection_head(enc(rbp, "rbp_encoder"), sd, "rbp_projection"))
+    ol = clip_ref.clip_loss_symmetric((oa @ ob.t()) * sd["logit_scale"].exp())
+    check("notebook rna embed", oa, ea, 2e-5)
+    check("notebook rbp embed", ob, eb, 2e-5)
+    check("notebook loss", ol, loss, 2e-5)
+    save("notebook_model.npz", rna=rna.numpy(), rbp=rbp.numpy(), rna_embed=ea.numpy(), rbp_embed=eb.numpy(),
+         loss=loss.item(), **sd_np(model))
+
+
+# ------------------------------------------------------------------------------------------------ torch layer
+def gen_tlayer():
+    torch.manual_seed(0)
+    E, H, FF, B, L = 64, 8, 128, 4, 24
+    for act in ("relu", "gelu"):
+        layer = nn.TransformerEncoderLayer(E, H, FF, dropout=0.0, activation=act, layer_norm_eps=1e-12).eval()
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(B, L, E, generator=g, requires_grad=True)
+        lens = torch.tensor([24, 17, 9, 24])
+        valid = torch.arange(L)[None] < lens[:, None]
+        y = layer(x.transpose(0, 1), src_key_padding_mask=~valid).transpose(0, 1)    # conventional layout
+        dy = torch.randn(B, L, E, generator=g) * valid[..., None]
+        grads = torch.autograd.grad(y, [x] + list(layer.parameters()), dy)
+        sd = {"l." + k: v.detach() for k, v in layer.state_dict().items()}
+        yo = encoder_ref.post_ln_layer(x.detach(), sd, "l", H, valid, act, 1e-12)
+        check(f"tlayer {act}", yo * valid[..., None], y.detach() * valid[..., None], 2e-5)
+        arrays = {"w:" + k: v.numpy() for k, v in sd.items()}
+        arrays.update({"g:l." + n: gr.numpy() for (n, _), gr in zip(layer.named_parameters(), grads[1:])})
+        save(f"tlayer_{act}.npz", x=x.detach().numpy(), valid=valid.numpy(), y=y.detach().numpy(), dy=dy.numpy(),
+             dx=grads[0].numpy(), **arrays)
+
+
+# ------------------------------------------------------------------------------------------------ ESM-2
+def gen_esm():
+    from transformers import EsmConfig, EsmModel
+    cfg = EsmConfig(vocab_size=33, hidden_size=96, num_hidden_layers=2, num_attention_heads=4, intermediate_size=384,
+                    position_embedding_type="rotary", token_dropout=True, emb_layer_norm_before=False, pad_token_id=1,
+                    mask_token_id=32, layer_norm_eps=1e-5, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    torch.manual_seed(0)
+    m = EsmModel(cfg, add_pooling_layer=False).eval()
+    g = torch.Generator().manual_seed(11)
+    B, L = 4, 40
+    ids = torch.randint(4, 24, (B, L), generator=g)
+    ids[:, 0] = 0
+    lens = [40, 33, 21, 40]
+    am = torch.zeros(B, L, dtype=torch.long)
+    for i, n in enumerate(lens):
+        am[i, :n] = 1
+        ids[i, n - 1] = 2
+        ids[i, n:] = 1
+    ids[1, 5] = 32                                           # one <mask> token: exercises the token-dropout rescale
+    with torch.no_grad():
+        y = m(input_ids=ids, attention_mask=am).last_hidden_state
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    yo = encoder_ref.esm_encoder(ids, am, sd, 2, 4, 1e-5)
+    check("esm tiny", yo * am[..., None], y * am[..., None], 3e-5)
+    save("esm_tiny.npz", ids=ids.numpy(), attention_mask=am.numpy(), last_hidden_state=y.numpy(), **sd_np(sd))
+    # gradient fixture: d(sum(y * dy)) / d params and loss through mean pooling
+    m.train(False)
+    for p in m.parameters():
+        p.requires_grad_(True)
+    dy = torch.randn(B, L, 96, generator=g) * am[..., None]
+    y2 = m(input_ids=ids, attention_mask=am).last_hidden_state
+    grads = torch.autograd.grad((y2 * dy).sum(), [p for p in m.parameters()], allow_unused=True)
+    arrays = {"g:" + n: (gr.numpy() if gr is not None else np.zeros(0)) for (n, _), gr in zip(m.named_parameters(), grads)}
+    save("esm_tiny_grads.npz", dy=dy.numpy(), **arrays)
+
+
+if __name__ == "__main__":
+    rc = gen_clip_c1()
+    gen_clip_opt(rc)
+    gen_notebook()
+    gen_tlayer()
+    gen_esm()
+    print("all golden fixtures written and the oracle agrees with the reference on each")
