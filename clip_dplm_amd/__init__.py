@@ -1,0 +1,23 @@
+"""clip_dplm_amd — MI355X-native (gfx950) CLIP-style dual-encoder contrastive path of SrikarK-code/clip-dplm.
+
+Python mirrors of the reference's module API on top of libclipk.so (hand-written HIP kernels behind the C ABI
+in include/clipk.h).  There is no CPU fallback: every forward needs device tensors and the built library.
+"""
+from .configuration_hybrid_clip import HybridCLIPConfig, ModelArchitectureConfig, SubConfig, TrainingConfig
+from .encoders import ESM2Encoder, ESM2_SHAPES, TransformerSeqEncoder, pool
+from .loss import clip_loss
+from .modeling_clip import (CLIPEncoder, DiffMapProteinCLIP, DiffMapProteinCLIPModule, OptimizedCLIPModule,
+                            OptimizedProjectionHead, ProjectionHead, RNAProteinCLIP, RNAProteinCLIPModule,
+                            optimized_clip_loss)
+from .modeling_seqclip import (ProteinRNACLIP, RNARBPCLIPEncoder, RNARBPCLIPModel, RNARBPCLIPProjectionHead,
+                               create_padding_mask)
+from .optim import FlatParams, FusedAdamW, cosine_annealing_lr
+
+__all__ = [
+    "HybridCLIPConfig", "ModelArchitectureConfig", "TrainingConfig", "SubConfig",
+    "CLIPEncoder", "ProjectionHead", "RNAProteinCLIPModule", "DiffMapProteinCLIPModule", "RNAProteinCLIP",
+    "DiffMapProteinCLIP", "OptimizedProjectionHead", "OptimizedCLIPModule", "optimized_clip_loss",
+    "RNARBPCLIPProjectionHead", "RNARBPCLIPEncoder", "RNARBPCLIPModel", "create_padding_mask", "ProteinRNACLIP",
+    "ESM2Encoder", "ESM2_SHAPES", "TransformerSeqEncoder", "pool", "clip_loss", "FlatParams", "FusedAdamW",
+    "cosine_annealing_lr",
+]

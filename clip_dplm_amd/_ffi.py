@@ -62,6 +62,7 @@ SIGNATURES = {
     "clipk_cast_transpose": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "clipk_act_fwd": (_i, [_vp, _vp, _i, _i64, _vp]),
     "clipk_act_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _vp]),
+    "clipk_dact": (_i, [_vp, _i, _vp, _i, _vp, _i64, _vp]),
     "clipk_axpby_dev": (_i, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "clipk_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "clipk_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),

@@ -80,6 +80,36 @@ __global__ void axpby_dev_kernel(const float* a, const float* b, const float* s,
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) y[i] = a[i] + sc * b[i];
 }
 
+// out_bf16 = dy * act'(aux): the activation backward between two Linear layers (dy f32 or bf16)
+template <bool DYBF16>
+__global__ void dact_kernel(const void* dy, const unsigned short* aux, int act, unsigned short* out, long n) {
+  const long n8 = n >> 3;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += stride) {
+    float d[8];
+    if (DYBF16) {
+      const u32x4 a = reinterpret_cast<const u32x4*>(dy)[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { d[2 * e] = bf16_to_f32(a[e] & 0xffffu); d[2 * e + 1] = bf16_to_f32(a[e] >> 16); }
+    } else {
+      const f32x4 a = reinterpret_cast<const f32x4*>(dy)[2 * i], b = reinterpret_cast<const f32x4*>(dy)[2 * i + 1];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { d[e] = a[e]; d[4 + e] = b[e]; }
+    }
+    const u32x4 x = reinterpret_cast<const u32x4*>(aux)[i];
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      o[e] = pack_bf16x2(d[2 * e] * act_grad(bf16_to_f32(x[e] & 0xffffu), act),
+                         d[2 * e + 1] * act_grad(bf16_to_f32(x[e] >> 16), act));
+    reinterpret_cast<u32x4*>(out)[i] = o;
+  }
+  for (long i = (n8 << 3) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float d = DYBF16 ? bf16_to_f32(reinterpret_cast<const unsigned short*>(dy)[i]) : reinterpret_cast<const float*>(dy)[i];
+    out[i] = f32_to_bf16(d * act_grad(bf16_to_f32(aux[i]), act));
+  }
+}
+
 // ---- embedding ----------------------------------------------------------------------------------
 __global__ void embed_fwd_kernel(const int64_t* ids, const float* table, const float* row_scale, const uint8_t* mask,
                                  int mask_token_id, float* x, int B, int L, int d) {
@@ -238,6 +268,18 @@ extern "C" int clipk_act_fwd(const float* x, float* y, int act, int64_t n, void*
 extern "C" int clipk_act_bwd(const float* dy, const float* x, float* dx, int act, int64_t n, void* stream) {
   if (!dy || !x || !dx || n <= 0) return CLIPK_ERR_BAD_ARG;
   hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, dy, x, dx, act, (long)n);
+  return clipk_check_launch();
+}
+extern "C" int clipk_dact(const void* dy, int dy_dtype, const void* aux_bf16, int act, void* out_bf16, int64_t n,
+                          void* stream) {
+  if (!dy || !aux_bf16 || !out_bf16 || n <= 0 || !aligned16(dy) || !aligned16(aux_bf16) || !aligned16(out_bf16))
+    return CLIPK_ERR_BAD_ARG;
+  if (dy_dtype == CLIPK_BF16)
+    hipLaunchKernelGGL(dact_kernel<true>, dim3(ew_blocks(n / 8 + 1)), dim3(EW_THREADS), 0, (hipStream_t)stream, dy,
+                       (const unsigned short*)aux_bf16, act, (unsigned short*)out_bf16, (long)n);
+  else
+    hipLaunchKernelGGL(dact_kernel<false>, dim3(ew_blocks(n / 8 + 1)), dim3(EW_THREADS), 0, (hipStream_t)stream, dy,
+                       (const unsigned short*)aux_bf16, act, (unsigned short*)out_bf16, (long)n);
   return clipk_check_launch();
 }
 extern "C" int clipk_axpby_dev(const float* a, const float* b, const float* s, float* y, int64_t n, void* stream) {

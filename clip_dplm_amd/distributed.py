@@ -1,0 +1,65 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed backend "nccl" (= RCCL over xGMI on ROCm).
+
+  * init_distributed(): env-var rendezvous + rank->device binding (the reference has neither,
+    run1/full.py:283,374);
+  * all_gather_with_grad: differentiable replacement of the two dist.all_gather calls at
+    old/clip_opt.py:102-112 (their outputs carry no gradient): forward all-gather,
+    backward reduce-scatter(sum);
+  * the global-batch loss itself uses the cheaper LSE-gather scheme in loss.py and never needs the
+    embedding-gradient reduce-scatter.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: str | None = None):
+    """Initialise from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT.  Returns (rank, world, device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_gpu = torch.cuda.is_available()
+    device = torch.device(f"cuda:{local}") if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend=backend or ("nccl" if use_gpu else "gloo"), rank=rank, world_size=world,
+                                device_id=device if use_gpu else None)
+    return rank, world, device
+
+
+class _AllGatherCat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, group):
+        world = dist.get_world_size(group)
+        x = x.contiguous()
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x, group=group)
+        ctx.group = group
+        ctx.n = x.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = torch.empty((ctx.n,) + tuple(dy.shape[1:]), dtype=dy.dtype, device=dy.device)
+        if dist.get_backend(ctx.group) == "gloo":           # gloo has no reduce_scatter: all_reduce + slice (tests)
+            full = dy.clone()
+            dist.all_reduce(full, group=ctx.group)
+            r = dist.get_rank(ctx.group)
+            dx.copy_(full[r * ctx.n:(r + 1) * ctx.n])
+        else:
+            dist.reduce_scatter_tensor(dx, dy, op=dist.ReduceOp.SUM, group=ctx.group)
+        return dx, None
+
+
+def all_gather_with_grad(x: torch.Tensor, group=None) -> torch.Tensor:
+    """[B_local, ...] -> [world * B_local, ...] in rank order; gradient = reduce-scatter(sum)."""
+    group = group or dist.group.WORLD
+    return _AllGatherCat.apply(x, group)

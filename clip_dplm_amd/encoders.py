@@ -1,0 +1,437 @@
+"""Sequence encoders on the libclipk kernels: ESM-2 (pre-LN, RoPE) and the post-LN transformer of
+nn.TransformerEncoderLayer.  Each encoder is ONE autograd.Function whose forward/backward walk the layers
+by hand (explicit kernel sequence, explicit saved activations): no per-op autograd graph, bf16 activations
+between GEMMs, f32 residual stream, f32 statistics.
+
+Reference:
+  * ESM-2: third-party transformers.EsmModel called at triple_flow/3_esm_integration.py:77-80,118-119
+    (modeling_esm.py:225-270 embeddings, :362-384 attention, :429-438/:517-521 blocks, :552-553 final LN);
+    state_dict keys follow EsmModel so HF checkpoints load as they are.
+  * post-LN: nn.TransformerEncoderLayer as built at current/rna_clip_codes.ipynb:1911-1923 and described by the
+    "transformer" architecture of run1/configuration_hybrid_clip.py:153-157 (6 x 768, 8 heads, ffn 2048, gelu).
+    Keys follow RNARBPCLIPEncoder: layers.{i}.self_attn.in_proj_weight, ..., layernorm.weight.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import functional as KF
+from . import ops
+
+
+def _rope_tables(L: int, hd: int, device, theta: float = 10000.0):
+    inv = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    fr = torch.arange(L, dtype=torch.float32)[:, None] * inv[None, :]
+    return fr.cos().contiguous().to(device), fr.sin().contiguous().to(device)
+
+
+class _Lin:
+    """Kernel-side view of one Linear: f32 master params + cached bf16 W / W^T."""
+
+    def __init__(self, w, b, cache: KF.WeightCache):
+        self.w, self.b = w, b
+        self.wb, self.wtb = cache.get(w)
+
+
+# =================================================================================================
+# ESM-2 (pre-LN) stack
+# =================================================================================================
+def _esm_layer_fwd(x, p, meta):
+    """x: f32 [T,d].  p: dict of this layer's tensors.  Returns y f32 [T,d] and the saved activations."""
+    B, L, H, D, mask, rope, eps = meta
+    _, h1, m1, r1 = ops.layernorm_fwd(x, p["ln1_w"], p["ln1_b"], eps, want_f32=False, want_bf16=True)
+    qkv = ops.gemm_nt(h1, p["qkv"].wb, bias=p["qkv"].b)
+    ctx, lse = ops.attn_fwd(qkv, B, L, H, D, key_mask=mask, rope=rope, q_scale=D ** -0.5)
+    x2 = ops.gemm_nt(ctx, p["out"].wb, bias=p["out"].b, residual=x, out_dtype=torch.float32)
+    _, h2, m2, r2 = ops.layernorm_fwd(x2, p["ln2_w"], p["ln2_b"], eps, want_f32=False, want_bf16=True)
+    g, u = ops.gemm_nt(h2, p["fc1"].wb, bias=p["fc1"].b, act="gelu", out_preact=True)
+    y = ops.gemm_nt(g, p["fc2"].wb, bias=p["fc2"].b, residual=x2, out_dtype=torch.float32)
+    return y, (x, h1, m1, r1, qkv, ctx, lse, x2, h2, m2, r2, g, u)
+
+
+def _esm_layer_bwd(dy, dyb, p, saved, meta, need_dx_bf16):
+    """dy f32 [T,d] (+ its bf16 copy dyb).  Returns dx f32, dx bf16 (or None) and the parameter grads."""
+    B, L, H, D, mask, rope, eps = meta
+    x, h1, m1, r1, qkv, ctx, lse, x2, h2, m2, r2, g, u = saved
+    if dyb is None:
+        dyb = ops.to_bf16(dy)
+    gr = {}
+    du = ops.gemm_nt(dyb, p["fc2"].wtb, dact_aux=u, dact="gelu")               # dgrad fused with GELU'
+    gr["fc2_w"], gr["fc2_b"] = ops.gemm_wgrad(dyb, g, want_bias=True)
+    dh2 = ops.gemm_nt(du, p["fc1"].wtb)
+    gr["fc1_w"], gr["fc1_b"] = ops.gemm_wgrad(du, h2, want_bias=True)
+    dx2, dx2b, gr["ln2_w"], gr["ln2_b"] = ops.layernorm_bwd(dh2, x2, p["ln2_w"], None, m2, r2, dx_add=dy,
+                                                            want_f32=True, want_bf16=True)
+    dctx = ops.gemm_nt(dx2b, p["out"].wtb)
+    gr["out_w"], gr["out_b"] = ops.gemm_wgrad(dx2b, ctx, want_bias=True)
+    dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, H, D, key_mask=mask, rope=rope, q_scale=D ** -0.5)
+    dh1 = ops.gemm_nt(dqkv, p["qkv"].wtb)
+    gr["qkv_w"], gr["qkv_b"] = ops.gemm_wgrad(dqkv, h1, want_bias=True)
+    dx, dxb, gr["ln1_w"], gr["ln1_b"] = ops.layernorm_bwd(dh1, x, p["ln1_w"], None, m1, r1, dx_add=dx2,
+                                                          want_f32=True, want_bf16=need_dx_bf16)
+    return dx, dxb, gr
+
+
+_ESM_KEYS = ["ln1_w", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b", "ln2_w", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b"]
+
+
+class EsmStackFn(torch.autograd.Function):
+    """ids -> final-LayerNorm hidden states [B*L, d] (f32)."""
+
+    @staticmethod
+    def forward(ctx, module, ids, mask_u8, row_scale, *flat):
+        nl = module.num_layers
+        table, fin_w, fin_b = flat[0], flat[1], flat[2]
+        B, L = ids.shape
+        d, H = module.hidden_size, module.num_heads
+        D = d // H
+        rope = module.rope(L, ids.device)
+        meta = (B, L, H, D, mask_u8, rope, module.eps)
+        x = ops.embed_fwd(ids, table, row_scale=row_scale, mask=mask_u8.view(-1) if mask_u8 is not None else None,
+                          mask_token_id=module.mask_token_id if module.token_dropout else -1)
+        layers, saved = [], []
+        for i in range(nl):
+            t = flat[3 + 12 * i: 3 + 12 * (i + 1)]
+            caches = module.layer_caches[i]
+            p = {"ln1_w": t[0], "ln1_b": t[1], "qkv": _Lin(t[2], t[3], caches[0]), "out": _Lin(t[4], t[5], caches[1]),
+                 "ln2_w": t[6], "ln2_b": t[7], "fc1": _Lin(t[8], t[9], caches[2]), "fc2": _Lin(t[10], t[11], caches[3])}
+            x, s = _esm_layer_fwd(x, p, meta)
+            layers.append(p)
+            saved.append(s)
+        y, _, mf, rf = ops.layernorm_fwd(x, fin_w, fin_b, module.eps, want_f32=True)
+        ctx.module, ctx.meta, ctx.layers, ctx.saved = module, meta, layers, saved
+        ctx.fin = (x, fin_w, mf, rf)
+        ctx.ids, ctx.row_scale = ids, row_scale
+        ctx.table_shape = table.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        module, meta = ctx.module, ctx.meta
+        x, fin_w, mf, rf = ctx.fin
+        nl = module.num_layers
+        grads: List[Optional[torch.Tensor]] = [None] * (3 + 12 * nl)
+        dx, dxb, grads[1], grads[2] = ops.layernorm_bwd(dy.contiguous(), x, fin_w, None, mf, rf, want_f32=True,
+                                                        want_bf16=True)
+        for i in reversed(range(nl)):
+            dx, dxb, gr = _esm_layer_bwd(dx, dxb, ctx.layers[i], ctx.saved[i], meta, need_dx_bf16=i > 0)
+            ctx.saved[i] = None                                     # free this layer's activations now
+            for j, k in enumerate(_ESM_KEYS):
+                grads[3 + 12 * i + j] = gr[k]
+        if ctx.needs_input_grad[4]:
+            mask_u8 = meta[4]
+            dtable = torch.zeros(ctx.table_shape, dtype=torch.float32, device=dx.device)
+            ops.embed_bwd(ctx.ids, dx, dtable, row_scale=ctx.row_scale,
+                          mask=mask_u8.view(-1) if mask_u8 is not None else None,
+                          mask_token_id=module.mask_token_id if module.token_dropout else -1)
+            grads[0] = dtable
+        ctx.layers = ctx.saved = None
+        return (None, None, None, None, *grads)
+
+
+class _EsmSelf(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.query, self.key, self.value = nn.Linear(d, d), nn.Linear(d, d), nn.Linear(d, d)
+
+
+class _Dense(nn.Module):
+    def __init__(self, i, o):
+        super().__init__()
+        self.dense = nn.Linear(i, o)
+
+
+class _EsmAttention(nn.Module):
+    def __init__(self, d, eps):
+        super().__init__()
+        self.self = _EsmSelf(d)
+        self.output = _Dense(d, d)
+        self.LayerNorm = nn.LayerNorm(d, eps=eps)
+
+
+class _EsmLayer(nn.Module):
+    def __init__(self, d, f, eps):
+        super().__init__()
+        self.attention = _EsmAttention(d, eps)
+        self.intermediate = _Dense(d, f)
+        self.output = _Dense(f, d)
+        self.LayerNorm = nn.LayerNorm(d, eps=eps)
+
+
+class _EsmEncoderModules(nn.Module):
+    def __init__(self, nl, d, f, eps):
+        super().__init__()
+        self.layer = nn.ModuleList([_EsmLayer(d, f, eps) for _ in range(nl)])
+        self.emb_layer_norm_after = nn.LayerNorm(d, eps=eps)
+
+
+class _EsmEmbeddings(nn.Module):
+    def __init__(self, vocab, d, pad):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(vocab, d, padding_idx=pad)
+
+
+ESM2_SHAPES = {                      # (layers, hidden, heads, ffn) — SURVEY App. A-17
+    "esm2_t6_8M_UR50D": (6, 320, 20, 1280),
+    "esm2_t12_35M_UR50D": (12, 480, 20, 1920),
+    "esm2_t30_150M_UR50D": (30, 640, 20, 2560),
+    "esm2_t33_650M_UR50D": (33, 1280, 20, 5120),
+}
+
+
+class ESM2Encoder(nn.Module):
+    """ESM-2 encoder with transformers.EsmModel's parameter names (add_pooling_layer=False, rotary positions).
+
+    forward(input_ids [B,L] int64, attention_mask [B,L] or None) -> last_hidden_state [B, L, d] (f32).
+    q/k/v weights are kept as three nn.Linear (checkpoint compatible) and fused into one [3d, d] GEMM operand.
+    """
+
+    def __init__(self, num_layers=12, hidden_size=480, num_heads=20, intermediate_size=1920, vocab_size=33,
+                 pad_token_id=1, mask_token_id=32, layer_norm_eps=1e-5, token_dropout=True, initializer_range=0.02):
+        super().__init__()
+        self.num_layers, self.hidden_size, self.num_heads = num_layers, hidden_size, num_heads
+        self.intermediate_size, self.eps = intermediate_size, layer_norm_eps
+        self.mask_token_id, self.token_dropout, self.pad_token_id = mask_token_id, token_dropout, pad_token_id
+        self.embeddings = _EsmEmbeddings(vocab_size, hidden_size, pad_token_id)
+        self.encoder = _EsmEncoderModules(num_layers, hidden_size, intermediate_size, layer_norm_eps)
+        self.layer_caches = [[KF.WeightCache() for _ in range(4)] for _ in range(num_layers)]
+        self._rope = {}
+        self._fused = None
+        self._init(initializer_range)
+
+    @classmethod
+    def from_name(cls, name: str, **kw):
+        nl, d, h, f = ESM2_SHAPES[name]
+        return cls(nl, d, h, f, **kw)
+
+    def _init(self, std):
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, 0.0, std)
+                nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.Embedding):
+                nn.init.normal_(m.weight, 0.0, std)
+                if m.padding_idx is not None:
+                    with torch.no_grad():
+                        m.weight[m.padding_idx].zero_()
+
+    def rope(self, L, device):
+        key = (L, str(device))
+        if key not in self._rope:
+            self._rope[key] = _rope_tables(L, self.hidden_size // self.num_heads, device)
+        return self._rope[key]
+
+    def _flat_params(self):
+        """Per layer: ln1 w,b | fused qkv w,b | out w,b | ln2 w,b | fc1 w,b | fc2 w,b (autograd-visible views)."""
+        flat = [self.embeddings.word_embeddings.weight, self.encoder.emb_layer_norm_after.weight,
+                self.encoder.emb_layer_norm_after.bias]
+        for lyr in self.encoder.layer:
+            s = lyr.attention.self
+            flat += [lyr.attention.LayerNorm.weight, lyr.attention.LayerNorm.bias,
+                     torch.cat([s.query.weight, s.key.weight, s.value.weight], 0),
+                     torch.cat([s.query.bias, s.key.bias, s.value.bias], 0),
+                     lyr.attention.output.dense.weight, lyr.attention.output.dense.bias,
+                     lyr.LayerNorm.weight, lyr.LayerNorm.bias,
+                     lyr.intermediate.dense.weight, lyr.intermediate.dense.bias,
+                     lyr.output.dense.weight, lyr.output.dense.bias]
+        return flat
+
+    def forward(self, input_ids, attention_mask=None):
+        B, L = input_ids.shape
+        mask_u8 = None
+        row_scale = None
+        if attention_mask is not None:
+            mask_u8 = attention_mask.to(torch.uint8).contiguous()
+        if self.token_dropout:
+            # modeling_esm.py:252-259: scale by (1 - 0.15*0.8) / (1 - observed mask ratio); [B] scalars: plumbing
+            src_len = attention_mask.sum(-1).float() if attention_mask is not None else \
+                torch.full((B,), float(L), device=input_ids.device)
+            ratio = (input_ids == self.mask_token_id).sum(-1).float() / src_len
+            row_scale = ((1 - 0.15 * 0.8) / (1 - ratio)).contiguous()
+        y = EsmStackFn.apply(self, input_ids.contiguous(), mask_u8, row_scale, *self._flat_params())
+        return y.view(B, L, self.hidden_size)
+
+
+# =================================================================================================
+# post-LN (nn.TransformerEncoderLayer) stack
+# =================================================================================================
+def _post_layer_fwd(x, xb, p, meta):
+    B, L, H, D, mask, act, eps, qs = meta
+    qkv = ops.gemm_nt(xb, p["in"].wb, bias=p["in"].b)
+    ctx, lse = ops.attn_fwd(qkv, B, L, H, D, key_mask=mask, rope=None, q_scale=qs)
+    s1 = ops.gemm_nt(ctx, p["out"].wb, bias=p["out"].b, residual=x, out_dtype=torch.float32)
+    x1, x1b, m1, r1 = ops.layernorm_fwd(s1, p["n1_w"], p["n1_b"], eps, want_f32=True, want_bf16=True)
+    if act == "gelu":
+        g, u = ops.gemm_nt(x1b, p["fc1"].wb, bias=p["fc1"].b, act="gelu", out_preact=True)
+    else:
+        g = ops.gemm_nt(x1b, p["fc1"].wb, bias=p["fc1"].b, act="relu")
+        u = g                                                   # relu'(pre) == relu'(relu(pre))
+    s2 = ops.gemm_nt(g, p["fc2"].wb, bias=p["fc2"].b, residual=x1, out_dtype=torch.float32)
+    y, yb, m2, r2 = ops.layernorm_fwd(s2, p["n2_w"], p["n2_b"], eps, want_f32=True, want_bf16=True)
+    return y, yb, (xb, qkv, ctx, lse, s1, x1b, m1, r1, g, u, s2, m2, r2)
+
+
+def _post_layer_bwd(dy, p, saved, meta):
+    B, L, H, D, mask, act, eps, qs = meta
+    xb, qkv, ctx, lse, s1, x1b, m1, r1, g, u, s2, m2, r2 = saved
+    gr = {}
+    ds2, ds2b, gr["n2_w"], gr["n2_b"] = ops.layernorm_bwd(dy, s2, p["n2_w"], None, m2, r2, want_f32=True, want_bf16=True)
+    du = ops.gemm_nt(ds2b, p["fc2"].wtb, dact_aux=u, dact=act)
+    gr["fc2_w"], gr["fc2_b"] = ops.gemm_wgrad(ds2b, g, want_bias=True)
+    dx1 = ops.gemm_nt(du, p["fc1"].wtb, residual=ds2, out_dtype=torch.float32)      # + residual-path gradient
+    gr["fc1_w"], gr["fc1_b"] = ops.gemm_wgrad(du, x1b, want_bias=True)
+    ds1, ds1b, gr["n1_w"], gr["n1_b"] = ops.layernorm_bwd(dx1, s1, p["n1_w"], None, m1, r1, want_f32=True, want_bf16=True)
+    dctx = ops.gemm_nt(ds1b, p["out"].wtb)
+    gr["out_w"], gr["out_b"] = ops.gemm_wgrad(ds1b, ctx, want_bias=True)
+    dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, H, D, key_mask=mask, rope=None, q_scale=qs)
+    dx = ops.gemm_nt(dqkv, p["in"].wtb, residual=ds1, out_dtype=torch.float32)
+    gr["in_w"], gr["in_b"] = ops.gemm_wgrad(dqkv, xb, want_bias=True)
+    return dx, gr
+
+
+_POST_KEYS = ["in_w", "in_b", "out_w", "out_b", "n1_w", "n1_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "n2_w", "n2_b"]
+
+
+class PostLNStackFn(torch.autograd.Function):
+    """x f32 [B*L, E] -> final-LayerNorm output f32 [B*L, E]."""
+
+    @staticmethod
+    def forward(ctx, module, x, mask_u8, B, L, *flat):
+        nl = module.num_layers
+        E, H = module.embed_dim, module.nhead
+        D = module.head_dim_padded
+        meta = (B, L, H, D, mask_u8, module.activation, module.eps, float(E // H) ** -0.5)
+        x = x.contiguous()
+        xb = ops.to_bf16(x)
+        fin_w, fin_b = flat[0], flat[1]
+        layers, saved = [], []
+        for i in range(nl):
+            t = flat[2 + 12 * i: 2 + 12 * (i + 1)]
+            c = module.layer_caches[i]
+            p = {"in": _Lin(t[0], t[1], c[0]), "out": _Lin(t[2], t[3], c[1]), "n1_w": t[4], "n1_b": t[5],
+                 "fc1": _Lin(t[6], t[7], c[2]), "fc2": _Lin(t[8], t[9], c[3]), "n2_w": t[10], "n2_b": t[11]}
+            x, xb, s = _post_layer_fwd(x, xb, p, meta)
+            layers.append(p)
+            saved.append(s)
+        y, _, mf, rf = ops.layernorm_fwd(x, fin_w, fin_b, module.final_eps, want_f32=True)
+        ctx.module, ctx.meta, ctx.layers, ctx.saved = module, meta, layers, saved
+        ctx.fin = (x, fin_w, mf, rf)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        module, meta = ctx.module, ctx.meta
+        x, fin_w, mf, rf = ctx.fin
+        nl = module.num_layers
+        grads: List[Optional[torch.Tensor]] = [None] * (2 + 12 * nl)
+        dx, _, grads[0], grads[1] = ops.layernorm_bwd(dy.contiguous(), x, fin_w, None, mf, rf, want_f32=True)
+        for i in reversed(range(nl)):
+            dx, gr = _post_layer_bwd(dx, ctx.layers[i], ctx.saved[i], meta)
+            ctx.saved[i] = None
+            for j, k in enumerate(_POST_KEYS):
+                grads[2 + 12 * i + j] = gr[k]
+        ctx.layers = ctx.saved = None
+        return (None, dx if ctx.needs_input_grad[1] else None, None, None, None, *grads)
+
+
+class _MHAParams(nn.Module):
+    def __init__(self, E):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * E, E))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * E))
+        self.out_proj = nn.Linear(E, E)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.zeros_(self.out_proj.bias)
+
+
+class _PostLayerParams(nn.Module):
+    """Same parameter names as nn.TransformerEncoderLayer."""
+
+    def __init__(self, E, F_, eps):
+        super().__init__()
+        self.self_attn = _MHAParams(E)
+        self.linear1 = nn.Linear(E, F_)
+        self.linear2 = nn.Linear(F_, E)
+        self.norm1 = nn.LayerNorm(E, eps=eps)
+        self.norm2 = nn.LayerNorm(E, eps=eps)
+
+
+class TransformerSeqEncoder(nn.Module):
+    """Stack of post-LN layers + final LayerNorm == RNARBPCLIPEncoder (rna_clip_codes.ipynb:1911-1923).
+
+    forward(x [B, L, E] f32, key_padding_mask [B, L] bool with True = PAD, as nn.TransformerEncoderLayer) -> [B, L, E].
+    Attention runs over axis 1 (per sequence).  To reproduce the notebook's batch-axis attention quirk
+     pass x.transpose(0, 1) and the matching mask — see RNARBPCLIPModel.
+    """
+
+    def __init__(self, embed_dim=768, num_layers=6, nhead=8, dim_feedforward=2048, activation="gelu",
+                 layer_norm_eps=1e-12, final_eps=None):
+        super().__init__()
+        self.embed_dim, self.num_layers, self.nhead = embed_dim, num_layers, nhead
+        self.activation, self.eps = activation, layer_norm_eps
+        self.final_eps = layer_norm_eps if final_eps is None else final_eps
+        self.layers = nn.ModuleList([_PostLayerParams(embed_dim, dim_feedforward, layer_norm_eps)
+                                     for _ in range(num_layers)])
+        self.layernorm = nn.LayerNorm(embed_dim, eps=self.final_eps)
+        self.layer_caches = [[KF.WeightCache() for _ in range(4)] for _ in range(num_layers)]
+        hd = embed_dim // nhead
+        self.head_dim_padded = (hd + 7) // 8 * 8          # kernels want head_dim % 8 == 0 (notebook: 120/8 = 15)
+
+    def _attn_params(self, l):
+        """in_proj / out_proj as the kernels consume them.  When head_dim % 8 != 0 every head is zero-padded to
+        head_dim_padded (zero q/k/v rows, zero out_proj columns): identical arithmetic, differentiable views."""
+        E, H, Dp = self.embed_dim, self.nhead, self.head_dim_padded
+        D = E // H
+        a = l.self_attn
+        if Dp == D:
+            return a.in_proj_weight, a.in_proj_bias, a.out_proj.weight
+        pad = Dp - D
+        w = torch.nn.functional.pad(a.in_proj_weight.view(3, H, D, E), (0, 0, 0, pad)).reshape(3 * H * Dp, E)
+        b = torch.nn.functional.pad(a.in_proj_bias.view(3, H, D), (0, pad)).reshape(3 * H * Dp)
+        wo = torch.nn.functional.pad(a.out_proj.weight.view(E, H, D), (0, pad)).reshape(E, H * Dp)
+        return w, b, wo
+
+    def _flat_params(self):
+        flat = [self.layernorm.weight, self.layernorm.bias]
+        for l in self.layers:
+            w_in, b_in, w_out = self._attn_params(l)
+            flat += [w_in, b_in, w_out,
+                     l.self_attn.out_proj.bias, l.norm1.weight, l.norm1.bias, l.linear1.weight, l.linear1.bias,
+                     l.linear2.weight, l.linear2.bias, l.norm2.weight, l.norm2.bias]
+        return flat
+
+    def forward(self, x, src_key_padding_mask=None):
+        B, L, E = x.shape
+        mask_u8 = None
+        if src_key_padding_mask is not None:
+            mask_u8 = (~src_key_padding_mask.bool()).to(torch.uint8).contiguous()      # kernels take 1 = valid
+        y = PostLNStackFn.apply(self, x.reshape(B * L, E), mask_u8, B, L, *self._flat_params())
+        return y.view(B, L, E)
+
+
+class PoolFn(torch.autograd.Function):
+    """mode 'first' (rna_clip_codes.ipynb:1948) or masked 'mean' (configuration_hybrid_clip.py:109)."""
+
+    @staticmethod
+    def forward(ctx, x, mask_u8, mode):
+        B, L, d = x.shape
+        ctx.meta = (B, L, mode)
+        ctx.mask = mask_u8
+        return ops.pool_fwd(x.contiguous().view(B * L, d), B, L, mask=mask_u8.view(-1) if mask_u8 is not None else None,
+                            mode=mode)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, L, mode = ctx.meta
+        m = ctx.mask
+        dx = ops.pool_bwd(dy.contiguous(), B, L, mask=m.view(-1) if m is not None else None, mode=mode)
+        return dx.view(B, L, -1), None, None
+
+
+def pool(x, valid_mask=None, mode: str = "mean"):
+    mask_u8 = valid_mask.to(torch.uint8).contiguous() if valid_mask is not None else None
+    return PoolFn.apply(x, mask_u8, 0 if mode == "first" else 1)

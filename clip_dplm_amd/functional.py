@@ -1,0 +1,187 @@
+"""autograd.Function wrappers of the libclipk kernels (per-op granularity, used by the drop-in modules).
+
+Forward and backward both run hand-written HIP kernels; torch.autograd only routes tensors.  bf16 copies of
+the f32 master weights (W and W^T) are cached per parameter and refreshed when the parameter changes.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+
+_WEIGHT_EPOCH = 0
+
+
+def mark_weights_dirty() -> None:
+    """Call after updating parameters outside torch's version counter (the fused optimiser kernels do)."""
+    global _WEIGHT_EPOCH
+    _WEIGHT_EPOCH += 1
+
+
+class WeightCache:
+    """bf16 W [N,K] and W^T [K,N] of an f32 master weight, refreshed lazily."""
+
+    __slots__ = ("wb", "wtb", "key")
+
+    def __init__(self):
+        self.wb = self.wtb = None
+        self.key = None
+
+    def get(self, w: torch.Tensor):
+        key = (w.data_ptr(), w._version, _WEIGHT_EPOCH, tuple(w.shape))
+        if key != self.key:
+            src = w.detach()
+            if not src.is_contiguous():
+                src = src.contiguous()
+            self.wb, self.wtb = ops.cast_transpose(src, w_out=self.wb if self.wb is not None and self.wb.shape == w.shape else None,
+                                                   wt_out=self.wtb if self.wtb is not None and self.wtb.shape == (w.shape[1], w.shape[0]) else None)
+            self.key = key
+        return self.wb, self.wtb
+
+
+def _bf16(x: torch.Tensor) -> torch.Tensor:
+    if x.dtype == torch.bfloat16:
+        return x if x.is_contiguous() else x.contiguous()
+    return ops.to_bf16(x.contiguous())
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b)   (old/clip.py:11,16,27,31).  x: [M,K] f32 or bf16; y dtype selectable."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cache: WeightCache, act, out_dtype):
+        wb, wtb = cache.get(weight)
+        xb = _bf16(x)
+        need_pre = act == "gelu"
+        r = ops.gemm_nt(xb, wb, bias=bias, act=act, out_dtype=out_dtype, out_preact=need_pre)
+        y, pre = r if need_pre else (r, None)
+        ctx.act = act
+        ctx.x_dtype = x.dtype
+        ctx.has_bias = bias is not None
+        # relu'(pre) == relu'(y): the output itself is the aux for ReLU
+        aux = pre if need_pre else (y if act == "relu" and y.dtype == torch.bfloat16 else None)
+        if act == "relu" and aux is None:
+            aux = _bf16(y)
+        ctx.save_for_backward(xb, wtb, aux)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, wtb, aux = ctx.saved_tensors
+        dy = dy.contiguous()
+        g = ops.dact(dy, aux, ctx.act) if aux is not None else _bf16(dy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm_nt(g, wtb, out_dtype=ctx.x_dtype)
+        dw = db = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dw, db = ops.gemm_wgrad(g, xb, want_bias=ctx.has_bias)
+        return dx, dw, db, None, None, None
+
+
+def linear(x, weight, bias, cache: WeightCache, act=None, out_dtype=torch.float32):
+    lead = x.shape[:-1]
+    y = LinearFn.apply(x.reshape(-1, x.shape[-1]), weight, bias, cache, act, out_dtype)
+    return y.reshape(*lead, y.shape[-1])
+
+
+class LayerNormFn(torch.autograd.Function):
+    """y = act(LayerNorm(x))  (old/clip.py:12,28-29,32); f32 in/out."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, act):
+        x = x.contiguous()
+        y, _, mean, rstd = ops.layernorm_fwd(x, gamma, beta, eps, act=act, want_f32=True)
+        ctx.act = act
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        dx, _, dg, db = ops.layernorm_bwd(dy.contiguous(), x, gamma, beta, mean, rstd, act=ctx.act, want_f32=True)
+        return dx, dg, db, None, None
+
+
+def layer_norm(x, gamma, beta, eps, act=None):
+    lead = x.shape[:-1]
+    if x.dtype != torch.float32:
+        x = x.float()
+    return LayerNormFn.apply(x.reshape(-1, x.shape[-1]), gamma, beta, eps, act).reshape(*lead, x.shape[-1])
+
+
+class ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        x = x.contiguous()
+        ctx.act = act
+        ctx.save_for_backward(x)
+        return ops.act_fwd(x, act)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.act_bwd(dy.contiguous(), x, ctx.act), None
+
+
+class L2NormFn(torch.autograd.Function):
+    """F.normalize(x, dim=-1) (old/clip.py:63-64)."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        y, n = ops.l2norm_fwd(x.contiguous(), eps)
+        ctx.eps = eps
+        ctx.save_for_backward(y, n)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, n = ctx.saved_tensors
+        return ops.l2norm_bwd(dy.contiguous(), y, n, ctx.eps), None
+
+
+def l2_normalize(x, eps: float = 1e-12):
+    return L2NormFn.apply(x, eps)
+
+
+class SkipScaleFn(torch.autograd.Function):
+    """skip + layer_scale * projected (old/clip_opt.py:41-44)."""
+
+    @staticmethod
+    def forward(ctx, skip, proj, scale):
+        ctx.save_for_backward(proj, scale)
+        return ops.axpby_dev(skip.contiguous(), proj.contiguous(), scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        proj, scale = ctx.saved_tensors
+        dy = dy.contiguous()
+        dproj = ops.axpby_dev(torch.zeros_like(dy), dy, scale)
+        dscale = (dy * proj).sum().reshape(scale.shape)          # scalar reduction: plumbing
+        return dy, dproj, dscale
+
+
+class SimLogitsFn(torch.autograd.Function):
+    """logits = scale * A B^T, materialised for the reference's module API (old/clip.py:66-67).
+    Forward is the exact-f32 MFMA kernel.  The backward of this cold, API-compatibility path uses
+    torch.matmul (rocBLAS): training should call clip_loss(), which never materialises the logits."""
+
+    @staticmethod
+    def forward(ctx, a, b, scale):
+        a, b = a.contiguous(), b.contiguous()
+        ctx.save_for_backward(a, b, scale)
+        return ops.sim_logits(a, b, scale.reshape(1))
+
+    @staticmethod
+    def backward(ctx, ds):
+        a, b, scale = ctx.saved_tensors
+        da = (ds @ b) * scale
+        db = (ds.t() @ a) * scale
+        dscale = (ds * (a @ b.t())).sum().reshape(scale.shape)
+        return da, db, dscale
+
+
+def sim_logits(a, b, scale):
+    return SimLogitsFn.apply(a, b, scale)

@@ -1,0 +1,95 @@
+"""Fused CLIP / InfoNCE loss on the simce kernels — the B x B (or B_local x B_global) logits never exist.
+
+Reference losses covered (weights select the variant):
+  * one-sided  CE(S, arange)                      old/ablation.py:16, run1/full.py:133      (w_row=1, w_col=0)
+  * symmetric  (CE(S) + CE(S^T)) / 2              current/rna_clip_codes.ipynb:1952-1953    (0.5, 0.5)
+  * cache-negative variant                        old/clip_opt.py:130-151                   (0.5, 0.5, cache=...)
+  * global batch over ranks                       old/clip_opt.py:102-112 — but differentiable
+
+Multi-GPU scheme: one all-gather of the stacked embeddings [2, B_l, P], one
+all-gather of the two LSE vectors [2, B_l]; every rank then computes the COMPLETE gradient of the global
+loss w.r.t. its own rows locally — no embedding-gradient reduce-scatter is needed.  Parameter gradients are
+summed across ranks afterwards by the optimiser's reduce-scatter.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+# kernel namespace; tests of the rank bookkeeping (gloo, CPU) substitute a torch restatement here — the product
+# itself never does: ops.* raise on anything but device tensors.
+_kernels = ops
+
+
+def _gather_cat(t: torch.Tensor, group) -> torch.Tensor:
+    world = dist.get_world_size(group)
+    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+    return out
+
+
+class ClipLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, scale, w_row, w_col, cache, group):
+        a, b = a.contiguous(), b.contiguous()
+        scale = scale.reshape(1).contiguous()
+        bl = a.shape[0]
+        if group is not None:
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+            both = _gather_cat(torch.stack([a, b]), group)                 # [W, 2, Bl, P]
+            a_g = both[:, 0].reshape(world * bl, -1)
+            b_g = both[:, 1].reshape(world * bl, -1)
+        else:
+            world, rank, a_g, b_g = 1, 0, a, b
+        off = rank * bl
+        bg = world * bl
+        lse_r, pos_r = _kernels.simce_lse(a, b_g, scale, label_offset=off, cache=cache)
+        local = w_row * (lse_r - pos_r).sum()
+        if w_col != 0.0:
+            lse_c, pos_c = _kernels.simce_lse(b, a_g, scale, label_offset=off)
+            local = local + w_col * (lse_c - pos_c).sum()
+        else:
+            lse_c = torch.full_like(lse_r, float("inf"))   # exp(s - inf) = 0: the unused direction contributes nothing
+        if group is not None:
+            lses = _gather_cat(torch.stack([lse_r, lse_c]), group)          # [W, 2, Bl]
+            lse_r_g = lses[:, 0].reshape(-1).contiguous()
+            lse_c_g = lses[:, 1].reshape(-1).contiguous()
+            dist.all_reduce(local, group=group)
+        else:
+            lse_r_g, lse_c_g = lse_r, lse_c
+        ctx.meta = (w_row, w_col, off, bg, cache)
+        ctx.save_for_backward(a, b, a_g, b_g, scale, lse_r, lse_c, lse_r_g, lse_c_g)
+        return local / bg
+
+    @staticmethod
+    def backward(ctx, dloss):
+        a, b, a_g, b_g, scale, lse_r, lse_c, lse_r_g, lse_c_g = ctx.saved_tensors
+        w_row, w_col, off, bg, cache = ctx.meta
+        # rows of a: row-direction softmax uses their own LSE, column direction the keys' LSE
+        da, dsa = _kernels.simce_grad(a, b_g, scale, lse_r, lse_c_g, w_row, w_col, 1.0 / bg, label_offset=off, cache=cache)
+        # rows of b are the queries of the column direction
+        db, _ = _kernels.simce_grad(b, a_g, scale, lse_c, lse_r_g, w_col, w_row, 1.0 / bg, label_offset=off)
+        dscale = dsa.sum().reshape(1)          # this rank's rows only; the optimiser sums parameter grads over ranks
+        if dloss.numel() == 1:
+            g = dloss.reshape(())
+            da, db, dscale = da * g, db * g, dscale * g
+        return da, db, dscale, None, None, None, None
+
+
+def clip_loss(a_embeds: torch.Tensor, b_embeds: torch.Tensor, logit_scale_exp: torch.Tensor, *,
+              symmetric: bool = True, cache: Optional[torch.Tensor] = None, group=None,
+              w_row: Optional[float] = None, w_col: Optional[float] = None) -> torch.Tensor:
+    """InfoNCE over L2-normalised embeddings [B_local, P] (f32).  `logit_scale_exp` = exp(logit_scale)
+    (already clamped if the model clamps, old/clip_opt.py:100).  With `group`, the batch is the concatenation
+    over ranks in rank order and the returned value is the global-batch loss on every rank."""
+    if w_row is None:
+        w_row, w_col = (0.5, 0.5) if symmetric else (1.0, 0.0)
+    if group is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        group = dist.group.WORLD
+    if group is not None and dist.get_world_size(group) == 1:
+        group = None
+    return ClipLossFn.apply(a_embeds, b_embeds, logit_scale_exp, float(w_row), float(w_col), cache, group)

@@ -1,0 +1,113 @@
+"""Sequence-level CLIP models on the kernel-backed encoders.
+
+  * RNARBPCLIPProjectionHead / RNARBPCLIPEncoder / RNARBPCLIPModel — the notebook model that was actually
+    trained (current/rna_clip_codes.ipynb:1901-1954), same names, forward signature `(rna_emb, rbp_emb) ->
+    (rna_embed, rbp_embed, loss)`, NaN-padding convention and batch-axis attention quirk.
+  * ProteinRNACLIP — BASELINE configs 2-4: ESM-2 protein encoder (third-party arithmetic, see encoders.py) +
+    the 6 x 768 "transformer" RNA encoder of run1/configuration_hybrid_clip.py:153-157 + the ProjectionHeads and
+    logit_scale of old/clip.py:38-54, returning the dict of old/clip.py:69-73 or the fused loss.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import functional as KF
+from .encoders import ESM2Encoder, ESM2_SHAPES, TransformerSeqEncoder, pool
+from .loss import clip_loss
+from .modeling_clip import KLayerNorm, KLinear, OptimizedProjectionHead, ProjectionHead
+
+
+def create_padding_mask(tensor):
+    """rna_clip_codes.ipynb:1841-1857: True = valid, False = NaN padding.  (tiny elementwise: plumbing)"""
+    return ~torch.isnan(tensor).any(dim=-1)
+
+
+class RNARBPCLIPProjectionHead(OptimizedProjectionHead):
+    """rna_clip_codes.ipynb:1901-1909 (= OptimizedProjectionHead with hidden 2*input_dim, default torch init)."""
+
+    def __init__(self, input_dim, output_dim):
+        super().__init__(input_dim, output_dim, hidden_dim=input_dim * 2, dropout=0.1, xavier=False)
+
+
+class RNARBPCLIPEncoder(TransformerSeqEncoder):
+    """rna_clip_codes.ipynb:1911-1923: 3 x nn.TransformerEncoderLayer(d, nhead=8, ffn=4d) + LayerNorm."""
+
+    def __init__(self, embed_dim, num_layers=3):
+        super().__init__(embed_dim=embed_dim, num_layers=num_layers, nhead=8, dim_feedforward=embed_dim * 4,
+                         activation="relu", layer_norm_eps=1e-5, final_eps=1e-5)
+
+
+class RNARBPCLIPModel(nn.Module):
+    """rna_clip_codes.ipynb:1925-1954."""
+
+    def __init__(self, rna_dim=120, rbp_dim=1280, projection_dim=512):
+        super().__init__()
+        self.rna_encoder = RNARBPCLIPEncoder(rna_dim)
+        self.rbp_encoder = RNARBPCLIPEncoder(rbp_dim)
+        self.rna_projection = RNARBPCLIPProjectionHead(rna_dim, projection_dim)
+        self.rbp_projection = RNARBPCLIPProjectionHead(rbp_dim, projection_dim)
+        self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
+
+    @staticmethod
+    def _encode(encoder, emb):
+        # The notebook hands (B, L, D) to batch_first=False layers with the mask transposed to (L, B): attention
+        # mixes the B samples at each position.  Same arithmetic here: positions become the kernel's batch axis.
+        valid = create_padding_mask(emb)                                  # [B, L]
+        x = torch.nan_to_num(emb, 0.0).transpose(0, 1).contiguous()       # [L, B, D]
+        y = encoder(x, src_key_padding_mask=~valid.transpose(0, 1))       # keys = samples
+        return y[0]                                                       # == enc[:, 0] in the notebook's layout
+
+    def forward(self, rna_emb, rbp_emb):
+        rna_embed = KF.l2_normalize(self.rna_projection(self._encode(self.rna_encoder, rna_emb)))
+        rbp_embed = KF.l2_normalize(self.rbp_projection(self._encode(self.rbp_encoder, rbp_emb)))
+        loss = clip_loss(rna_embed, rbp_embed, self.logit_scale.exp(), symmetric=True, group=None)
+        return rna_embed, rbp_embed, loss
+
+
+class ProteinRNACLIP(nn.Module):
+    """BASELINE configs 2-4: protein ids -> ESM-2, RNA features -> 6-layer post-LN transformer; masked-mean
+    pooling (`use_mean_pooling`), ProjectionHead (hidden 2P), L2 normalise, exp(logit_scale) similarity,
+    symmetric InfoNCE."""
+
+    def __init__(self, esm: str = "esm2_t12_35M_UR50D", rna_dim: int = 768, rna_layers: int = 6, rna_heads: int = 8,
+                 rna_ffn: int = 2048, rna_act: str = "gelu", projection_dim: int = 512,
+                 logit_scale_init_value: float = 2.6592, layer_norm_eps: float = 1e-12, pooling: str = "mean",
+                 initializer_range: float = 0.02, freeze_protein_encoder: bool = False):
+        super().__init__()
+        self.protein_model = ESM2Encoder.from_name(esm, initializer_range=initializer_range)
+        self.rna_model = TransformerSeqEncoder(rna_dim, rna_layers, rna_heads, rna_ffn, rna_act, layer_norm_eps)
+        for m in self.rna_model.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, 0.0, initializer_range)
+                nn.init.zeros_(m.bias)
+        for l in self.rna_model.layers:
+            nn.init.normal_(l.self_attn.in_proj_weight, 0.0, initializer_range)
+        self.rna_projection = ProjectionHead(rna_dim, projection_dim, hidden_dim=projection_dim * 2)
+        self.protein_projection = ProjectionHead(self.protein_model.hidden_size, projection_dim,
+                                                 hidden_dim=projection_dim * 2)
+        self.logit_scale = nn.Parameter(torch.ones([]) * logit_scale_init_value)
+        self.pooling = pooling
+        if freeze_protein_encoder:                       # triple_flow/3_esm_integration.py:83-84
+            for p in self.protein_model.parameters():
+                p.requires_grad_(False)
+
+    def embed(self, rna_values, protein_ids, rna_mask=None, protein_mask=None):
+        """rna_values [B, Lr, rna_dim] f32; protein_ids [B, Lp] int64; masks [B, L] with 1 = valid."""
+        hr = self.rna_model(rna_values, src_key_padding_mask=None if rna_mask is None else ~rna_mask.bool())
+        hp = self.protein_model(protein_ids, attention_mask=protein_mask)
+        er = self.rna_projection(pool(hr, rna_mask, self.pooling))
+        ep = self.protein_projection(pool(hp, protein_mask, self.pooling))
+        return KF.l2_normalize(er), KF.l2_normalize(ep)
+
+    def forward(self, rna_values, protein_ids, rna_mask=None, protein_mask=None):
+        er, ep = self.embed(rna_values, protein_ids, rna_mask, protein_mask)
+        return {"logits_per_rna_protein": KF.sim_logits(er, ep, self.logit_scale.exp()),
+                "rna_embeds": er, "protein_embeds": ep}
+
+    def loss(self, rna_values, protein_ids, rna_mask=None, protein_mask=None, group=None, symmetric: bool = True):
+        er, ep = self.embed(rna_values, protein_ids, rna_mask, protein_mask)
+        return clip_loss(er, ep, self.logit_scale.exp(), symmetric=symmetric, group=group)

@@ -16,6 +16,45 @@ from ._ffi import ACT, BF16, F32, GemmArgs, check, ptr
 _WS: dict = {}
 
 
+class KernelTimer:
+    """Optional HIP-event timing of individual kernel launches on torch's current stream (the stream the
+    kernels are enqueued on).  bench.py uses it for the live roofline numbers; off by default."""
+
+    def __init__(self):
+        self.records = {}          # name -> list of (start_event, end_event, algorithmic work)
+
+    def add(self, name, s, e, work):
+        self.records.setdefault(name, []).append((s, e, work))
+
+    def summary(self):
+        """name -> dict(launches, total_ms, avg_us, work) — call after torch.cuda.synchronize()."""
+        out = {}
+        for name, recs in self.records.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            out[name] = {"launches": len(recs), "total_ms": ms, "avg_us": 1e3 * ms / max(len(recs), 1),
+                         "work": float(sum(w for _, _, w in recs))}
+        return out
+
+
+_TIMER: Optional[KernelTimer] = None
+
+
+def set_kernel_timer(t: Optional[KernelTimer]) -> None:
+    global _TIMER
+    _TIMER = t
+
+
+def _timed(name: str, work: float, fn):
+    if _TIMER is None:
+        return fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    r = fn()
+    e.record()
+    _TIMER.add(name, s, e, work)
+    return r
+
+
 def _lib():
     return _ffi.load()
 
@@ -77,7 +116,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
     else:
         args.residual, args.ldr, args.r_dtype = None, 0, 0
     args.alpha = alpha
-    check(_lib().clipk_gemm_nt(C.byref(args), _stream()), "clipk_gemm_nt")
+    check(_timed("gemm_nt", 2.0 * M * N * K, lambda: _lib().clipk_gemm_nt(C.byref(args), _stream())), "clipk_gemm_nt")
     return (c, pre) if out_preact else c
 
 
@@ -96,9 +135,10 @@ def gemm_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: Optional[torch.Tensor] = N
     lib = _lib()
     nbytes = lib.clipk_gemm_wgrad_workspace(M, N, K)
     ws = workspace(nbytes, dy.device, "wgrad")
-    check(lib.clipk_gemm_wgrad(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(), dw.stride(0),
-                               ptr(dbias), M, N, K, int(accumulate), ws.data_ptr(), ws.numel(), _stream()),
-          "clipk_gemm_wgrad")
+    check(_timed("gemm_wgrad", 2.0 * M * N * K,
+                 lambda: lib.clipk_gemm_wgrad(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(),
+                                              dw.stride(0), ptr(dbias), M, N, K, int(accumulate), ws.data_ptr(),
+                                              ws.numel(), _stream())), "clipk_gemm_wgrad")
     return dw, dbias
 
 
@@ -156,9 +196,11 @@ def layernorm_fwd(x, gamma, beta, eps, act=None, want_f32=True, want_bf16=False,
     y16 = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
     mean = torch.empty(rows, dtype=torch.float32, device=x.device) if want_stats else None
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if want_stats else None
-    check(_lib().clipk_layernorm_fwd(x.data_ptr(), _dt(x), x.stride(0), gamma.data_ptr(), beta.data_ptr(), float(eps),
-                                     ACT[act], ptr(y32), ptr(y16), cols, ptr(mean), ptr(rstd), rows, cols, _stream()),
-          "clipk_layernorm_fwd")
+    nbytes = rows * cols * (x.element_size() + (4 if want_f32 else 0) + (2 if want_bf16 else 0))
+    check(_timed("layernorm_fwd", nbytes,
+                 lambda: _lib().clipk_layernorm_fwd(x.data_ptr(), _dt(x), x.stride(0), gamma.data_ptr(), beta.data_ptr(),
+                                                    float(eps), ACT[act], ptr(y32), ptr(y16), cols, ptr(mean),
+                                                    ptr(rstd), rows, cols, _stream())), "clipk_layernorm_fwd")
     return y32, y16, mean, rstd
 
 
@@ -175,10 +217,14 @@ def layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=None, dx_add=None, want_f3
     lib = _lib()
     nbytes = lib.clipk_layernorm_bwd_workspace(rows, cols)
     ws = workspace(nbytes, x.device, "ln")
-    check(lib.clipk_layernorm_bwd(dy.data_ptr(), _dt(dy), dy.stride(0), x.data_ptr(), _dt(x), x.stride(0),
-                                  gamma.data_ptr(), ptr(beta), mean.data_ptr(), rstd.data_ptr(), ACT[act], ptr(dx_add),
-                                  ptr(dx32), ptr(dx16), cols, dgamma.data_ptr(), dbeta.data_ptr(), int(accumulate),
-                                  rows, cols, ws.data_ptr(), ws.numel(), _stream()), "clipk_layernorm_bwd")
+    nb = rows * cols * (dy.element_size() + x.element_size() + (4 if dx_add is not None else 0) +
+                        (4 if want_f32 else 0) + (2 if want_bf16 else 0))
+    check(_timed("layernorm_bwd", nb,
+                 lambda: lib.clipk_layernorm_bwd(dy.data_ptr(), _dt(dy), dy.stride(0), x.data_ptr(), _dt(x), x.stride(0),
+                                                 gamma.data_ptr(), ptr(beta), mean.data_ptr(), rstd.data_ptr(), ACT[act],
+                                                 ptr(dx_add), ptr(dx32), ptr(dx16), cols, dgamma.data_ptr(),
+                                                 dbeta.data_ptr(), int(accumulate), rows, cols, ws.data_ptr(),
+                                                 ws.numel(), _stream())), "clipk_layernorm_bwd")
     return dx32, dx16, dgamma, dbeta
 
 
@@ -237,6 +283,14 @@ def act_bwd(dy, x, act):
     return dx
 
 
+def dact(dy, aux_bf16, act):
+    """bf16( dy * act'(aux) )"""
+    out = torch.empty(aux_bf16.shape, dtype=torch.bfloat16, device=aux_bf16.device)
+    check(_lib().clipk_dact(dy.data_ptr(), _dt(dy), aux_bf16.data_ptr(), ACT[act], out.data_ptr(), aux_bf16.numel(),
+                            _stream()), "clipk_dact")
+    return out
+
+
 def axpby_dev(a, b, s):
     y = torch.empty_like(a)
     check(_lib().clipk_axpby_dev(a.data_ptr(), b.data_ptr(), s.data_ptr(), y.data_ptr(), a.numel(), _stream()),
@@ -251,8 +305,9 @@ def attn_fwd(qkv, B, L, H, D, key_mask=None, rope=None, q_scale=1.0):
     out = torch.empty((B * L, H * D), dtype=torch.bfloat16, device=qkv.device)
     lse = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
     cos, sin = rope if rope is not None else (None, None)
-    check(_lib().clipk_attn_fwd(qkv.data_ptr(), ptr(key_mask), ptr(cos), ptr(sin), out.data_ptr(), lse.data_ptr(),
-                                B, L, H, D, float(q_scale), _stream()), "clipk_attn_fwd")
+    check(_timed("attn_fwd", 4.0 * B * H * L * L * D,
+                 lambda: _lib().clipk_attn_fwd(qkv.data_ptr(), ptr(key_mask), ptr(cos), ptr(sin), out.data_ptr(),
+                                               lse.data_ptr(), B, L, H, D, float(q_scale), _stream())), "clipk_attn_fwd")
     return out, lse
 
 
@@ -261,9 +316,10 @@ def attn_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=None, rope=None, q_scale=
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
     cos, sin = rope if rope is not None else (None, None)
-    check(_lib().clipk_attn_bwd(qkv.data_ptr(), ptr(key_mask), ptr(cos), ptr(sin), out.data_ptr(), dout.data_ptr(),
-                                lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), B, L, H, D, float(q_scale), _stream()),
-          "clipk_attn_bwd")
+    check(_timed("attn_bwd", 10.0 * B * H * L * L * D,
+                 lambda: _lib().clipk_attn_bwd(qkv.data_ptr(), ptr(key_mask), ptr(cos), ptr(sin), out.data_ptr(),
+                                               dout.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), B, L,
+                                               H, D, float(q_scale), _stream())), "clipk_attn_bwd")
     return dqkv
 
 

@@ -1,0 +1,126 @@
+"""Flat-buffer optimiser: AdamW + global-norm gradient clipping in two HIP kernels, sharded over ranks.
+
+Reference step (current/rna_clip_codes.ipynb:2033-2034,2076-2077; old/clip_opt.py:168-171):
+    clip_grad_norm_(model.parameters(), 1.0); AdamW(lr, weight_decay=0.01).step()   [+ CosineAnnealingLR(T_max=20)]
+
+MI355X design:
+  * every trainable parameter lives in ONE flat f32 buffer (params are views), gradients in a second one,
+    Adam moments in two more: the update is a single grid-stride kernel at HBM speed (16 B/param/step)
+    instead of ~300 small foreach launches;
+  * multi-GPU (ZeRO-1 style, one process per GPU): reduce-scatter(sum) the flat gradient over RCCL, each rank
+    updates its 1/W shard of the master weights and moments, all-gather the updated parameters.  On the
+    fully-connected xGMI mesh both collectives drive all 7 links at once; a ring all-reduce would be
+    per-link bound.  The global gradient norm is one scalar all-reduce of the shard sums of squares.
+"""
+from __future__ import annotations
+
+import math
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import functional as KF
+from . import ops
+
+_ALIGN = 64          # elements: every parameter starts on a 256-byte boundary (16-byte aligned kernel pointers)
+
+# kernel namespace (see loss.py): gloo/CPU tests of the sharding bookkeeping substitute a torch restatement
+_kernels = ops
+
+
+class FlatParams:
+    """Re-home the trainable parameters of `module` into one flat f32 buffer and give them flat .grad views."""
+
+    def __init__(self, module: torch.nn.Module, world_size: int = 1):
+        params = [p for p in module.parameters() if p.requires_grad]
+        if not params:
+            raise ValueError("no trainable parameters")
+        dev = params[0].device
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        chunk = _ALIGN * max(world_size, 1)
+        total = (total + chunk - 1) // chunk * chunk          # shard size stays _ALIGN-aligned
+        self.params, self.offsets, self.numel = params, offs, total
+        self.data = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(params, offs):
+                self.data[o:o + p.numel()].copy_(p.detach().reshape(-1))
+                p.data = self.data[o:o + p.numel()].view(p.shape)
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):          # keep .grad pointing into the flat buffer
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+
+class FusedAdamW:
+    """AdamW (torch.optim.AdamW semantics) + clip_grad_norm_ folded in, on FlatParams; optional sharding."""
+
+    def __init__(self, module: torch.nn.Module, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01,
+                 max_grad_norm: Optional[float] = 1.0, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if group is not None else 1
+        self.rank = dist.get_rank(group) if group is not None else 0
+        self.flat = FlatParams(module, self.world)
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.max_grad_norm = max_grad_norm
+        self.step_count = 0
+        n = self.flat.numel
+        self.shard = n // self.world
+        dev = self.flat.data.device
+        self.m = torch.zeros(self.shard, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(self.shard, dtype=torch.float32, device=dev)
+        self.gshard = torch.empty(self.shard, dtype=torch.float32, device=dev) if self.world > 1 else None
+        self.norm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def zero_grad(self):
+        self.flat.zero_grad()
+
+    @torch.no_grad()
+    def step(self, lr: Optional[float] = None) -> torch.Tensor:
+        """Returns the (device) squared global gradient norm before clipping."""
+        self.step_count += 1
+        lr = self.lr if lr is None else lr
+        lo = self.rank * self.shard
+        if self.world > 1:
+            if dist.get_backend(self.group) == "gloo":
+                dist.all_reduce(self.flat.grad, group=self.group)
+                self.gshard.copy_(self.flat.grad[lo:lo + self.shard])
+            else:
+                dist.reduce_scatter_tensor(self.gshard, self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)
+            g = self.gshard
+        else:
+            g = self.flat.grad
+        w = self.flat.data[lo:lo + self.shard]
+        _kernels.sumsq(g, out=self.norm_sq)
+        if self.world > 1:
+            dist.all_reduce(self.norm_sq, group=self.group)
+        clip = self.max_grad_norm is not None and self.max_grad_norm > 0
+        _kernels.adamw_step(w, g, self.m, self.v, lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count,
+                            grad_norm_sq=self.norm_sq if clip else None,
+                            max_norm=self.max_grad_norm if clip else 0.0)
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.flat.data, w.clone() if dist.get_backend(self.group) == "gloo" else w,
+                                        group=self.group)
+        KF.mark_weights_dirty()              # bf16 W / W^T copies are refreshed lazily at the next forward
+        return self.norm_sq
+
+    def state_dict(self):
+        return {"step": self.step_count, "m": self.m, "v": self.v, "lr": self.lr}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+        self.lr = sd.get("lr", self.lr)
+
+
+def cosine_annealing_lr(base_lr: float, epoch: int, t_max: int = 20, eta_min: float = 0.0) -> float:
+    """torch.optim.lr_scheduler.CosineAnnealingLR closed form (rna_clip_codes.ipynb:2034, T_max=20)."""
+    return eta_min + (base_lr - eta_min) * (1 + math.cos(math.pi * epoch / t_max)) / 2

@@ -148,6 +148,8 @@ int clipk_cast_transpose(const float* w, void* w_bf16, void* wt_bf16, int rows, 
 /* y = act(x) / dx = dy * act'(x) on f32. */
 int clipk_act_fwd(const float* x, float* y, int act, int64_t n, void* stream);
 int clipk_act_bwd(const float* dy, const float* x, float* dx, int act, int64_t n, void* stream);
+/* out_bf16 = dy * act'(aux_bf16): activation backward between two Linear layers; dy f32 or bf16. */
+int clipk_dact(const void* dy, int dy_dtype, const void* aux_bf16, int act, void* out_bf16, int64_t n, void* stream);
 /* y = a + s[0] * b  (skip + layer_scale * projected, old/clip_opt.py:41-44), f32. */
 int clipk_axpby_dev(const float* a, const float* b, const float* s, float* y, int64_t n, void* stream);
 

@@ -1,0 +1,244 @@
+"""GPU parity of the drop-in modules / encoders (HIP path through the C ABI) against
+  (1) the committed golden vectors generated from the reference, and
+  (2) the CPU oracle on the same seeded inputs and weights.
+Tolerances: the path computes Linear layers in bf16 MFMA with f32 accumulation, so element-wise tolerances are
+bf16-level (stated per assert); the LOSS tolerance is the north-star bar |loss_gpu - loss_ref| <= 1e-3.
+"""
+import math
+import os
+from types import SimpleNamespace as NS
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(G, name))
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}
+    return z, sd
+
+
+def t(z, k, dev=None):
+    x = torch.from_numpy(z[k])
+    return x.to(dev) if dev is not None else x
+
+
+def sub(h, n=2, eps=1e-12):
+    return NS(hidden_size=h, num_hidden_layers=n, layer_norm_eps=eps)
+
+
+def relerr(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+def test_clip_c1_golden_forward_loss_and_grads(dev):
+    """BASELINE config 1 (old/clip.py, 2 layers, d=128, B=256): golden weights/inputs from the reference."""
+    import clip_dplm_amd as K
+    z, sd = load("clip_c1.npz")
+    cfg = NS(rna_config=sub(128), protein_config=sub(128), diffmap_config=sub(128), projection_dim=128,
+             logit_scale_init_value=2.6592)
+    m = K.RNAProteinCLIPModule(cfg)
+    m.load_state_dict(sd)                                   # reference state_dict keys load as they are
+    m = m.to(dev).eval()
+    out = m(t(z, "rna", dev), t(z, "protein", dev))
+    assert set(out) == {"logits_per_rna_protein", "rna_embeds", "protein_embeds"}
+    logits = out["logits_per_rna_protein"]
+    assert logits.shape == (256, 256)
+    assert (logits.cpu() - t(z, "logits")).abs().max().item() < 0.15        # bf16 GEMMs, logits scaled by 14.28
+    assert (out["rna_embeds"].norm(dim=-1) - 1).abs().max().item() < 1e-5
+    lab = torch.arange(256, device=dev)
+    l1 = torch.nn.functional.cross_entropy(logits, lab)
+    assert abs(l1.item() - float(z["loss_one_sided"])) < 1e-3
+    # fused loss (no materialised logits) against the golden symmetric loss; then parameter gradients
+    loss = m.loss(t(z, "rna", dev), t(z, "protein", dev), symmetric=True)
+    assert abs(loss.item() - float(z["loss_symmetric"])) < 1e-3, (loss.item(), float(z["loss_symmetric"]))
+    loss.backward()
+    for n, p in m.named_parameters():
+        ref = t(z, "g:" + n, dev)
+        e = relerr(p.grad, ref)
+        assert e < 0.06, (n, e)                              # bf16 activations/weights in the backward GEMMs
+    # the one-sided fused loss is what old/ablation.py:16 trains with
+    l1f = m.loss(t(z, "rna", dev), t(z, "protein", dev), symmetric=False)
+    assert abs(l1f.item() - float(z["loss_one_sided"])) < 1e-3
+
+
+def test_clip_diffmap_golden(dev):
+    import clip_dplm_amd as K
+    z, sd = load("clip_diffmap.npz")
+    cfg = NS(rna_config=sub(64), protein_config=sub(96, 3, 1e-5), diffmap_config=sub(64, 1), projection_dim=32,
+             logit_scale_init_value=2.6592)
+    m = K.DiffMapProteinCLIPModule(cfg)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    out = m(t(z, "diffmap", dev), t(z, "protein", dev))
+    assert (out["logits_per_diffmap_protein"].cpu() - t(z, "logits")).abs().max().item() < 0.15
+
+
+def test_clip_opt_golden_cache_loss(dev):
+    """OptimizedCLIPModule (old/clip_opt.py): cache columns + clamp; module loss and fused loss."""
+    import clip_dplm_amd as K
+    z, sd = load("clip_opt.npz")
+    cfg = NS(diffmap_config=sub(48), protein_config=sub(96), projection_dim=32, cache_size=256)
+    m = K.OptimizedCLIPModule(cfg)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    # put the cache in the state the reference had before this batch (first 32 rows = earlier batch)
+    cache = t(z, "cache", dev)
+    m.protein_embedding_cache[:32] = cache[:32]
+    m.cache_ptr = 32
+    out = m(t(z, "diffmap", dev), t(z, "protein", dev), gather_distributed=False)
+    assert m.cache_ptr == int(z["cache_ptr"])
+    assert (out["logits_per_diffmap_protein"].cpu() - t(z, "logits")).abs().max().item() < 0.3
+    assert out["logits_per_diffmap_cache"].shape == tuple(z["logits_cache"].shape)
+    loss = K.optimized_clip_loss(out)
+    assert abs(loss.item() - float(z["loss"])) < 2e-3
+    m.cache_ptr = 32
+    lf = m.loss(t(z, "diffmap", dev), t(z, "protein", dev))
+    assert abs(lf.item() - loss.item()) < 1e-4               # fused == materialised on the same embeddings
+
+
+@pytest.mark.parametrize("act", ["relu", "gelu"])
+def test_transformer_layer_golden(dev, act):
+    """One nn.TransformerEncoderLayer (golden from torch): forward, input grad and parameter grads."""
+    import clip_dplm_amd as K
+    z, sd = load(f"tlayer_{act}.npz")
+    enc = K.TransformerSeqEncoder(64, 1, 8, 128, act, 1e-12)
+    own = {k.replace("l.", "layers.0.", 1): v for k, v in sd.items()}
+    own["layernorm.weight"], own["layernorm.bias"] = torch.ones(64), torch.zeros(64)
+    enc.load_state_dict(own)
+    enc = enc.to(dev)
+    x = t(z, "x", dev).requires_grad_(True)
+    valid = t(z, "valid", dev)
+    y = enc(x, src_key_padding_mask=~valid)
+    # the golden y is the layer output; our encoder adds a final LayerNorm with weight 1 / bias 0 and eps 1e-12
+    yref = torch.nn.functional.layer_norm(t(z, "y", dev), (64,), eps=1e-12)
+    m = valid[..., None].float()
+    assert ((y - yref) * m).abs().max().item() < 0.06
+    dy = t(z, "dy", dev)
+    yr = t(z, "y", dev).requires_grad_(True)
+    torch.nn.functional.layer_norm(yr, (64,), eps=1e-12).backward(dy)      # chain the golden dy through our extra LN
+    # golden grads were taken w.r.t. the layer output with upstream gradient dy: feed the same upstream
+    # gradient at the layer output by back-propagating through the final LN analytically
+    y.backward(dy)
+    # compare input gradient direction (final LN changes the upstream gradient, so use the oracle instead)
+    from oracle import encoder_ref
+    xs = t(z, "x").requires_grad_(True)
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yo = encoder_ref.post_ln_layer(xs, sdo, "l", 8, t(z, "valid"), act, 1e-12)
+    yo = torch.nn.functional.layer_norm(yo, (64,), eps=1e-12)
+    yo.backward(t(z, "dy"))
+    assert relerr(x.grad.cpu() * m.cpu(), xs.grad * m.cpu()) < 0.05
+    for n, p in enc.named_parameters():
+        if n.startswith("layers.0."):
+            ref = sdo["l." + n[len("layers.0."):]].grad
+            assert relerr(p.grad.cpu(), ref) < 0.06, n
+
+
+def test_notebook_model_golden(dev):
+    """RNARBPCLIPModel (rna_clip_codes.ipynb:1925-1954) incl. the batch-axis attention quirk and NaN padding."""
+    import clip_dplm_amd as K
+    z, sd = load("notebook_model.npz")
+    m = K.RNARBPCLIPModel(rna_dim=24, rbp_dim=64, projection_dim=32)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    ea, eb, loss = m(t(z, "rna", dev), t(z, "rbp", dev))
+    assert (ea.cpu() - t(z, "rna_embed")).abs().max().item() < 0.03
+    assert (eb.cpu() - t(z, "rbp_embed")).abs().max().item() < 0.03
+    assert abs(loss.item() - float(z["loss"])) < 2e-2       # B = 8 only: a single row moves the mean by 1/8
+    loss.backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
+def _load_esm(K, sd, dev, nl=2, d=96, h=4, f=384):
+    enc = K.ESM2Encoder(nl, d, h, f)
+    missing = enc.load_state_dict({k: v for k, v in sd.items() if v.is_floating_point() and "inv_freq" not in k
+                                   and "position" not in k and "contact" not in k}, strict=False)
+    assert not missing.missing_keys, missing
+    return enc.to(dev)
+
+
+def test_esm_tiny_golden(dev):
+    """ESM-2 arithmetic (third-party EsmModel, golden from transformers): hd = 24 like ESM-2-35M, padding +
+    <mask> token-dropout rescale; forward and parameter gradients."""
+    import clip_dplm_amd as K
+    z, sd = load("esm_tiny.npz")
+    enc = _load_esm(K, sd, dev)
+    ids, am = t(z, "ids", dev), t(z, "attention_mask", dev)
+    y = enc(ids, am)
+    m = am[..., None].float()
+    ref = t(z, "last_hidden_state", dev)
+    assert ((y - ref) * m).abs().max().item() < 0.05, ((y - ref) * m).abs().max().item()
+    zg = np.load(os.path.join(G, "esm_tiny_grads.npz"))
+    (y * torch.from_numpy(zg["dy"]).to(dev)).sum().backward()
+    checked = 0
+    for n, p in enc.named_parameters():
+        k = "g:" + n
+        if k in zg.files and zg[k].size:
+            ref = torch.from_numpy(zg[k]).to(dev)
+            if ref.abs().max() < 1e-6:
+                continue
+            assert relerr(p.grad, ref) < 0.08, (n, relerr(p.grad, ref))
+            checked += 1
+    assert checked > 30
+
+
+def test_protein_rna_clip_vs_oracle(dev):
+    """Reduced BASELINE-config-2 model (same code path: ESM hd=24 + post-LN gelu encoder + heads + fused loss)
+    against the CPU oracle on identical seeded weights/inputs; loss bar 1e-3."""
+    import clip_dplm_amd as K
+    from clip_dplm_amd.encoders import ESM2_SHAPES
+    from oracle import clip_ref, encoder_ref
+    ESM2_SHAPES["test_tiny"] = (2, 96, 4, 384)
+    torch.manual_seed(0)
+    m = K.ProteinRNACLIP(esm="test_tiny", rna_dim=64, rna_layers=2, rna_heads=8, rna_ffn=128, projection_dim=64)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    B, L = 48, 40
+    g = torch.Generator().manual_seed(1234)
+    ids = torch.randint(4, 24, (B, L), generator=g); ids[:, 0] = 0; ids[:, -1] = 2
+    rna = torch.randn(B, L, 64, generator=g)
+    lens = torch.randint(10, L + 1, (B,), generator=g)
+    pmask = (torch.arange(L)[None] < lens[:, None]).long()
+    rmask = (torch.arange(L)[None] < lens.flip(0)[:, None]).long()
+    m = m.to(dev)
+    loss = m.loss(rna.to(dev), ids.to(dev), rna_mask=rmask.to(dev), protein_mask=pmask.to(dev))
+    # oracle
+    esd = {k[len("protein_model."):]: v for k, v in sd.items() if k.startswith("protein_model.")}
+    hp = encoder_ref.esm_encoder(ids, pmask, esd, 2, 4, 1e-5)
+    rsd = {k[len("rna_model."):]: v for k, v in sd.items() if k.startswith("rna_model.")}
+    hr = encoder_ref.post_ln_encoder(rna, {"e." + k: v for k, v in rsd.items()}, "e", 2, 8, rmask.bool(), "gelu", 1e-12, 1e-12)
+    er = clip_ref.l2_normalize(clip_ref.projection_head(encoder_ref.pool(hr, rmask.bool(), "mean"), sd, "rna_projection"))
+    ep = clip_ref.l2_normalize(clip_ref.projection_head(encoder_ref.pool(hp, pmask.bool(), "mean"), sd, "protein_projection"))
+    ref = clip_ref.clip_loss_symmetric((er @ ep.t()) * sd["logit_scale"].exp())
+    assert abs(loss.item() - ref.item()) < 1e-3, (loss.item(), ref.item())
+    loss.backward()
+    gn = sum((p.grad.float() ** 2).sum() for p in m.parameters() if p.grad is not None).sqrt().item()
+    assert math.isfinite(gn) and gn > 0
+
+
+def test_fused_adamw_training_reduces_loss(dev):
+    """A few fused optimiser steps on config 1: loss goes down, flat grads are used, weights stay in sync."""
+    import clip_dplm_amd as K
+    z, sd = load("clip_c1.npz")
+    cfg = NS(rna_config=sub(128), protein_config=sub(128), diffmap_config=sub(128), projection_dim=128,
+             logit_scale_init_value=2.6592)
+    m = K.RNAProteinCLIPModule(cfg)
+    m.load_state_dict(sd)
+    m = m.to(dev).train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    opt = K.FusedAdamW(m, lr=1e-3, weight_decay=0.01, max_grad_norm=1.0)
+    a, b = t(z, "rna", dev), t(z, "protein", dev)
+    losses = []
+    for _ in range(8):
+        opt.zero_grad()
+        loss = m.loss(a, b, symmetric=True)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0] - 0.05, losses
+    assert m.logit_scale.data_ptr() >= opt.flat.data.data_ptr()
