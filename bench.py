@@ -45,13 +45,18 @@ def synth_batch(B, L, rna_dim, device, seed):
 def cpu_baseline(model_sd, cfg, L, sample_b=8, steps=2):
     """Time the CPU oracle (kind 'port') on a bounded sample of the same workload: forward + backward + AdamW."""
     from oracle import model_ref
-    ncores = os.cpu_count() or 1
+    try:
+        ncores = len(os.sched_getaffinity(0))             # the cores this process may actually use (cgroup share)
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    ncores = max(1, min(ncores, 64))
     torch.set_num_threads(ncores)
     sd = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in model_sd.items()}
     params = [v for v in sd.values() if v.requires_grad]
     opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01)
     rna, ids = synth_batch(sample_b, L, cfg["rna_dim"], "cpu", 1234)
     times = []
+    budget_s, t_start = 30.0, time.perf_counter()
     for it in range(steps + 1):
         t0 = time.perf_counter()
         opt.zero_grad()
@@ -61,12 +66,15 @@ def cpu_baseline(model_sd, cfg, L, sample_b=8, steps=2):
         loss.backward()
         torch.nn.utils.clip_grad_norm_(params, 1.0)
         opt.step()
-        if it > 0:
-            times.append(time.perf_counter() - t0)
-    dt = sum(times) / len(times)
-    return {"value": round(sample_b / dt, 3), "unit": "seq-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} training steps (fwd+bwd+clip+AdamW) of the CPU oracle at B={sample_b}, L={L}, f32, "
-                      f"after 1 warm-up step; {dt:.2f} s/step"}
+        times.append(time.perf_counter() - t0)
+        print(f"[cpu_baseline] step {it}: {times[-1]:.2f} s on {ncores} threads", file=sys.stderr, flush=True)
+        if time.perf_counter() - t_start > budget_s:      # bounded sample: never hold the bench for minutes
+            break
+    timed = times[1:] if len(times) > 1 else times         # drop the warm-up step when there is more than one
+    dt = sum(timed) / len(timed)
+    return {"value": round(sample_b / dt, 3), "unit": "seq-pairs/s", "cores": ncores, "kind": "port",
+            "sample": f"{len(timed)} training step(s) (fwd+bwd+clip+AdamW) of the CPU oracle at B={sample_b}, L={L}, "
+                      f"f32, {'after 1 warm-up step' if len(times) > 1 else 'no warm-up (time budget)'}; {dt:.2f} s/step"}
 
 
 def main():
@@ -111,8 +119,12 @@ def main():
         opt.step()
         return loss
 
-    for _ in range(args.warmup):
+    tw = time.perf_counter()
+    for i in range(args.warmup):
         step()
+        torch.cuda.synchronize()
+        if rank == 0:
+            print(f"[bench] warm-up step {i}: {time.perf_counter() - tw:.2f} s since start", file=sys.stderr, flush=True)
     timer = None
     if not args.no_kernel_timers:
         timer = ops.KernelTimer()
@@ -132,6 +144,8 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
+    if rank == 0:
+        print(f"[bench] {args.steps} timed steps: {dt:.3f} s", file=sys.stderr, flush=True)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()

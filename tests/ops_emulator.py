@@ -1,0 +1,270 @@
+"""TEST-ONLY torch/CPU restatement of clip_dplm_amd.ops (same signatures), used to exercise the HOST logic —
+hand-written layer backward wiring, flat-buffer optimiser, rank bookkeeping over gloo — in the CPU-only
+container.  It is installed by monkeypatching inside tests (see `install`); the product never imports it and has
+no CPU path of its own.  Rounds to bf16 where the kernels round, so CPU results track the GPU path closely.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+BF = torch.bfloat16
+
+
+def _act(x, act):
+    if act == "relu":
+        return torch.relu(x)
+    if act == "gelu":
+        return F.gelu(x)
+    return x
+
+
+def _act_grad(x, act):
+    if act == "relu":
+        return (x > 0).to(x.dtype)
+    if act == "gelu":
+        cdf = 0.5 * (1 + torch.erf(x / math.sqrt(2)))
+        pdf = torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+        return cdf + x * pdf
+    return torch.ones_like(x)
+
+
+def gemm_nt(a, b, bias=None, act=None, out_dtype=BF, residual=None, out_preact=False, dact_aux=None, dact=None,
+            alpha=1.0, out=None):
+    v = (a.float() @ b.float().t()) * alpha
+    if bias is not None:
+        v = v + bias
+    pre = v.to(BF) if out_preact else None
+    v = _act(v, act)
+    if dact_aux is not None:
+        v = v * _act_grad(dact_aux.float(), dact)
+    if residual is not None:
+        v = v + residual.float()
+    c = v.to(out.dtype if out is not None else out_dtype)
+    if out is not None:
+        out.copy_(c)
+        c = out
+    return (c, pre) if out_preact else c
+
+
+def gemm_wgrad(dy, x, dw=None, dbias=None, accumulate=False, want_bias=False):
+    g = dy.float().t() @ x.float()
+    b = dy.float().sum(0)
+    if dw is None:
+        dw = g
+    else:
+        dw.copy_(dw + g if accumulate else g)
+    if want_bias or dbias is not None:
+        if dbias is None:
+            dbias = b
+        else:
+            dbias.copy_(dbias + b if accumulate else b)
+    return dw, dbias
+
+
+def _scores(x, y, scale, cache):
+    keys = y if cache is None else torch.cat([y, cache], 0)
+    return (x.double() @ keys.double().t()) * scale.double()
+
+
+def simce_lse(x, y, scale, label_offset=0, cache=None):
+    s = _scores(x, y, scale, cache)
+    idx = torch.arange(x.shape[0]) + label_offset
+    return torch.logsumexp(s, 1).float(), s[torch.arange(x.shape[0]), idx].float()
+
+
+def simce_grad(x, y, scale, lse_x, lse_y, w_row, w_col, inv_bg, label_offset=0, cache=None):
+    s = _scores(x, y, scale, cache)
+    ny = y.shape[0]
+    g = w_row * torch.exp(s - lse_x.double()[:, None])
+    g[:, :ny] += w_col * torch.exp(s[:, :ny] - lse_y.double()[None, :])
+    idx = torch.arange(x.shape[0]) + label_offset
+    g[torch.arange(x.shape[0]), idx] -= (w_row + w_col)
+    g = g * inv_bg
+    keys = y if cache is None else torch.cat([y, cache], 0)
+    dx = (g @ keys.double()) * scale.double()
+    dsc = (g * (s / scale.double())).sum(1)
+    return dx.float(), dsc.float()
+
+
+def sim_logits(x, y, scale):
+    return (x @ y.t()) * scale
+
+
+def layernorm_fwd(x, gamma, beta, eps, act=None, want_f32=True, want_bf16=False, want_stats=True):
+    xf = x.float()
+    mean = xf.mean(-1)
+    var = ((xf - mean[:, None]) ** 2).mean(-1)
+    rstd = torch.rsqrt(var + eps)
+    y = _act((xf - mean[:, None]) * rstd[:, None] * gamma + beta, act)
+    return (y if want_f32 else None), (y.to(BF) if want_bf16 else None), mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=None, dx_add=None, want_f32=True, want_bf16=False,
+                  dgamma=None, dbeta=None, accumulate=False):
+    xf, dyf = x.float(), dy.float()
+    xh = (xf - mean[:, None]) * rstd[:, None]
+    if act is not None:
+        dyf = dyf * _act_grad(xh * gamma + beta, act)
+    g = dyf * gamma
+    c1 = g.mean(-1, keepdim=True)
+    c2 = (g * xh).mean(-1, keepdim=True)
+    dx = rstd[:, None] * (g - c1 - xh * c2)
+    if dx_add is not None:
+        dx = dx + dx_add
+    dg, db = (dyf * xh).sum(0), dyf.sum(0)
+    if dgamma is not None:
+        dgamma.copy_(dgamma + dg if accumulate else dg)
+        dbeta.copy_(dbeta + db if accumulate else db)
+        dg, db = dgamma, dbeta
+    return (dx if want_f32 else None), (dx.to(BF) if want_bf16 else None), dg, db
+
+
+def l2norm_fwd(x, eps=1e-12):
+    n = x.norm(dim=-1)
+    return x / n.clamp_min(eps)[:, None], n
+
+
+def l2norm_bwd(dy, y, n, eps=1e-12):
+    dot = (dy * y).sum(-1, keepdim=True)
+    return (dy - y * dot) / n.clamp_min(eps)[:, None]
+
+
+def to_bf16(x):
+    return x.to(BF)
+
+
+def to_f32(x):
+    return x.float()
+
+
+def cast_transpose(w, want_w=True, want_wt=True, w_out=None, wt_out=None):
+    wb = w.to(BF)
+    return wb, wb.t().contiguous()
+
+
+def act_fwd(x, act):
+    return _act(x, act)
+
+
+def act_bwd(dy, x, act):
+    return dy * _act_grad(x, act)
+
+
+def dact(dy, aux_bf16, act):
+    return (dy.float() * _act_grad(aux_bf16.float(), act)).to(BF)
+
+
+def axpby_dev(a, b, s):
+    return a + s * b
+
+
+def _attn_math(qkv, B, L, H, D, key_mask, rope, q_scale):
+    x = qkv.view(B, L, 3, H, D).permute(2, 0, 3, 1, 4)
+    q, k, v = x[0], x[1], x[2]
+    if rope is not None:
+        cos, sin = rope
+        cosf, sinf = torch.cat([cos, cos], -1)[None, None], torch.cat([sin, sin], -1)[None, None]
+
+        def rot(t):
+            return torch.cat([-t[..., D // 2:], t[..., : D // 2]], -1)
+        q = (q * cosf + rot(q) * sinf).to(BF).float()        # kernels keep rotated q/k in bf16
+        k = (k * cosf + rot(k) * sinf).to(BF).float()
+    s = (q @ k.transpose(-1, -2)) * q_scale
+    if key_mask is not None:
+        s = s.masked_fill(~key_mask.bool()[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, -1)
+    o = p @ v
+    return o.permute(0, 2, 1, 3).reshape(B * L, H * D), torch.logsumexp(s, -1)
+
+
+def attn_fwd(qkv, B, L, H, D, key_mask=None, rope=None, q_scale=1.0):
+    o, lse = _attn_math(qkv.float(), B, L, H, D, key_mask, rope, q_scale)
+    return o.to(BF), lse
+
+
+def attn_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=None, rope=None, q_scale=1.0):
+    with torch.enable_grad():
+        q = qkv.float().detach().requires_grad_(True)
+        o, _ = _attn_math(q, B, L, H, D, key_mask, rope, q_scale)
+        g, = torch.autograd.grad(o, q, dout.float())
+    return g.to(BF)
+
+
+def embed_fwd(ids, table, row_scale=None, mask=None, mask_token_id=-1):
+    B, L = ids.shape
+    x = table[ids]
+    sc = torch.ones(B, L)
+    if row_scale is not None:
+        sc = sc * row_scale[:, None]
+    if mask is not None:
+        sc = sc * mask.view(B, L).float()
+    sc = sc * (ids != mask_token_id).float()
+    return (x * sc[..., None]).reshape(B * L, -1)
+
+
+def embed_bwd(ids, dx, dtable, row_scale=None, mask=None, mask_token_id=-1):
+    B, L = ids.shape
+    sc = torch.ones(B, L)
+    if row_scale is not None:
+        sc = sc * row_scale[:, None]
+    if mask is not None:
+        sc = sc * mask.view(B, L).float()
+    sc = sc * (ids != mask_token_id).float()
+    dtable.index_add_(0, ids.view(-1), dx * sc.view(-1, 1))
+    return dtable
+
+
+def pool_fwd(x, B, L, mask=None, mode=1):
+    x3 = x.view(B, L, -1)
+    if mode == 0:
+        return x3[:, 0].clone()
+    if mask is None:
+        return x3.mean(1)
+    m = mask.view(B, L).float()
+    return (x3 * m[..., None]).sum(1) / m.sum(1, keepdim=True)
+
+
+def pool_bwd(dy, B, L, mask=None, mode=1):
+    d = dy.shape[-1]
+    if mode == 0:
+        dx = torch.zeros(B, L, d)
+        dx[:, 0] = dy
+        return dx.view(B * L, d)
+    m = mask.view(B, L).float() if mask is not None else torch.ones(B, L)
+    return (dy[:, None] * (m / m.sum(1, keepdim=True))[..., None]).reshape(B * L, d)
+
+
+def sumsq(g, out=None):
+    v = (g.double() ** 2).sum().float().reshape(1)
+    if out is not None:
+        out.copy_(v)
+        return out
+    return v
+
+
+def adamw_step(w, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq=None, max_norm=0.0, grad_scale=1.0,
+               w_bf16=None):
+    clip = grad_scale
+    if grad_norm_sq is not None:
+        norm = grad_norm_sq.sqrt().item() * grad_scale
+        clip *= min(1.0, max_norm / (norm + 1e-6))
+    gi = g * clip
+    w.mul_(1 - lr * weight_decay)
+    m.mul_(beta1).add_(gi, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(gi, gi, value=1 - beta2)
+    bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+    w.addcdiv_(m, v.sqrt() / math.sqrt(bc2) + eps, value=-lr / bc1)
+
+
+_NAMES = [n for n, f in list(globals().items()) if callable(f) and not n.startswith("_") and n not in ("install",)]
+
+
+def install(monkeypatch):
+    """Route clip_dplm_amd.ops.* to this restatement for the duration of one test."""
+    from clip_dplm_amd import ops
+    for n in _NAMES:
+        if hasattr(ops, n) and n not in ("KernelTimer",):
+            monkeypatch.setattr(ops, n, globals()[n])

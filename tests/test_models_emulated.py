@@ -1,0 +1,26 @@
+"""CPU: run every model-level parity test of test_gpu_models.py with tests/ops_emulator.py standing in for the
+HIP kernels (host wiring + tolerance calibration in the GPU-less container).  The same functions run against the
+real kernels under `-m gpu`."""
+import pytest
+import torch
+
+import ops_emulator
+import test_gpu_models as T
+
+CASES = [
+    ("c1", T.test_clip_c1_golden_forward_loss_and_grads, {}),
+    ("diffmap", T.test_clip_diffmap_golden, {}),
+    ("clip_opt", T.test_clip_opt_golden_cache_loss, {}),
+    ("tlayer_relu", T.test_transformer_layer_golden, {"act": "relu"}),
+    ("tlayer_gelu", T.test_transformer_layer_golden, {"act": "gelu"}),
+    ("notebook", T.test_notebook_model_golden, {}),
+    ("esm_tiny", T.test_esm_tiny_golden, {}),
+    ("protein_rna", T.test_protein_rna_clip_vs_oracle, {}),
+    ("adamw_train", T.test_fused_adamw_training_reduces_loss, {}),
+]
+
+
+@pytest.mark.parametrize("name,fn,kw", CASES, ids=[c[0] for c in CASES])
+def test_emulated(monkeypatch, name, fn, kw):
+    ops_emulator.install(monkeypatch)
+    fn(torch.device("cpu"), **kw)
