@@ -14,6 +14,9 @@
 //   * 1-D grid with an XCD-aware bijective remap; N-tiles vary fastest so one XCD's L2 keeps the A
 //     row panel while it sweeps the (small, L2-resident) weight.
 #include "common.h"
+#include <stdlib.h>
+
+extern "C" int clipk_gemm_nt_v2_launch(const clipk_gemm_args* a, void* stream);
 
 namespace {
 
@@ -218,6 +221,9 @@ extern "C" int clipk_gemm_nt(const clipk_gemm_args* a, void* stream) {
   if (a->out_preact && (!aligned16(a->out_preact) || (a->ldp & 7))) return CLIPK_ERR_BAD_ARG;
   if (a->dact_aux && (!aligned16(a->dact_aux) || (a->ldd & 7))) return CLIPK_ERR_BAD_ARG;
   if (a->residual && (!aligned16(a->residual) || (a->ldr & 7))) return CLIPK_ERR_BAD_ARG;
+  // fast path: LDS-DMA staged, 4 workgroups per CU (gemm_nt_v2.hip); needs whole 32-deep K steps
+  const bool force_v1 = getenv("CLIPK_GEMM_V1") != nullptr;     // A/B switch for tools/bench_kernels.py
+  if (!force_v1 && (a->K & 31) == 0) return clipk_gemm_nt_v2_launch(a, stream);
   Params p;
   p.A = (const unsigned short*)a->A; p.lda = a->lda;
   p.B = (const unsigned short*)a->B; p.ldb = a->ldb;

@@ -1,0 +1,209 @@
+// gemm_nt_v2.hip — fast path of clipk_gemm_nt for K % 32 == 0: same contract and epilogue as gemm_nt.hip.
+//
+// What changed against the register-staged v1 kernel, and why (measured on MI355X, profiles/):
+//   * operand tiles go HBM/L2 -> LDS directly with global_load_lds_dwordx4 (LDS-DMA, 1 KiB per wave-instruction):
+//     no staging VGPRs, no ds_write pass.  The LDS image stays the XOR-swizzled one of v1; because an LDS-DMA
+//     writes lane-linear bytes, the swizzle is applied to the per-lane SOURCE address instead
+//     (cdna_hip_programming.md §5.4 rule 21);
+//   * one 32 KiB K-step buffer instead of two: 4 workgroups per CU fit (LDS 4 x 32 KiB, <= 128 VGPRs), and the
+//     other resident workgroups' MFMAs cover this one's load phase — with K = 480..768 a tile has only 8-12
+//     K-steps, so cross-workgroup overlap hides prologue / epilogue better than in-kernel double buffering;
+//   * swapped operand roles (A fragment = weight rows, B fragment = activation rows): each lane then owns 4
+//     consecutive output columns of one row, so the accumulator -> LDS staging of the epilogue is 16
+//     ds_write_b128 per lane instead of 64 ds_write_b32.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
+constexpr int A_TILE_BYTES = BM * BK * 2;               // activations  [128 m][64 k]
+constexpr int B_TILE_BYTES = BN * BK * 2;               // weights      [128 n][64 k]
+constexpr int LDS_BYTES = A_TILE_BYTES + B_TILE_BYTES;  // 32 KiB
+constexpr int EPI_LD = 68;                              // f32 per staged row (16 rows x 64 cols per wave + pad)
+
+struct Params {
+  const unsigned short* A; long lda;
+  const unsigned short* B; long ldb;
+  void* C; long ldc; int c_f32;
+  int M, N, K;
+  const float* bias;
+  int act;
+  unsigned short* out_preact; long ldp;
+  const unsigned short* dact_aux; long ldd; int dact;
+  const void* residual; long ldr; int r_f32;
+  float alpha;
+  int ntn;
+};
+
+__device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(gptr, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(NTHREADS, 4) void gemm_nt_v2_kernel(const Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int M = p.M, N = p.N, K = p.K;
+
+  // ---- LDS-DMA assignment: wave w, piece i (0..3) fills rows 8*(4w+i) .. +7 of each operand tile.
+  // lane -> (row in piece = lane>>3, physical 16-B slot = lane&7); source chunk = slot ^ ((row>>1)&7)
+  const int prow = lane >> 3, pslot = lane & 7;
+  const unsigned short* asrc[4];
+  const unsigned short* bsrc[4];
+  int kchunk[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 8 * (4 * wid + i) + prow;
+    kchunk[i] = (pslot ^ ((row >> 1) & 7)) * 8;
+    int ra = m0 + row; ra = ra < M ? ra : M - 1;
+    int rb = n0 + row; rb = rb < N ? rb : N - 1;
+    asrc[i] = p.A + (long)ra * p.lda;
+    bsrc[i] = p.B + (long)rb * p.ldb;
+  }
+
+  f32x4 acc[4][4];          // [n-tile i][m-tile j]: rows n = 4g+r, col m = lane&15
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int lane_sw = (lane >> 1) & 7;
+  const int frow = lane & 15, fch = lane >> 4;
+  const int x_frag_off = (wm * 64 + frow) * 128;                   // activation rows (B operand)
+  const int w_frag_off = A_TILE_BYTES + (wn * 64 + frow) * 128;    // weight rows (A operand)
+
+  const int nk = (K + BK - 1) / BK;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int k = k0 + kchunk[i];
+      k = k < K ? k : 0;                                 // K tail (K % 64 == 32): slot is never read, keep the address valid
+      char* dst = smem + (4 * wid + i) * 1024;
+      glds16(asrc[i] + k, dst);
+      glds16(bsrc[i] + k, dst + A_TILE_BYTES);
+    }
+    __syncthreads();                                     // drains the LDS-DMA (vmcnt(0)) and publishes the tile
+    const int ksub = (k0 + 32 < K) ? 2 : 1;
+    for (int kk = 0; kk < ksub; ++kk) {
+      const int choff = (((kk * 4 + fch) ^ lane_sw) << 4);
+      bf16x8 wf[4], xf[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        wf[t] = *reinterpret_cast<const bf16x8*>(smem + w_frag_off + t * 2048 + choff);
+        xf[t] = *reinterpret_cast<const bf16x8*>(smem + x_frag_off + t * 2048 + choff);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();                                     // everyone done reading before the next DMA lands
+  }
+
+  // ---- epilogue, one 16-row m-tile at a time through a wave-private LDS slab [16 m][64 n (+4)] f32
+  float* eb = reinterpret_cast<float*>(smem) + wid * 16 * EPI_LD;
+  const float alpha = p.alpha;
+  const int g = lane >> 4, li = lane & 15;
+  const int ecol = (lane & 7) * 8;
+  const int gn = n0 + wn * 64 + ecol;
+  float bv[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) bv[c] = 0.f;
+  if (p.bias && gn < N) {
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + gn);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + gn + 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { bv[c] = b0[c]; bv[4 + c] = b1[c]; }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<f32x4*>(eb + li * EPI_LD + i * 16 + 4 * g) = acc[i][j] * alpha;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int row = half * 8 + (lane >> 3);
+      const int gm = m0 + wm * 64 + j * 16 + row;
+      float v[8];
+      {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(eb + row * EPI_LD + ecol);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(eb + row * EPI_LD + ecol + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { v[c] = v0[c] + bv[c]; v[4 + c] = v1[c] + bv[4 + c]; }
+      }
+      if (gm < M && gn < N) {
+        if (p.out_preact) {
+          u32x4 o;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) o[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
+          *reinterpret_cast<u32x4*>(p.out_preact + (long)gm * p.ldp + gn) = o;
+        }
+        if (p.act != CLIPK_ACT_NONE) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) v[c] = act_apply(v[c], p.act);
+        }
+        if (p.dact_aux) {
+          const u32x4 a = *reinterpret_cast<const u32x4*>(p.dact_aux + (long)gm * p.ldd + gn);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            v[2 * c] *= act_grad(bf16_to_f32((unsigned short)(a[c] & 0xffffu)), p.dact);
+            v[2 * c + 1] *= act_grad(bf16_to_f32((unsigned short)(a[c] >> 16)), p.dact);
+          }
+        }
+        if (p.residual) {
+          if (p.r_f32) {
+            const float* r = reinterpret_cast<const float*>(p.residual) + (long)gm * p.ldr + gn;
+            const f32x4 r0 = *reinterpret_cast<const f32x4*>(r);
+            const f32x4 r1 = *reinterpret_cast<const f32x4*>(r + 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { v[c] += r0[c]; v[4 + c] += r1[c]; }
+          } else {
+            const u32x4 a = *reinterpret_cast<const u32x4*>(
+                reinterpret_cast<const unsigned short*>(p.residual) + (long)gm * p.ldr + gn);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              v[2 * c] += bf16_to_f32((unsigned short)(a[c] & 0xffffu));
+              v[2 * c + 1] += bf16_to_f32((unsigned short)(a[c] >> 16));
+            }
+          }
+        }
+        if (p.c_f32) {
+          float* c = reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn;
+          *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(c + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+          u32x4 o;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) o[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
+          *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.C) + (long)gm * p.ldc + gn) = o;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// called by clipk_gemm_nt (gemm_nt.hip) after it validated the arguments; returns CLIPK_OK / launch error
+extern "C" int clipk_gemm_nt_v2_launch(const clipk_gemm_args* a, void* stream) {
+  Params p;
+  p.A = (const unsigned short*)a->A; p.lda = a->lda;
+  p.B = (const unsigned short*)a->B; p.ldb = a->ldb;
+  p.C = a->C; p.ldc = a->ldc; p.c_f32 = (a->c_dtype == CLIPK_F32);
+  p.M = a->M; p.N = a->N; p.K = a->K;
+  p.bias = a->bias; p.act = a->act;
+  p.out_preact = (unsigned short*)a->out_preact; p.ldp = a->ldp;
+  p.dact_aux = (const unsigned short*)a->dact_aux; p.ldd = a->ldd; p.dact = a->dact;
+  p.residual = a->residual; p.ldr = a->ldr; p.r_f32 = (a->r_dtype == CLIPK_F32);
+  p.alpha = a->alpha;
+  const int ntm = (a->M + BM - 1) / BM, ntn = (a->N + BN - 1) / BN;
+  p.ntn = ntn;
+  hipLaunchKernelGGL(gemm_nt_v2_kernel, dim3(ntm * ntn), dim3(NTHREADS), LDS_BYTES, (hipStream_t)stream, p);
+  return clipk_check_launch();
+}

@@ -4,23 +4,27 @@
 // gfx950 design:
 //   * the contraction runs over the M tokens, which are the ROW index of both operands in memory, so
 //     both MFMA fragments are "8 consecutive m at a fixed column": exactly what the CDNA4 transposed
-//     LDS read ds_read_b64_tr_b16 delivers from a row-major tile.  Tiles are staged row-major
-//     (coalesced 256-B rows) with a 288-byte LDS row stride that tools/lds_conflicts.py shows
-//     conflict-free for the 4x16 transposed blocks; no transposed copies of activations ever exist;
+//     LDS read ds_read_b64_tr_b16 delivers from a row-major tile.  No transposed copy of an activation ever
+//     exists in HBM;
+//   * tiles are [64 m][128 cols] bf16 (256-B rows) filled by LDS-DMA (global_load_lds_dwordx4, 1 KiB = 4 rows
+//     per wave-instruction).  An LDS-DMA writes lane-linear bytes, so rows cannot be padded; instead the
+//     32-byte column segments are XOR-swizzled with (row & 7) — applied to the per-lane SOURCE address and to
+//     the transposed-read address — which makes every 4x16 transposed block read conflict-free
+//     (tools/lds_conflicts.py);
+//   * one 32 KiB step buffer, <= 128 VGPRs: 4 workgroups per CU overlap each other's load and MFMA phases;
 //   * 128(n) x 128(k) f32 output tile per workgroup, 4 waves as 2x2, 16x16x32 bf16 MFMA;
-//   * M is split across workgroups (enough splits to fill 256 CUs); each split writes an f32 slab and a
-//     second kernel sums the slabs in a fixed order — deterministic, no float atomics;
-//   * the bias gradient rides along as one extra MFMA per n-tile against an all-ones B fragment in
-//     the k-tile-0 workgroups (no second pass over dY).
+//   * M is split across workgroups; each split writes an f32 slab and a second kernel sums the slabs in a
+//     fixed order — deterministic, no float atomics;
+//   * the bias gradient rides along as one extra MFMA per n-tile against an all-ones B fragment in the
+//     k-tile-0 workgroups (no second pass over dY).
 #include "common.h"
 
 namespace {
 
 constexpr int BN = 128, BKO = 128, BMS = 64, NTHREADS = 256;
-constexpr int ROWB = 288;                               // LDS row stride in bytes (256 + 32)
-constexpr int TILE_BYTES = BMS * ROWB;                  // 18 KiB per operand tile
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;              // 72 KiB
+constexpr int ROWB = 256;                               // LDS row bytes (128 bf16, unpadded: LDS-DMA image)
+constexpr int TILE_BYTES = BMS * ROWB;                  // 16 KiB per operand tile
+constexpr int LDS_BYTES = 2 * TILE_BYTES;               // 32 KiB
 
 struct WP {
   const unsigned short* dY; long lddy;
@@ -31,22 +35,31 @@ struct WP {
   int ntn, ntk, splits, m_per_split;
 };
 
-__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int row0, int colbyte) {
-  // rows row0..row0+3 and row0+16..row0+19 of a 16-column block -> 8 k-values of one column per lane
-  typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// logical (row, 32-byte segment) -> byte offset in the swizzled tile
+__device__ __forceinline__ int seg_off(int row, int seg) { return row * ROWB + ((seg ^ (row & 7)) << 5); }
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int row0, int seg, int pbyte) {
+  // rows row0 (+16) supplied by this lane, 16-column block `seg`; returns 8 m-values of one column
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (s16x4 __attribute__((address_space(3)))*)(tile + row0 * ROWB + colbyte));
+      (s16x4 __attribute__((address_space(3)))*)(tile + seg_off(row0, seg) + pbyte));
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (s16x4 __attribute__((address_space(3)))*)(tile + (row0 + 16) * ROWB + colbyte));
+      (s16x4 __attribute__((address_space(3)))*)(tile + seg_off(row0 + 16, seg) + pbyte));
   bf16x8 f;
   f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
   f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
   return f;
 }
 
-__global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WP p) {
+__device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(gptr, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(NTHREADS, 3) void wgrad_kernel(const WP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wid >> 1, wk = wid & 1;
   const int ntiles = p.ntn * p.ntk;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -58,36 +71,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WP p) {
   int m_end = m_beg + p.m_per_split; m_end = m_end < p.M ? m_end : p.M;
   const bool do_bias = (p.bslab != nullptr) && (tk == 0) && (wk == 0);
 
-  // staging: chunk c = tid + 256*i -> row = (tid>>4) + 16*i, 16-byte column chunk = tid & 15
-  const int srow = tid >> 4, scc = tid & 15;
-  int ncol = n0 + scc * 8; ncol = ncol < p.N ? ncol : p.N - 8;     // N % 8 == 0: clamp to a valid chunk
-  int kcol = k0 + scc * 8; kcol = kcol < p.K ? kcol : p.K - 8;
-  const unsigned short* yg = p.dY + ncol;
-  const unsigned short* xg = p.X + kcol;
-  const int soff = srow * ROWB + scc * 16;
-
-  u32x4 ry[4], rx[4];
-  auto gload = [&](int m0) {
+  // ---- LDS-DMA assignment: wave w, piece i (0..3) fills rows 4*(4w+i) .. +3 of each operand tile.
+  // lane -> (row in piece = lane>>4, physical 16-B slot = lane&15); the slot's 32-B segment is (slot>>1)
+  // and holds logical segment (slot>>1) ^ (row&7).
+  const int prow = lane >> 4, pslot = lane & 15;
+  const int row0 = 16 * wid + prow;                               // piece i adds 4*i rows
+  int ncol[4], kcol[4];                                           // swizzled source columns of this lane's chunks
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + srow + 16 * i;
-      const bool ok = m < m_end;
-      const long mm = ok ? m : m_beg;
-      const u32x4 vy = *reinterpret_cast<const u32x4*>(yg + mm * p.lddy);
-      const u32x4 vx = *reinterpret_cast<const u32x4*>(xg + mm * p.ldx);
-      const u32x4 z = {0u, 0u, 0u, 0u};
-      ry[i] = ok ? vy : z;
-      rx[i] = ok ? vx : z;
-    }
-  };
-  auto lstore = [&](int buf) {
-    char* base = smem + buf * STAGE_BYTES + soff;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<u32x4*>(base + i * 16 * ROWB) = ry[i];
-      *reinterpret_cast<u32x4*>(base + TILE_BYTES + i * 16 * ROWB) = rx[i];
-    }
-  };
+  for (int i = 0; i < 4; ++i) {
+    const int row = row0 + 4 * i;
+    const int lseg = (pslot >> 1) ^ (row & 7);
+    const int col = lseg * 16 + (pslot & 1) * 8;                   // logical column (elements) of this 16-B chunk
+    int nc = n0 + col; nc = nc < p.N ? nc : p.N - 8;               // N, K % 8 == 0: clamp to a valid chunk
+    int kc = k0 + col; kc = kc < p.K ? kc : p.K - 8;
+    ncol[i] = nc;
+    kcol[i] = kc;
+  }
 
   f32x4 acc[4][4], accb[4];
 #pragma unroll
@@ -103,40 +102,55 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad_kernel(const WP p) {
   // transposed-read lane addressing: group g = lane>>4, in-group i = lane&15, q = i>>2, p = i&3
   const int g = lane >> 4, li = lane & 15;
   const int trow = 4 * g + (li >> 2);
-  const int tcolb = 8 * (li & 3);                                // 4 bf16 = 8 bytes per p
-  const int a_colb = (wn * 64) * 2 + tcolb;
-  const int b_colb = (wk * 64) * 2 + tcolb;
+  const int pbyte = 8 * (li & 3);
+  char* ytile = smem;
+  char* xtile = smem + TILE_BYTES;
 
   const int nsteps = (m_end - m_beg + BMS - 1) / BMS;
-  if (nsteps > 0) {
-    gload(m_beg);
-    lstore(0);
-  }
-  __syncthreads();
   for (int st = 0; st < nsteps; ++st) {
-    const bool more = (st + 1) < nsteps;
-    if (more) gload(m_beg + (st + 1) * BMS);
-    const char* ytile = smem + (st & 1) * STAGE_BYTES;
-    const char* xtile = ytile + TILE_BYTES;
+    const int ms0 = m_beg + st * BMS;
+    const unsigned short* ybase = p.dY + (long)ms0 * p.lddy;      // wave-uniform (SGPR) base of this step
+    const unsigned short* xbase = p.X + (long)ms0 * p.ldx;
+    const int ldy = (int)p.lddy, ldxx = (int)p.ldx;
+    if (ms0 + BMS <= m_end) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        char* dst = smem + (4 * wid + i) * 1024;
+        glds16(ybase + ((row0 + 4 * i) * ldy + ncol[i]), dst);       // SGPR base + 32-bit lane offset
+        glds16(xbase + ((row0 + 4 * i) * ldxx + kcol[i]), dst + TILE_BYTES);
+      }
+    } else {
+      // ragged last step of the last split: rows past M must contribute zeros -> register staging + select
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool ok = ms0 + row0 + 4 * i < m_end;
+        const int rr = ok ? row0 + 4 * i : 0;                        // row ms0 itself is always valid
+        u32x4 vy = *reinterpret_cast<const u32x4*>(ybase + (rr * ldy + ncol[i]));
+        u32x4 vx = *reinterpret_cast<const u32x4*>(xbase + (rr * ldxx + kcol[i]));
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        char* dst = smem + (4 * wid + i) * 1024 + lane * 16;
+        *reinterpret_cast<u32x4*>(dst) = ok ? vy : z;
+        *reinterpret_cast<u32x4*>(dst + TILE_BYTES) = ok ? vx : z;
+      }
+    }
+    __syncthreads();
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms) {
-      bf16x8 af[4], bf[4];
+      bf16x8 af[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        af[t] = tr_frag(ytile, ms * 32 + trow, a_colb + t * 32);
-        bf[t] = tr_frag(xtile, ms * 32 + trow, b_colb + t * 32);
+      for (int t = 0; t < 4; ++t) af[t] = tr_frag(ytile, ms * 32 + trow, wn * 4 + t, pbyte);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16x8 bfj = tr_frag(xtile, ms * 32 + trow, wk * 4 + j, pbyte);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfj, acc[i][j], 0, 0, 0);
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
       if (do_bias) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
       }
     }
-    if (more) lstore((st + 1) & 1);
     __syncthreads();
   }
 
@@ -190,8 +204,8 @@ Plan make_plan(int M, int N, int K) {
   Plan pl;
   pl.ntn = (N + BN - 1) / BN; pl.ntk = (K + BKO - 1) / BKO;
   const int ntiles = pl.ntn * pl.ntk;
-  int splits = (512 + ntiles - 1) / ntiles;
-  const int max_splits = (M + 4 * BMS - 1) / (4 * BMS);      // at least 256 rows per split
+  int splits = (1024 + ntiles - 1) / ntiles;                 // ~4 workgroups per CU resident
+  const int max_splits = (M + 8 * BMS - 1) / (8 * BMS);      // at least 512 rows per split
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   int mps = (M + splits - 1) / splits;
@@ -225,12 +239,6 @@ extern "C" int clipk_gemm_wgrad(const void* dY, int64_t lddy, const void* X, int
   p.bslab = dbias ? (float*)workspace + (size_t)pl.splits * N * K : nullptr;
   p.M = M; p.N = N; p.K = K;
   p.ntn = pl.ntn; p.ntk = pl.ntk; p.splits = pl.splits; p.m_per_split = pl.mps;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              LDS_BYTES);
-    attr_set = true;
-  }
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(wgrad_kernel, dim3(pl.ntn * pl.ntk * pl.splits), dim3(NTHREADS), LDS_BYTES, st, p);
   int rc = clipk_check_launch();

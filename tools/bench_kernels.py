@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Per-kernel microbenchmarks at the BASELINE-config-2 shapes (run on the GPU box).
+
+    python tools/bench_kernels.py gemm        # gemm_nt v1 vs v2, interleaved rounds in one process
+    python tools/bench_kernels.py wgrad | attn | ln | all
+
+Random data (cdna_hip_programming.md §5.4 rule 25), HIP events on the launch stream, median of rounds.
+"""
+from __future__ import annotations
+
+import os
+import statistics
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from clip_dplm_amd import ops  # noqa: E402
+
+DEV = torch.device("cuda:0")
+T = 512 * 256            # tokens per step at B = 512, L = 256
+
+
+def timeit(fn, iters=5, rounds=5):
+    fn()
+    torch.cuda.synchronize()
+    res = []
+    for _ in range(rounds):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        res.append(s.elapsed_time(e) / iters)
+    return statistics.median(res), min(res)
+
+
+def rnd(shape, dtype=torch.bfloat16, scale=1.0):
+    return (torch.randn(shape, device=DEV) * scale).to(dtype)
+
+
+GEMM_SHAPES = [  # (name, M, N, K, epilogue)
+    ("esm qkv", T, 1440, 480, "bias"), ("esm out", T, 480, 480, "res32"), ("esm fc1", T, 1920, 480, "gelu+pre"),
+    ("esm fc2", T, 480, 1920, "res32"), ("rna qkv", T, 2304, 768, "bias"), ("rna out", T, 768, 768, "res32"),
+    ("rna fc1", T, 2048, 768, "gelu+pre"), ("rna fc2", T, 768, 2048, "res32"),
+    ("esm d_fc2", T, 1920, 480, "dact"), ("rna d_qkv", T, 768, 2304, "res32"),
+]
+
+
+def bench_gemm():
+    print(f"{'shape':12s} {'M':>7s} {'N':>5s} {'K':>5s} {'epi':9s} | v1 us    TF/s | v2 us    TF/s | v2/v1")
+    tot = {"v1": 0.0, "v2": 0.0}
+    for name, M, N, K, epi in GEMM_SHAPES:
+        a, b = rnd((M, K)), rnd((N, K), scale=0.05)
+        bias = torch.randn(N, device=DEV)
+        kw = {"bias": bias}
+        if epi == "res32":
+            kw.update(residual=torch.randn(M, N, device=DEV), out_dtype=torch.float32)
+        elif epi == "gelu+pre":
+            kw.update(act="gelu", out_preact=True)
+        elif epi == "dact":
+            kw = {"dact_aux": rnd((M, N)), "dact": "gelu"}
+        out = {}
+        for ver in ("v1", "v2"):
+            if ver == "v1":
+                os.environ["CLIPK_GEMM_V1"] = "1"
+            else:
+                os.environ.pop("CLIPK_GEMM_V1", None)
+            med, mn = timeit(lambda: ops.gemm_nt(a, b, **kw))
+            out[ver] = med
+            tot[ver] += med
+        fl = 2.0 * M * N * K
+        print(f"{name:12s} {M:7d} {N:5d} {K:5d} {epi:9s} | {out['v1'] * 1e3:7.1f} {fl / out['v1'] / 1e9:6.0f} | "
+              f"{out['v2'] * 1e3:7.1f} {fl / out['v2'] / 1e9:6.0f} | {out['v1'] / out['v2']:.2f}x")
+        del a, b, kw
+    print(f"sum: v1 {tot['v1']:.2f} ms, v2 {tot['v2']:.2f} ms")
+
+
+def bench_wgrad():
+    print(f"{'shape':12s} {'M':>7s} {'N':>5s} {'K':>5s} | us     TF/s")
+    for name, M, N, K, _ in GEMM_SHAPES[:8]:
+        dy, x = rnd((M, N), scale=0.1), rnd((M, K))
+        med, mn = timeit(lambda: ops.gemm_wgrad(dy, x, want_bias=True))
+        print(f"{name:12s} {M:7d} {N:5d} {K:5d} | {med * 1e3:7.1f} {2.0 * M * N * K / med / 1e9:6.0f}")
+
+
+def bench_attn():
+    for name, B, L, H, D, rope in (("esm 35M", 512, 256, 20, 24, True), ("rna", 512, 256, 8, 96, False)):
+        qkv = rnd((B * L, 3 * H * D))
+        r = None
+        if rope:
+            inv = 1.0 / (10000 ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
+            fr = torch.arange(L, dtype=torch.float32)[:, None] * inv[None]
+            r = (fr.cos().contiguous().to(DEV), fr.sin().contiguous().to(DEV))
+        out, lse = ops.attn_fwd(qkv, B, L, H, D, rope=r, q_scale=D ** -0.5)
+        dout = rnd((B * L, H * D))
+        f, _ = timeit(lambda: ops.attn_fwd(qkv, B, L, H, D, rope=r, q_scale=D ** -0.5))
+        bw, _ = timeit(lambda: ops.attn_bwd(qkv, out, dout, lse, B, L, H, D, rope=r, q_scale=D ** -0.5))
+        fl = 4.0 * B * H * L * L * D
+        print(f"attn {name:8s} fwd {f * 1e3:8.1f} us {fl / f / 1e9:6.0f} TF/s | bwd {bw * 1e3:8.1f} us "
+              f"{2.5 * fl / bw / 1e9:6.0f} TF/s (algorithmic 10*B*H*L^2*D)")
+
+
+def bench_ln():
+    for cols in (480, 768):
+        x = torch.randn(T, cols, device=DEV)
+        g, b = torch.ones(cols, device=DEV), torch.zeros(cols, device=DEV)
+        f, _ = timeit(lambda: ops.layernorm_fwd(x, g, b, 1e-5, want_f32=False, want_bf16=True))
+        _, _, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-5, want_f32=False, want_bf16=True)
+        dy = rnd((T, cols))
+        bw, _ = timeit(lambda: ops.layernorm_bwd(dy, x, g, None, mean, rstd, dx_add=x, want_f32=True, want_bf16=True))
+        fb = T * cols * (4 + 2)
+        bb = T * cols * (2 + 4 + 4 + 4 + 2)
+        print(f"layernorm d={cols}: fwd {f * 1e3:7.1f} us {fb / f / 1e9:6.2f} TB/s | bwd {bw * 1e3:7.1f} us {bb / bw / 1e9:6.2f} TB/s")
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("gemm", "all"):
+        bench_gemm()
+    if what in ("wgrad", "all"):
+        bench_wgrad()
+    if what in ("attn", "all"):
+        bench_attn()
+    if what in ("ln", "all"):
+        bench_ln()
