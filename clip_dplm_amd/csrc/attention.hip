@@ -5,19 +5,22 @@
 // (transformers modeling_esm.py:362-384: q *= hd^-1/2, rotate-half RoPE on q,k :48-52,74-79, softmax :306-314).
 //
 // gfx950 design:
-//   * the L x L score matrix never leaves registers; 16x16x32 bf16 MFMA everywhere, f32 softmax;
-//   * "swapped" products: S^T = K·Q^T puts keys on accumulator rows and queries on lanes, so the
-//     online-softmax row statistics are in-register reductions + two lane exchanges, and the P^T
-//     accumulator registers ARE the B operand of O^T += V^T·P^T (no LDS round trip for P);
-//   * V^T / K^T / Q^T / dO^T operands come from row-major LDS tiles through ds_read_b64_tr_b16
-//     (CDNA4 transposed read); tiles use a (2*DP+32)-byte row stride that tools/lds_conflicts.py shows
-//     conflict-free for both the b128 row reads and the transposed reads;
-//   * head dims that are not a multiple of 32 (ESM-2-35M: 24) are zero-padded to DP in LDS only;
-//   * RoPE is applied in LDS on the staged q / k rows (f32 math), its transpose on dq / dk before the
-//     store, so q/k are read once from HBM and no rotated copy is ever written;
-//   * backward = a dQ kernel (one workgroup per 128 queries, sweeping keys) and a dK/dV kernel (one
-//     workgroup per 128 or 64 keys, sweeping queries): 7 MFMA products instead of 5, but no float atomics
-//     and bitwise-reproducible gradients.
+//   * the L x L score matrix never leaves registers; 16x16x32 bf16 MFMA everywhere, f32 softmax (exp2, scale folded);
+//   * "swapped" products: S^T = K·Q^T puts keys on accumulator rows and queries on lanes, so the online-softmax
+//     row statistics are in-register reductions + two lane exchanges, and the P^T accumulator registers ARE the B
+//     operand of O^T += V^T·P^T (no LDS round trip for P);
+//   * V^T / K^T / Q^T / dO^T operands come from row-major LDS tiles through ds_read_b64_tr_b16 (CDNA4 transposed
+//     read); tiles use a (2*DP+32)-byte row stride that tools/lds_conflicts.py shows conflict-free for both the b128
+//     row reads and the transposed reads; head dims that are not a multiple of 32 (ESM-2-35M: 24) are zero-padded
+//     to DP in LDS only;
+//   * "row-owner" staging: one thread owns one token row of one operand (its D bf16 = D/8 16-byte chunks) in
+//     registers, applies RoPE there (f32 math, static indices — the head dim is a template parameter on the RoPE
+//     path) and writes the finished row to LDS: q/k are read once from HBM, no rotated copy is ever written and
+//     no in-LDS rotation pass or extra barrier exists.  The same registers prefetch the next key (or query) block
+//     while the MFMAs of the current one run;
+//   * backward = a dQ kernel (one workgroup per 128 queries, sweeping keys; it also produces delta = rowsum(dO*O)
+//     from the rows it already holds) and a dK/dV kernel (one workgroup per 128 or 64 keys, sweeping queries):
+//     7 MFMA products instead of 5, but no float atomics and bitwise-reproducible gradients.
 #include "common.h"
 #include <math.h>
 
@@ -28,7 +31,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 struct AP {
   const unsigned short* qkv; const uint8_t* key_mask; const float* cosT; const float* sinT;
   unsigned short* out; float* lse;
-  const unsigned short* dout; const float* delta_in; float* delta; unsigned short* dqkv;
+  const unsigned short* dout; float* delta; unsigned short* dqkv;
   int B, L, H, D;
   float scale;
 };
@@ -39,32 +42,42 @@ template <int DP> struct Geo {
   static constexpr int RS = DP * 2 + 32;     // LDS row stride in bytes
   static constexpr int KS = DP / 32;         // contraction steps over the head dim
   static constexpr int DT = DP / 16;         // 16-wide d tiles
+  static constexpr int NCH = DP / 8;         // 16-byte chunks per (padded) row
+  static constexpr int KVB = (DP <= 96) ? 128 : 64;   // keys (or queries) per staged block
 };
 
-// stage `nrows` token rows (16-byte chunks of the D real columns) into an LDS tile
-__device__ __forceinline__ void stage_rows(char* tile, int RS, const unsigned short* base, long tokstride,
-                                           int pos0, int nrows, int L, int D, int tid) {
-  const int cpr = D >> 3;
-  for (int c = tid; c < nrows * cpr; c += 256) {
-    const int r = c / cpr, ch = c - r * cpr;
-    int pos = pos0 + r; pos = pos < L ? pos : L - 1;
-    *reinterpret_cast<u32x4*>(tile + r * RS + ch * 16) =
-        *reinterpret_cast<const u32x4*>(base + (long)pos * tokstride + ch * 8);
+template <int NCH> struct RowRegs { u32x4 c[NCH]; };
+
+template <int NCH>
+__device__ __forceinline__ void load_row(RowRegs<NCH>& r, const unsigned short* rowptr, int cpr) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    r.c[i] = u32x4{0u, 0u, 0u, 0u};
+    if (i < cpr) r.c[i] = *reinterpret_cast<const u32x4*>(rowptr + 8 * i);
   }
 }
+// writes all NCH chunks: the pad columns D..DP-1 become zero in LDS
+template <int NCH>
+__device__ __forceinline__ void store_row(const RowRegs<NCH>& r, char* ldsrow) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) *reinterpret_cast<u32x4*>(ldsrow + 16 * i) = r.c[i];
+}
 
-// rotate-half RoPE in place on an LDS tile of bf16 rows; dir = +1 forward, -1 transpose (for gradients)
-__device__ __forceinline__ void rope_rows(char* tile, int RS, int pos0, int nrows, int L, int D,
-                                          const float* cosT, const float* sinT, float dir, int tid) {
-  const int half = D >> 1;
-  for (int i = tid; i < nrows * half; i += 256) {
-    const int r = i / half, j = i - r * half;
-    int pos = pos0 + r; pos = pos < L ? pos : L - 1;
-    const float c = cosT[(long)pos * half + j], s = sinT[(long)pos * half + j] * dir;
-    unsigned short* row = reinterpret_cast<unsigned short*>(tile + r * RS);
-    const float x1 = bf16_to_f32(row[j]), x2 = bf16_to_f32(row[j + half]);
-    row[j] = f32_to_bf16(x1 * c - x2 * s);
-    row[j + half] = f32_to_bf16(x2 * c + x1 * s);
+// rotate-half RoPE on a register-resident row; D is compile time so every index is static.  dir=+1: forward.
+template <int D, int NCH>
+__device__ __forceinline__ void rope_regs(RowRegs<NCH>& r, const float* cosr, const float* sinr) {
+  constexpr int H = D / 2;
+#pragma unroll
+  for (int j = 0; j < H; j += 2) {
+    const int ja = j, jb = j + H;                         // element indices of the two words (H is even)
+    unsigned int wa = r.c[ja >> 3][(ja & 7) >> 1], wb = r.c[jb >> 3][(jb & 7) >> 1];
+    const float c0 = cosr[j], c1 = cosr[j + 1], s0 = sinr[j], s1 = sinr[j + 1];
+    const float x1a = bf16_to_f32(wa & 0xffffu), x1b = bf16_to_f32(wa >> 16);
+    const float x2a = bf16_to_f32(wb & 0xffffu), x2b = bf16_to_f32(wb >> 16);
+    wa = pack_bf16x2(x1a * c0 - x2a * s0, x1b * c1 - x2b * s1);
+    wb = pack_bf16x2(x2a * c0 + x1a * s0, x2b * c1 + x1b * s1);
+    r.c[ja >> 3][(ja & 7) >> 1] = wa;
+    r.c[jb >> 3][(jb & 7) >> 1] = wb;
   }
 }
 
@@ -96,20 +109,58 @@ __device__ __forceinline__ float group_sum(float v) {
   return v + __shfl_xor(v, 32, 64);
 }
 
+// Row-owner staging of a K/V (or Q/dO) block pair.  With BLK rows per operand: threads [0,BLK) own operand-A rows,
+// threads [BLK,2*BLK) own operand-B rows (BLK = 128 uses all 256 threads, BLK = 64 the first 128).
+template <int DP, int DR, int BLK>
+struct PairStager {
+  static constexpr int NCH = Geo<DP>::NCH;
+  RowRegs<NCH> r;
+  int row, pos;
+  bool is_a, active;
+
+  __device__ __forceinline__ void init(int tid) {
+    active = tid < 2 * BLK;
+    is_a = tid < BLK;
+    row = tid & (BLK - 1);
+  }
+  // a_base / b_base: row pointers base (token 0 of this batch element, head offset applied); strides in elements
+  __device__ __forceinline__ void load(const unsigned short* a_base, long a_stride, const unsigned short* b_base,
+                                       long b_stride, int pos0, int L, int cpr) {
+    if (!active) return;
+    pos = pos0 + row;
+    const int pc = pos < L ? pos : L - 1;
+    const unsigned short* rp = is_a ? a_base + (long)pc * a_stride : b_base + (long)pc * b_stride;
+    load_row<NCH>(r, rp, cpr);
+  }
+  // rope_a: rotate operand-A rows (K or Q) before they reach LDS
+  __device__ __forceinline__ void store(char* a_tile, char* b_tile, int RS, const AP& p, int L, bool rope_a) {
+    if (!active) return;
+    if (DR > 0) {
+      if (rope_a && is_a) {
+        const int pc = pos < L ? pos : L - 1;
+        rope_regs<(DR > 0 ? DR : 2), NCH>(r, p.cosT + (long)pc * (DR / 2), p.sinT + (long)pc * (DR / 2));
+      }
+    }
+    store_row<NCH>(r, (is_a ? a_tile : b_tile) + row * RS);
+  }
+};
+
 // =================================================================================================
-// forward: one workgroup = 128 queries of one (batch, head); 4 waves x 32 queries; 64-key tiles
+// forward: one workgroup = 128 queries of one (batch, head); 4 waves x 32 queries; KVB-key staged blocks
 // =================================================================================================
-template <int DP, bool ROPE>
+template <int DP, int DR>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AP p) {
-  constexpr int RS = Geo<DP>::RS, KS = Geo<DP>::KS, DT = Geo<DP>::DT;
+  constexpr int RS = Geo<DP>::RS, KS = Geo<DP>::KS, DT = Geo<DP>::DT, NCH = Geo<DP>::NCH, KVB = Geo<DP>::KVB;
+  constexpr int NSUB = KVB / 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ktile = smem;
-  char* vtile = smem + 64 * RS;
-  unsigned char* mask_l = reinterpret_cast<unsigned char*>(smem + 128 * RS);
+  char* vtile = smem + KVB * RS;
+  unsigned char* mask_l = reinterpret_cast<unsigned char*>(smem + 2 * KVB * RS);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
   const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int D = p.D, L = p.L, H = p.H;
+  const int cpr = D >> 3;
   const long tokstride = 3L * H * D;
   const unsigned short* qbase = p.qkv + (long)b * L * tokstride + (long)h * D;
   const unsigned short* kbase = qbase + (long)H * D;
@@ -118,16 +169,32 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AP p) {
   const int dtv = (D + 15) >> 4;
   const float c2 = p.scale * LOG2E;
 
-  for (int i = tid; i < (128 * RS) / 16; i += 256) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+  // ---- issue every first-use load up front: this thread's Q row and its row of K/V block 0
+  RowRegs<NCH> rq;
+  if (tid < 128) {
+    int pq = q0 + tid; pq = pq < L ? pq : L - 1;
+    load_row<NCH>(rq, qbase + (long)pq * tokstride, cpr);
+  }
+  PairStager<DP, DR, KVB> kv;
+  kv.init(tid);
+  kv.load(kbase, tokstride, vbase, tokstride, 0, L, cpr);
+  // Q rows: RoPE in registers, then to LDS (the 128 Q rows borrow the [K|V] region before K/V land there)
+  if (tid < 128) {
+    if (DR > 0) {
+      int pq = q0 + tid; pq = pq < L ? pq : L - 1;
+      rope_regs<(DR > 0 ? DR : 2), NCH>(rq, p.cosT + (long)pq * (DR / 2), p.sinT + (long)pq * (DR / 2));
+    }
+    store_row<NCH>(rq, smem + tid * RS);
+  }
   __syncthreads();
-  stage_rows(smem, RS, qbase, tokstride, q0, 128, L, D, tid);
-  __syncthreads();
-  if (ROPE) { rope_rows(smem, RS, q0, 128, L, D, p.cosT, p.sinT, 1.f, tid); __syncthreads(); }
   bf16x8 qf[2][KS];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[qt][ks] = row_frag(smem, RS, wid * 32 + qt * 16 + li, ks, lane);
+  __syncthreads();
+  kv.store(ktile, vtile, RS, p, L, true);
+  if (tid < KVB) mask_l[tid] = (tid < L && (!p.key_mask || p.key_mask[(long)b * L + tid])) ? 1 : 0;
   __syncthreads();
 
   f32x4 o[DT][2];
@@ -136,73 +203,80 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AP p) {
   float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
   const int trow = 4 * g + (li >> 2), tcolb = 8 * (li & 3);
 
-  const int nkb = (L + 63) >> 6;
+  const int nkb = (L + KVB - 1) / KVB;
   for (int kb = 0; kb < nkb; ++kb) {
-    stage_rows(ktile, RS, kbase, tokstride, kb * 64, 64, L, D, tid);
-    stage_rows(vtile, RS, vbase, tokstride, kb * 64, 64, L, D, tid);
-    if (tid < 64) {
-      const int pos = kb * 64 + tid;
-      mask_l[tid] = (pos < L && (!p.key_mask || p.key_mask[(long)b * L + pos])) ? 1 : 0;
-    }
-    __syncthreads();
-    if (ROPE) { rope_rows(ktile, RS, kb * 64, 64, L, D, p.cosT, p.sinT, 1.f, tid); __syncthreads(); }
-
-    f32x4 s[4][2];
+    const bool more = (kb + 1) < nkb;
+    if (more) kv.load(kbase, tokstride, vbase, tokstride, (kb + 1) * KVB, L, cpr);   // in flight during the MFMAs
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) { s[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[kt][1] = s[kt][0]; }
+    for (int sub = 0; sub < NSUB; ++sub) {
+      if (kb * KVB + sub * 64 >= L) break;                       // wave-uniform: nothing valid in this sub-block
+      const char* kt_ = ktile + sub * 64 * RS;
+      const char* vt_ = vtile + sub * 64 * RS;
+      f32x4 s[4][2];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+      for (int kt = 0; kt < 4; ++kt) { s[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[kt][1] = s[kt][0]; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          const bf16x8 kf = row_frag(kt_, RS, kt * 16 + li, ks, lane);
+          s[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[kt][0], 0, 0, 0);
+          s[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[kt][1], 0, 0, 0);
+        }
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
-        const bf16x8 kf = row_frag(ktile, RS, kt * 16 + li, ks, lane);
-        s[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[kt][0], 0, 0, 0);
-        s[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[kt][1], 0, 0, 0);
+        const unsigned int mk = *reinterpret_cast<const unsigned int*>(mask_l + sub * 64 + kt * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (!((mk >> (8 * r)) & 0xffu)) { s[kt][0][r] = -INFINITY; s[kt][1][r] = -INFINITY; }
+      }
+      bf16x8 pb[2][2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
+        mx = group_max(mx);
+        const float m_new = fmaxf(m_run[qt], mx);
+        const bool dead = (m_new == -INFINITY);
+        const float alpha = dead ? 1.f : exp2f((m_run[qt] - m_new) * c2);
+        float ls = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = dead ? 0.f : exp2f((s[kt][qt][r] - m_new) * c2);
+            s[kt][qt][r] = pv;
+            ls += pv;
+          }
+        l_run[qt] = l_run[qt] * alpha + ls;
+        m_run[qt] = m_new;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt][qt] *= alpha;
+        pb[qt][0] = pack_acc_pair(s[0][qt], s[1][qt]);
+        pb[qt][1] = pack_acc_pair(s[2][qt], s[3][qt]);
       }
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      const unsigned int mk = *reinterpret_cast<const unsigned int*>(mask_l + kt * 16 + 4 * g);
+      for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (!((mk >> (8 * r)) & 0xffu)) { s[kt][0][r] = -INFINITY; s[kt][1][r] = -INFINITY; }
+        for (int dt = 0; dt < DT; ++dt)
+          if (dt < dtv) {
+            const bf16x8 vf = tr_frag(vt_, RS, 32 * s2 + trow, dt * 32 + tcolb);
+            o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[0][s2], o[dt][0], 0, 0, 0);
+            o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[1][s2], o[dt][1], 0, 0, 0);
+          }
     }
-    bf16x8 pb[2][2];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      float mx = -INFINITY;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
-      mx = group_max(mx);
-      const float m_new = fmaxf(m_run[qt], mx);
-      const bool dead = (m_new == -INFINITY);
-      const float alpha = dead ? 1.f : exp2f((m_run[qt] - m_new) * c2);
-      float ls = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = dead ? 0.f : exp2f((s[kt][qt][r] - m_new) * c2);
-          s[kt][qt][r] = pv;
-          ls += pv;
-        }
-      l_run[qt] = l_run[qt] * alpha + ls;
-      m_run[qt] = m_new;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) o[dt][qt] *= alpha;
-      pb[qt][0] = pack_acc_pair(s[0][qt], s[1][qt]);
-      pb[qt][1] = pack_acc_pair(s[2][qt], s[3][qt]);
+    if (more) {
+      __syncthreads();                                           // everyone done reading this block
+      kv.store(ktile, vtile, RS, p, L, true);
+      if (tid < KVB) {
+        const int pos = (kb + 1) * KVB + tid;
+        mask_l[tid] = (pos < L && (!p.key_mask || p.key_mask[(long)b * L + pos])) ? 1 : 0;
+      }
+      __syncthreads();
     }
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-        if (dt < dtv) {
-          const bf16x8 vf = tr_frag(vtile, RS, 32 * s2 + trow, dt * 32 + tcolb);
-          o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[0][s2], o[dt][0], 0, 0, 0);
-          o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[1][s2], o[dt][1], 0, 0, 0);
-        }
-    __syncthreads();
   }
 
 #pragma unroll
@@ -225,27 +299,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AP p) {
       }
     }
   }
-}
-
-// delta[b,h,q] = sum_d dout[q,d] * out[q,d]
-__global__ __launch_bounds__(256) void attn_delta_kernel(const AP p) {
-  const long total = (long)p.B * p.L * p.H;
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const long tok = i / p.H; const int h = (int)(i - tok * p.H);
-  const int b = (int)(tok / p.L), q = (int)(tok - (long)b * p.L);
-  const unsigned short* o = p.out + tok * ((long)p.H * p.D) + (long)h * p.D;
-  const unsigned short* d_ = p.dout + tok * ((long)p.H * p.D) + (long)h * p.D;
-  float acc = 0.f;
-  for (int c = 0; c < p.D; c += 8) {
-    const u32x4 a = *reinterpret_cast<const u32x4*>(o + c), bb = *reinterpret_cast<const u32x4*>(d_ + c);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      acc += bf16_to_f32(a[e] & 0xffffu) * bf16_to_f32(bb[e] & 0xffffu);
-      acc += bf16_to_f32(a[e] >> 16) * bf16_to_f32(bb[e] >> 16);
-    }
-  }
-  p.delta[((long)b * p.H + h) * p.L + q] = acc;
 }
 
 // write an f32 [rows][DP+4] LDS image (gradient w.r.t. rotated q/k) as bf16 rows of dqkv, applying the
@@ -282,113 +335,145 @@ __device__ __forceinline__ void store_grad_rows(const float* img, int ILD, unsig
 }
 
 // =================================================================================================
-// backward dQ: one workgroup = 128 queries, sweeps 64-key tiles
+// backward dQ (+ delta): one workgroup = 128 queries, sweeps KVB-key blocks
 // =================================================================================================
-template <int DP, bool ROPE>
+template <int DP, int DR>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AP p) {
-  constexpr int RS = Geo<DP>::RS, KS = Geo<DP>::KS, DT = Geo<DP>::DT, ILD = DP + 4;
+  constexpr int RS = Geo<DP>::RS, KS = Geo<DP>::KS, DT = Geo<DP>::DT, NCH = Geo<DP>::NCH, KVB = Geo<DP>::KVB;
+  constexpr int NSUB = KVB / 64, ILD = DP + 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ktile = smem;
-  char* vtile = smem + 64 * RS;
-  unsigned char* mask_l = reinterpret_cast<unsigned char*>(smem + 128 * RS);
+  char* vtile = smem + KVB * RS;
+  // rows [0,128) and [128,256) of smem stage Q and dO in the prologue (the region holds >= 256 rows)
+  float* delta_l = reinterpret_cast<float*>(smem + 256 * RS);            // [128]
+  unsigned char* mask_l = reinterpret_cast<unsigned char*>(delta_l + 128);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
   const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int D = p.D, L = p.L, H = p.H;
+  const int cpr = D >> 3;
   const long tokstride = 3L * H * D, ostride = (long)H * D;
   const unsigned short* qbase = p.qkv + (long)b * L * tokstride + (long)h * D;
   const unsigned short* kbase = qbase + (long)H * D;
   const unsigned short* vbase = qbase + 2L * H * D;
   const unsigned short* dobase = p.dout + (long)b * L * ostride + (long)h * D;
+  const unsigned short* obase = p.out + (long)b * L * ostride + (long)h * D;
   const int q0 = qb * 128;
   const int dtv = (D + 15) >> 4;
   const float c2 = p.scale * LOG2E;
 
-  for (int i = tid; i < (128 * RS) / 16; i += 256) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+  // ---- prologue: Q rows (threads 0..127, rotated) and dO rows (threads 128..255, which also form delta)
+  {
+    PairStager<DP, DR, 128> qd;
+    qd.init(tid);
+    qd.load(qbase, tokstride, dobase, ostride, q0, L, cpr);
+    if (!qd.is_a) {
+      RowRegs<NCH> ro;
+      const int pc = qd.pos < L ? qd.pos : L - 1;
+      load_row<NCH>(ro, obase + (long)pc * ostride, cpr);
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc += bf16_to_f32(ro.c[i][e] & 0xffffu) * bf16_to_f32(qd.r.c[i][e] & 0xffffu);
+          acc += bf16_to_f32(ro.c[i][e] >> 16) * bf16_to_f32(qd.r.c[i][e] >> 16);
+        }
+      delta_l[qd.row] = acc;
+      if (qd.pos < L) p.delta[((long)b * H + h) * L + qd.pos] = acc;      // consumed by the dK/dV kernel
+    }
+    qd.store(smem, smem + 128 * RS, RS, p, L, true);
+  }
+  PairStager<DP, DR, KVB> kv;
+  kv.init(tid);
+  kv.load(kbase, tokstride, vbase, tokstride, 0, L, cpr);
   __syncthreads();
-  stage_rows(smem, RS, qbase, tokstride, q0, 128, L, D, tid);
-  __syncthreads();
-  if (ROPE) { rope_rows(smem, RS, q0, 128, L, D, p.cosT, p.sinT, 1.f, tid); __syncthreads(); }
   bf16x8 qf[2][KS], dof[2][KS];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[qt][ks] = row_frag(smem, RS, wid * 32 + qt * 16 + li, ks, lane);
-  __syncthreads();
-  stage_rows(smem, RS, dobase, ostride, q0, 128, L, D, tid);
-  __syncthreads();
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) dof[qt][ks] = row_frag(smem, RS, wid * 32 + qt * 16 + li, ks, lane);
-  __syncthreads();
-
+    for (int ks = 0; ks < KS; ++ks) {
+      qf[qt][ks] = row_frag(smem, RS, wid * 32 + qt * 16 + li, ks, lane);
+      dof[qt][ks] = row_frag(smem + 128 * RS, RS, wid * 32 + qt * 16 + li, ks, lane);
+    }
   float lse2[2], dl[2];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     int q = q0 + wid * 32 + qt * 16 + li; q = q < L ? q : L - 1;
     lse2[qt] = p.lse[((long)b * H + h) * L + q] * LOG2E;
-    dl[qt] = p.delta_in[((long)b * H + h) * L + q];
+    dl[qt] = delta_l[wid * 32 + qt * 16 + li];
   }
+  __syncthreads();
+  kv.store(ktile, vtile, RS, p, L, true);
+  if (tid < KVB) mask_l[tid] = (tid < L && (!p.key_mask || p.key_mask[(long)b * L + tid])) ? 1 : 0;
+  __syncthreads();
+
   f32x4 dq[DT][2];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) { dq[dt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dq[dt][1] = dq[dt][0]; }
   const int trow = 4 * g + (li >> 2), tcolb = 8 * (li & 3);
 
-  const int nkb = (L + 63) >> 6;
+  const int nkb = (L + KVB - 1) / KVB;
   for (int kb = 0; kb < nkb; ++kb) {
-    stage_rows(ktile, RS, kbase, tokstride, kb * 64, 64, L, D, tid);
-    stage_rows(vtile, RS, vbase, tokstride, kb * 64, 64, L, D, tid);
-    if (tid < 64) {
-      const int pos = kb * 64 + tid;
-      mask_l[tid] = (pos < L && (!p.key_mask || p.key_mask[(long)b * L + pos])) ? 1 : 0;
-    }
-    __syncthreads();
-    if (ROPE) { rope_rows(ktile, RS, kb * 64, 64, L, D, p.cosT, p.sinT, 1.f, tid); __syncthreads(); }
-
-    f32x4 s[4][2], dp[4][2];
+    const bool more = (kb + 1) < nkb;
+    if (more) kv.load(kbase, tokstride, vbase, tokstride, (kb + 1) * KVB, L, cpr);
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) { s[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[kt][1] = s[kt][0]; dp[kt][0] = s[kt][0]; dp[kt][1] = s[kt][0]; }
+    for (int sub = 0; sub < NSUB; ++sub) {
+      if (kb * KVB + sub * 64 >= L) break;
+      const char* kt_ = ktile + sub * 64 * RS;
+      const char* vt_ = vtile + sub * 64 * RS;
+      f32x4 s[4][2], dp[4][2];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+      for (int kt = 0; kt < 4; ++kt) { s[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[kt][1] = s[kt][0]; dp[kt][0] = s[kt][0]; dp[kt][1] = s[kt][0]; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          const bf16x8 kf = row_frag(kt_, RS, kt * 16 + li, ks, lane);
+          const bf16x8 vf = row_frag(vt_, RS, kt * 16 + li, ks, lane);
+          s[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[kt][0], 0, 0, 0);
+          s[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[kt][1], 0, 0, 0);
+          dp[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[0][ks], dp[kt][0], 0, 0, 0);
+          dp[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[1][ks], dp[kt][1], 0, 0, 0);
+        }
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
-        const bf16x8 kf = row_frag(ktile, RS, kt * 16 + li, ks, lane);
-        const bf16x8 vf = row_frag(vtile, RS, kt * 16 + li, ks, lane);
-        s[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[kt][0], 0, 0, 0);
-        s[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[kt][1], 0, 0, 0);
-        dp[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[0][ks], dp[kt][0], 0, 0, 0);
-        dp[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[1][ks], dp[kt][1], 0, 0, 0);
-      }
+        const unsigned int mk = *reinterpret_cast<const unsigned int*>(mask_l + sub * 64 + kt * 16 + 4 * g);
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      const unsigned int mk = *reinterpret_cast<const unsigned int*>(mask_l + kt * 16 + 4 * g);
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = ((mk >> (8 * r)) & 0xffu) != 0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const bool ok = ((mk >> (8 * r)) & 0xffu) != 0;
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-          const float pv = ok ? exp2f(s[kt][qt][r] * c2 - lse2[qt]) : 0.f;
-          s[kt][qt][r] = pv * (dp[kt][qt][r] - dl[qt]);          // dS^T (w.r.t. the scaled score)
+          for (int qt = 0; qt < 2; ++qt) {
+            const float pv = ok ? exp2f(s[kt][qt][r] * c2 - lse2[qt]) : 0.f;
+            s[kt][qt][r] = pv * (dp[kt][qt][r] - dl[qt]);          // dS^T (w.r.t. the scaled score)
+          }
         }
       }
+      bf16x8 db[2][2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        db[qt][0] = pack_acc_pair(s[0][qt], s[1][qt]);
+        db[qt][1] = pack_acc_pair(s[2][qt], s[3][qt]);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+          if (dt < dtv) {
+            const bf16x8 kt_f = tr_frag(kt_, RS, 32 * s2 + trow, dt * 32 + tcolb);
+            dq[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_f, db[0][s2], dq[dt][0], 0, 0, 0);
+            dq[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_f, db[1][s2], dq[dt][1], 0, 0, 0);
+          }
     }
-    bf16x8 db[2][2];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      db[qt][0] = pack_acc_pair(s[0][qt], s[1][qt]);
-      db[qt][1] = pack_acc_pair(s[2][qt], s[3][qt]);
-    }
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-        if (dt < dtv) {
-          const bf16x8 kt_f = tr_frag(ktile, RS, 32 * s2 + trow, dt * 32 + tcolb);
-          dq[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_f, db[0][s2], dq[dt][0], 0, 0, 0);
-          dq[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_f, db[1][s2], dq[dt][1], 0, 0, 0);
-        }
     __syncthreads();
+    if (more) {
+      kv.store(ktile, vtile, RS, p, L, true);
+      if (tid < KVB) {
+        const int pos = (kb + 1) * KVB + tid;
+        mask_l[tid] = (pos < L && (!p.key_mask || p.key_mask[(long)b * L + pos])) ? 1 : 0;
+      }
+      __syncthreads();
+    }
   }
 
   // dq~ (gradient w.r.t. the rotated q) -> f32 LDS image [128][DP+4] -> RoPE^T -> bf16 rows of dqkv
@@ -401,60 +486,59 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AP p) {
       for (int r = 0; r < 4; ++r)
         img[(wid * 32 + qt * 16 + li) * ILD + dt * 16 + 4 * g + r] = dq[dt][qt][r] * p.scale;
   __syncthreads();
-  store_grad_rows<ROPE>(img, ILD, p.dqkv + (long)b * L * tokstride + (long)h * D, tokstride, q0, 128, L, D,
-                        p.cosT, p.sinT, tid);
+  store_grad_rows<(DR > 0)>(img, ILD, p.dqkv + (long)b * L * tokstride + (long)h * D, tokstride, q0, 128, L, D,
+                            p.cosT, p.sinT, tid);
 }
 
 // =================================================================================================
-// backward dK/dV: one workgroup = 4 waves x (16*KTW) keys, sweeps 64-query tiles
+// backward dK/dV: one workgroup = KVB keys (4 waves x KVB/4), sweeps KVB-query blocks
 // =================================================================================================
-template <int DP, bool ROPE, int KTW>
+template <int DP, int DR>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AP p) {
-  constexpr int RS = Geo<DP>::RS, KS = Geo<DP>::KS, DT = Geo<DP>::DT, ILD = DP + 4;
-  constexpr int KPW = 16 * KTW, KPB = 4 * KPW;            // keys per wave / per workgroup
+  constexpr int RS = Geo<DP>::RS, KS = Geo<DP>::KS, DT = Geo<DP>::DT, KVB = Geo<DP>::KVB, ILD = DP + 4;
+  constexpr int KTW = KVB / 64;                           // 16-key tiles per wave
+  constexpr int KPW = 16 * KTW, QB = KVB, NS2 = QB / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* qtile = smem;                                     // [64 q][RS]   (also the staging area for K/V blocks)
-  char* dotile = smem + 64 * RS;                          // [64 q][RS]
-  float* lse_l = reinterpret_cast<float*>(smem + 128 * RS);      // [64]
-  float* dl_l = lse_l + 64;                                      // [64]
+  char* qtile = smem;                                     // [QB q][RS]   (first holds this workgroup's K rows)
+  char* dotile = smem + QB * RS;                          // [QB q][RS]   (first holds this workgroup's V rows)
+  float* lse_l = reinterpret_cast<float*>(smem + 2 * QB * RS);   // [QB]
+  float* dl_l = lse_l + QB;                                      // [QB]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
   const int kbk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int D = p.D, L = p.L, H = p.H;
+  const int cpr = D >> 3;
   const long tokstride = 3L * H * D, ostride = (long)H * D;
   const unsigned short* qbase = p.qkv + (long)b * L * tokstride + (long)h * D;
   const unsigned short* kbase = qbase + (long)H * D;
   const unsigned short* vbase = qbase + 2L * H * D;
   const unsigned short* dobase = p.dout + (long)b * L * ostride + (long)h * D;
-  const int k0 = kbk * KPB;
+  const int k0 = kbk * KVB;
   const int dtv = (D + 15) >> 4;
   const float c2 = p.scale * LOG2E;
 
-  for (int i = tid; i < (128 * RS) / 16; i += 256) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+  // ---- this workgroup's keys: K (rotated) and V as B fragments B[k = d][col = key], kept in registers
+  PairStager<DP, DR, KVB> st;
+  st.init(tid);
+  st.load(kbase, tokstride, vbase, tokstride, k0, L, cpr);
+  st.store(qtile, dotile, RS, p, L, true);
+  st.load(qbase, tokstride, dobase, ostride, 0, L, cpr);            // first query block: in flight during the fragment reads
   __syncthreads();
-  // this workgroup's keys: K (rotated) and V as B fragments B[k = d][col = key] kept in registers
   bf16x8 kf[KTW][KS], vf[KTW][KS];
-  stage_rows(smem, RS, kbase, tokstride, k0, KPB, L, D, tid);
-  __syncthreads();
-  if (ROPE) { rope_rows(smem, RS, k0, KPB, L, D, p.cosT, p.sinT, 1.f, tid); __syncthreads(); }
 #pragma unroll
   for (int kt = 0; kt < KTW; ++kt)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) kf[kt][ks] = row_frag(smem, RS, wid * KPW + kt * 16 + li, ks, lane);
-  __syncthreads();
-  stage_rows(smem, RS, vbase, tokstride, k0, KPB, L, D, tid);
-  __syncthreads();
-#pragma unroll
-  for (int kt = 0; kt < KTW; ++kt)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) vf[kt][ks] = row_frag(smem, RS, wid * KPW + kt * 16 + li, ks, lane);
-  __syncthreads();
+    for (int ks = 0; ks < KS; ++ks) {
+      kf[kt][ks] = row_frag(qtile, RS, wid * KPW + kt * 16 + li, ks, lane);
+      vf[kt][ks] = row_frag(dotile, RS, wid * KPW + kt * 16 + li, ks, lane);
+    }
   bool kvalid[KTW];
 #pragma unroll
   for (int kt = 0; kt < KTW; ++kt) {
     const int key = k0 + wid * KPW + kt * 16 + li;
     kvalid[kt] = key < L && (!p.key_mask || p.key_mask[(long)b * L + key]);
   }
+  __syncthreads();
 
   f32x4 dk[DT][KTW], dv[DT][KTW];
 #pragma unroll
@@ -463,22 +547,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AP p) {
     for (int kt = 0; kt < KTW; ++kt) { dk[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt][kt] = dk[dt][kt]; }
   const int trow = 4 * g + (li >> 2), tcolb = 8 * (li & 3);
 
-  const int nqb = (L + 63) >> 6;
+  const int nqb = (L + QB - 1) / QB;
   for (int qb = 0; qb < nqb; ++qb) {
-    stage_rows(qtile, RS, qbase, tokstride, qb * 64, 64, L, D, tid);
-    stage_rows(dotile, RS, dobase, ostride, qb * 64, 64, L, D, tid);
-    if (tid < 64) {
-      const int q = qb * 64 + tid;
+    st.store(qtile, dotile, RS, p, L, true);                         // Q rows rotated, dO rows as they are
+    if (tid < QB) {
+      const int q = qb * QB + tid;
       const bool ok = q < L;
       // queries past the end: lse = +inf makes p = exp2(-inf) = 0
       lse_l[tid] = ok ? p.lse[((long)b * H + h) * L + q] * LOG2E : INFINITY;
-      dl_l[tid] = ok ? p.delta_in[((long)b * H + h) * L + q] : 0.f;
+      dl_l[tid] = ok ? p.delta[((long)b * H + h) * L + q] : 0.f;
     }
     __syncthreads();
-    if (ROPE) { rope_rows(qtile, RS, qb * 64, 64, L, D, p.cosT, p.sinT, 1.f, tid); __syncthreads(); }
+    if (qb + 1 < nqb) st.load(qbase, tokstride, dobase, ostride, (qb + 1) * QB, L, cpr);   // prefetch under the MFMAs
 
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {                       // 32 queries at a time
+    for (int s2 = 0; s2 < NS2; ++s2) {                     // 32 queries at a time
+      if (qb * QB + s2 * 32 >= L) break;
       f32x4 s[2][KTW], dp[2][KTW];
 #pragma unroll
       for (int qq = 0; qq < 2; ++qq)
@@ -540,7 +624,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AP p) {
       for (int r = 0; r < 4; ++r)
         img[(wid * KPW + kt * 16 + li) * ILD + dt * 16 + 4 * g + r] = dk[dt][kt][r] * p.scale;
   __syncthreads();
-  store_grad_rows<ROPE>(img, ILD, dkbase, tokstride, k0, KPB, L, D, p.cosT, p.sinT, tid);
+  store_grad_rows<(DR > 0)>(img, ILD, dkbase, tokstride, k0, KVB, L, D, p.cosT, p.sinT, tid);
   __syncthreads();
 #pragma unroll
   for (int kt = 0; kt < KTW; ++kt)
@@ -550,90 +634,104 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AP p) {
       for (int r = 0; r < 4; ++r)
         img[(wid * KPW + kt * 16 + li) * ILD + dt * 16 + 4 * g + r] = dv[dt][kt][r];
   __syncthreads();
-  store_grad_rows<false>(img, ILD, dvbase, tokstride, k0, KPB, L, D, p.cosT, p.sinT, tid);
+  store_grad_rows<false>(img, ILD, dvbase, tokstride, k0, KVB, L, D, p.cosT, p.sinT, tid);
 }
 
-template <int DP> constexpr size_t lds_bytes() {
-  const size_t tiles = 128 * (size_t)Geo<DP>::RS + 512;
+template <int DP> constexpr size_t lds_fwd() { return (size_t)2 * Geo<DP>::KVB * Geo<DP>::RS + 256; }
+template <int DP> constexpr size_t lds_dq() {
+  const size_t rows = 256 * (size_t)Geo<DP>::RS + 128 * 4 + 256;
   const size_t img = 128 * (size_t)(DP + 4) * 4;
-  return tiles > img ? tiles : img;
+  return rows > img ? rows : img;
+}
+template <int DP> constexpr size_t lds_dkv() {
+  const size_t rows = (size_t)2 * Geo<DP>::KVB * Geo<DP>::RS + 2 * Geo<DP>::KVB * 4;
+  const size_t img = (size_t)Geo<DP>::KVB * (DP + 4) * 4;
+  return rows > img ? rows : img;
 }
 
-template <int DP, bool ROPE>
+template <int DP, int DR>
 int launch_fwd(const AP& p, hipStream_t st) {
-  const size_t lds = lds_bytes<DP>();
+  constexpr size_t lds = lds_fwd<DP>();
   if (lds > 65536)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<DP, ROPE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<DP, DR>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   dim3 grid((p.L + 127) / 128, p.H, p.B);
-  hipLaunchKernelGGL((attn_fwd_kernel<DP, ROPE>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((attn_fwd_kernel<DP, DR>), grid, dim3(256), lds, st, p);
   return clipk_check_launch();
 }
 
-template <int DP, bool ROPE>
+template <int DP, int DR>
 int launch_bwd(const AP& p, hipStream_t st) {
-  constexpr int KTW = (DP > 96) ? 1 : 2;
-  const size_t lds = lds_bytes<DP>();
-  if (lds > 65536) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<DP, ROPE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<DP, ROPE, KTW>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  }
-  const long total = (long)p.B * p.L * p.H;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+  constexpr size_t l1 = lds_dq<DP>(), l2 = lds_dkv<DP>();
+  if (l1 > 65536)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<DP, DR>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1);
+  if (l2 > 65536)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<DP, DR>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
   dim3 gq((p.L + 127) / 128, p.H, p.B);
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<DP, ROPE>), gq, dim3(256), lds, st, p);
-  constexpr int KPB = 64 * KTW;
-  dim3 gk((p.L + KPB - 1) / KPB, p.H, p.B);
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, ROPE, KTW>), gk, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<DP, DR>), gq, dim3(256), l1, st, p);
+  constexpr int KVB = Geo<DP>::KVB;
+  dim3 gk((p.L + KVB - 1) / KVB, p.H, p.B);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, DR>), gk, dim3(256), l2, st, p);
   return clipk_check_launch();
 }
 
-int check_common(const void* qkv, int B, int L, int H, int D) {
+int check_common(const void* qkv, int B, int L, int H, int D, bool rope) {
   if (!qkv || B <= 0 || L <= 0 || H <= 0 || D <= 0) return CLIPK_ERR_BAD_ARG;
   if ((D & 7) || D > 160) return CLIPK_ERR_UNSUPPORTED;
+  // RoPE runs on register-resident rows with compile-time indices: the ESM-2 head dims
+  if (rope && !(D == 16 || D == 24 || D == 32 || D == 64 || D == 128)) return CLIPK_ERR_UNSUPPORTED;
   if (!aligned16(qkv)) return CLIPK_ERR_BAD_ARG;
   return CLIPK_OK;
 }
 
 }  // namespace
 
-#define ATTN_DISPATCH(FN, D, ROPE, P, ST)                                 \
-  do {                                                                    \
-    if ((D) <= 32) return (ROPE) ? FN<32, true>(P, ST) : FN<32, false>(P, ST);    \
-    if ((D) <= 64) return (ROPE) ? FN<64, true>(P, ST) : FN<64, false>(P, ST);    \
-    if ((D) <= 96) return (ROPE) ? FN<96, true>(P, ST) : FN<96, false>(P, ST);    \
-    if ((D) <= 128) return (ROPE) ? FN<128, true>(P, ST) : FN<128, false>(P, ST); \
-    return (ROPE) ? FN<160, true>(P, ST) : FN<160, false>(P, ST);                 \
+#define ATTN_DISPATCH(FN, D, ROPE, P, ST)                                   \
+  do {                                                                      \
+    if (ROPE) {                                                             \
+      switch (D) {                                                          \
+        case 16: return FN<32, 16>(P, ST);                                  \
+        case 24: return FN<32, 24>(P, ST);                                  \
+        case 32: return FN<32, 32>(P, ST);                                  \
+        case 64: return FN<64, 64>(P, ST);                                  \
+        default: return FN<128, 128>(P, ST);                                \
+      }                                                                     \
+    }                                                                       \
+    if ((D) <= 32) return FN<32, 0>(P, ST);                                 \
+    if ((D) <= 64) return FN<64, 0>(P, ST);                                 \
+    if ((D) <= 96) return FN<96, 0>(P, ST);                                 \
+    if ((D) <= 128) return FN<128, 0>(P, ST);                               \
+    return FN<160, 0>(P, ST);                                               \
   } while (0)
 
 extern "C" int clipk_attn_fwd(const void* qkv, const uint8_t* key_mask, const float* rope_cos, const float* rope_sin,
                               void* out, float* lse, int B, int L, int H, int D, float q_scale, void* stream) {
-  int rc = check_common(qkv, B, L, H, D);
+  if ((rope_cos == nullptr) != (rope_sin == nullptr)) return CLIPK_ERR_BAD_ARG;
+  const bool rope = rope_cos != nullptr;
+  int rc = check_common(qkv, B, L, H, D, rope);
   if (rc) return rc;
   if (!out || !lse || !aligned16(out)) return CLIPK_ERR_BAD_ARG;
-  if ((rope_cos == nullptr) != (rope_sin == nullptr)) return CLIPK_ERR_BAD_ARG;
   AP p{};
   p.qkv = (const unsigned short*)qkv; p.key_mask = key_mask; p.cosT = rope_cos; p.sinT = rope_sin;
   p.out = (unsigned short*)out; p.lse = lse; p.B = B; p.L = L; p.H = H; p.D = D; p.scale = q_scale;
-  const bool rope = rope_cos != nullptr;
   ATTN_DISPATCH(launch_fwd, D, rope, p, (hipStream_t)stream);
 }
 
 extern "C" int clipk_attn_bwd(const void* qkv, const uint8_t* key_mask, const float* rope_cos, const float* rope_sin,
                               const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                               int B, int L, int H, int D, float q_scale, void* stream) {
-  int rc = check_common(qkv, B, L, H, D);
+  if ((rope_cos == nullptr) != (rope_sin == nullptr)) return CLIPK_ERR_BAD_ARG;
+  const bool rope = rope_cos != nullptr;
+  int rc = check_common(qkv, B, L, H, D, rope);
   if (rc) return rc;
   if (!out || !dout || !lse || !delta || !dqkv) return CLIPK_ERR_BAD_ARG;
   if (!aligned16(out) || !aligned16(dout) || !aligned16(dqkv)) return CLIPK_ERR_BAD_ARG;
-  if ((rope_cos == nullptr) != (rope_sin == nullptr)) return CLIPK_ERR_BAD_ARG;
   AP p{};
   p.qkv = (const unsigned short*)qkv; p.key_mask = key_mask; p.cosT = rope_cos; p.sinT = rope_sin;
   p.out = (unsigned short*)out; p.lse = const_cast<float*>(lse);
-  p.dout = (const unsigned short*)dout; p.delta_in = delta; p.delta = delta; p.dqkv = (unsigned short*)dqkv;
+  p.dout = (const unsigned short*)dout; p.delta = delta; p.dqkv = (unsigned short*)dqkv;
   p.B = B; p.L = L; p.H = H; p.D = D; p.scale = q_scale;
-  const bool rope = rope_cos != nullptr;
   ATTN_DISPATCH(launch_bwd, D, rope, p, (hipStream_t)stream);
 }

@@ -173,15 +173,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
   }
 }
 
-__global__ void colreduce_kernel(const float* part, int nparts, int ncols, float* out0, float* out1, int cols,
-                                 int accumulate) {
-  // part: [nparts][ncols] with ncols = 2*cols ([dgamma | dbeta]); fixed summation order
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ncols) return;
+// part: [nparts][ncols] with ncols = 2*cols ([dgamma | dbeta]).  Block = 64 columns x 4 row groups; each row group
+// sums every 4th partial row (coalesced 256-B reads), LDS combines the 4 groups in a fixed order.
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* part, int nparts, int ncols, float* out0,
+                                                        float* out1, int cols, int accumulate) {
+  __shared__ float sm[4][64];
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + c;
   float a = 0.f;
-  for (int s = 0; s < nparts; ++s) a += part[(long)s * ncols + i];
-  float* o = (i < cols) ? (out0 ? out0 + i : nullptr) : (out1 ? out1 + (i - cols) : nullptr);
-  if (o) *o = accumulate ? (*o + a) : a;
+  if (i < ncols)
+    for (int s = rg; s < nparts; s += 4) a += part[(long)s * ncols + i];
+  sm[rg][c] = a;
+  __syncthreads();
+  if (rg == 0 && i < ncols) {
+    a = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
+    float* o = (i < cols) ? (out0 ? out0 + i : nullptr) : (out1 ? out1 + (i - cols) : nullptr);
+    if (o) *o = accumulate ? (*o + a) : a;
+  }
 }
 
 // ---- L2 normalise -------------------------------------------------------------------------------
@@ -327,7 +335,7 @@ extern "C" int clipk_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, c
   int rc = clipk_check_launch();
   if (rc) return rc;
   if (dgamma || dbeta) {
-    hipLaunchKernelGGL(colreduce_kernel, dim3((2 * cols + 255) / 256), dim3(256), 0, st, (const float*)workspace,
+    hipLaunchKernelGGL(colreduce_kernel, dim3((2 * cols + 63) / 64), dim3(256), 0, st, (const float*)workspace,
                        blocks, 2 * cols, dgamma, dbeta, cols, accumulate);
     rc = clipk_check_launch();
   }

@@ -27,9 +27,10 @@ _kernels = ops
 
 def _gather_cat(t: torch.Tensor, group) -> torch.Tensor:
     world = dist.get_world_size(group)
-    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t.contiguous(), group=group)
-    return out
+    t = t.contiguous()
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t, group=group)          # concatenation along dim 0 (works on nccl and gloo)
+    return out.view((world,) + tuple(t.shape))
 
 
 class ClipLossFn(torch.autograd.Function):

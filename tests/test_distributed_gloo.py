@@ -1,0 +1,131 @@
+"""CPU, world_size = 2 over gloo: the rank bookkeeping of the multi-GPU path.
+
+The HIP kernels cannot run here, so tests/ops_emulator.py stands in for them inside each spawned rank; what is
+under test is the product's own distributed logic: embedding all-gather + label offsets + LSE gather + local
+backward (loss.py), the differentiable all-gather (distributed.py) and the sharded flat AdamW (optim.py).
+Contract: distributed loss / gradients / updated weights == single-process results on the concatenated batch.
+"""
+import os
+import sys
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _install_emulator():
+    sys.path[:0] = [ROOT, HERE]
+    import ops_emulator
+    from clip_dplm_amd import ops
+    for n in ops_emulator._NAMES:
+        if hasattr(ops, n) and n != "KernelTimer":
+            setattr(ops, n, getattr(ops_emulator, n))
+
+
+def _unit(n, p, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.nn.functional.normalize(torch.randn(n, p, generator=g), dim=-1)
+
+
+def _worker(rank, world, initfile, results):
+    torch.set_num_threads(1)
+    _install_emulator()
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    try:
+        from types import SimpleNamespace as NS
+
+        import clip_dplm_amd as K
+        from clip_dplm_amd.distributed import all_gather_with_grad
+        from clip_dplm_amd.loss import clip_loss
+        out = {}
+        # ---- (1) fused global-batch loss: local rows of a global batch
+        Bl, P = 12, 16
+        a_g, b_g = _unit(world * Bl, P, 1), _unit(world * Bl, P, 2)
+        sl = slice(rank * Bl, (rank + 1) * Bl)
+        a = a_g[sl].clone().requires_grad_(True)
+        b = b_g[sl].clone().requires_grad_(True)
+        s = torch.tensor(14.2849, requires_grad=True)
+        loss = clip_loss(a, b, s, symmetric=True, group=dist.group.WORLD)
+        loss.backward()
+        out["loss"], out["da"], out["db"], out["ds"] = loss.item(), a.grad.clone(), b.grad.clone(), s.grad.clone()
+        # ---- (2) differentiable all-gather (forward all-gather, backward reduce-scatter)
+        x = a_g[sl].clone().requires_grad_(True)
+        y = all_gather_with_grad(x)
+        assert torch.equal(y.detach(), a_g)
+        (y * torch.arange(y.numel()).view_as(y).float()).sum().backward()
+        out["dx"] = x.grad.clone()
+        # ---- (3) sharded flat AdamW == unsharded on the summed gradient
+        sub = lambda h: NS(hidden_size=h, num_hidden_layers=1, layer_norm_eps=1e-12)
+        cfg = NS(rna_config=sub(16), protein_config=sub(16), diffmap_config=sub(16), projection_dim=8,
+                 logit_scale_init_value=2.6592)
+        torch.manual_seed(0)
+        m = K.RNAProteinCLIPModule(cfg).eval()
+        opt = K.FusedAdamW(m, lr=1e-2, weight_decay=0.01, max_grad_norm=1.0, group=dist.group.WORLD)
+        g = torch.Generator().manual_seed(5)
+        xa, xb = torch.randn(world * 8, 16, generator=g), torch.randn(world * 8, 16, generator=g)
+        for _ in range(2):
+            opt.zero_grad()
+            l = m.loss(xa[rank * 8:(rank + 1) * 8], xb[rank * 8:(rank + 1) * 8], symmetric=True, group=dist.group.WORLD)
+            l.backward()
+            opt.step()
+        out["params"] = {n: p.detach().clone() for n, p in m.named_parameters()}
+        out["train_loss"] = l.item()
+        results[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world2_matches_single_process():
+    world = 2
+    mp.set_sharing_strategy("file_system")
+    with tempfile.TemporaryDirectory() as d:
+        mgr = mp.Manager()
+        results = mgr.dict()
+        mp.spawn(_worker, args=(world, os.path.join(d, "init"), results), nprocs=world, join=True)
+        res = [results[r] for r in range(world)]
+    # ---- single-process references (same emulated kernels, no process group)
+    _install_emulator()
+    from types import SimpleNamespace as NS
+
+    import clip_dplm_amd as K
+    from clip_dplm_amd.loss import clip_loss
+    Bl, P = 12, 16
+    a = _unit(world * Bl, P, 1).requires_grad_(True)
+    b = _unit(world * Bl, P, 2).requires_grad_(True)
+    s = torch.tensor(14.2849, requires_grad=True)
+    loss = clip_loss(a, b, s, symmetric=True, group=None)
+    loss.backward()
+    for r in range(world):
+        sl = slice(r * Bl, (r + 1) * Bl)
+        assert abs(res[r]["loss"] - loss.item()) < 1e-6
+        assert torch.allclose(res[r]["da"], a.grad[sl], rtol=1e-5, atol=1e-7)
+        assert torch.allclose(res[r]["db"], b.grad[sl], rtol=1e-5, atol=1e-7)
+    assert abs(sum(res[r]["ds"].item() for r in range(world)) - s.grad.item()) < 1e-5   # summed by the optimiser
+    # all-gather backward = reduce-scatter(sum): every rank back-propagated the same upstream gradient
+    up = torch.arange(world * Bl * P).view(world * Bl, P).float() * world
+    for r in range(world):
+        assert torch.allclose(res[r]["dx"], up[r * Bl:(r + 1) * Bl])
+    # sharded AdamW
+    sub = lambda h: NS(hidden_size=h, num_hidden_layers=1, layer_norm_eps=1e-12)
+    cfg = NS(rna_config=sub(16), protein_config=sub(16), diffmap_config=sub(16), projection_dim=8,
+             logit_scale_init_value=2.6592)
+    torch.manual_seed(0)
+    m = K.RNAProteinCLIPModule(cfg).eval()
+    opt = K.FusedAdamW(m, lr=1e-2, weight_decay=0.01, max_grad_norm=1.0)
+    g = torch.Generator().manual_seed(5)
+    xa, xb = torch.randn(world * 8, 16, generator=g), torch.randn(world * 8, 16, generator=g)
+    for _ in range(2):
+        opt.zero_grad()
+        l = m.loss(xa, xb, symmetric=True)
+        l.backward()
+        opt.step()
+    for r in range(world):
+        assert abs(res[r]["train_loss"] - l.item()) < 1e-5
+        for n, p in m.named_parameters():
+            assert torch.allclose(res[r]["params"][n], p, rtol=1e-4, atol=1e-6), (r, n)
