@@ -12,14 +12,15 @@
 //     consecutive output columns of one row, so the accumulator -> LDS staging of the epilogue is 16
 //     ds_write_b128 per lane instead of 64 ds_write_b32.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64, NTHREADS = 256;
-constexpr int A_TILE_BYTES = BM * BK * 2;               // activations  [128 m][64 k]
+constexpr int BN = 128, BK = 64;
 constexpr int B_TILE_BYTES = BN * BK * 2;               // weights      [128 n][64 k]
-constexpr int LDS_BYTES = A_TILE_BYTES + B_TILE_BYTES;  // 32 KiB
 constexpr int EPI_LD = 68;                              // f32 per staged row (16 rows x 64 cols per wave + pad)
+// BM = 128: 4 waves (2x2), 32 KiB LDS, 4 workgroups / CU.   BM = 256: 8 waves (4x2), 48 KiB LDS, 2 workgroups / CU
+// — a third fewer bytes per FLOP through the CU's L2->LDS path, which is what bounds this kernel.
 
 struct Params {
   const unsigned short* A; long lda;
@@ -33,13 +34,20 @@ struct Params {
   const void* residual; long ldr; int r_f32;
   float alpha;
   int ntn;
+  int stagger;      // s_sleep(127) units (~3.4 us each) per quarter-phase, 0 = off
 };
 
 __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(gptr, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-__global__ __launch_bounds__(NTHREADS, 4) void gemm_nt_v2_kernel(const Params p) {
+template <int BM, int STAGES>
+__global__ __launch_bounds__(BM * 2, (STAGES == 1 ? 4 : 2)) void gemm_nt_v2_kernel(const Params p) {
+  constexpr int A_TILE_BYTES = BM * BK * 2;             // activations  [BM m][64 k]
+  constexpr int STAGE_BYTES = A_TILE_BYTES + B_TILE_BYTES;
+  constexpr int NWAVES = BM / 32;
+  constexpr int A_PIECES = BM / 8 / NWAVES;             // 1-KiB LDS-DMA pieces of the A tile per wave (= 4)
+  constexpr int B_PIECES = BN / 8 / NWAVES;             // 4 (BM = 128) or 2 (BM = 256)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -48,20 +56,33 @@ __global__ __launch_bounds__(NTHREADS, 4) void gemm_nt_v2_kernel(const Params p)
   const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
   const int m0 = tm * BM, n0 = tn * BN;
   const int M = p.M, N = p.N, K = p.K;
+  // Phase stagger: every workgroup runs the same load / MFMA / store sequence for the same time, so the
+  // workgroups sharing a CU (and the whole chip) march in lockstep — all streaming outputs to HBM together, then
+  // all on the matrix pipe together.  Delaying the first-round workgroups by 0..3 quarter periods de-phases
+  // them for the rest of the launch (each CU slot keeps its offset as tiles are re-dispatched).
+  if (p.stagger > 0 && blockIdx.x < 2048) {
+    const int q = (blockIdx.x >> 3) & 3;
+    for (int i = 0; i < q * p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
 
   // ---- LDS-DMA assignment: wave w, piece i (0..3) fills rows 8*(4w+i) .. +7 of each operand tile.
   // lane -> (row in piece = lane>>3, physical 16-B slot = lane&7); source chunk = slot ^ ((row>>1)&7)
   const int prow = lane >> 3, pslot = lane & 7;
-  const unsigned short* asrc[4];
-  const unsigned short* bsrc[4];
-  int kchunk[4];
+  const unsigned short* asrc[A_PIECES];
+  const unsigned short* bsrc[B_PIECES];
+  int akchunk[A_PIECES], bkchunk[B_PIECES];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = 8 * (4 * wid + i) + prow;
-    kchunk[i] = (pslot ^ ((row >> 1) & 7)) * 8;
+  for (int i = 0; i < A_PIECES; ++i) {
+    const int row = 8 * (A_PIECES * wid + i) + prow;
+    akchunk[i] = (pslot ^ ((row >> 1) & 7)) * 8;
     int ra = m0 + row; ra = ra < M ? ra : M - 1;
-    int rb = n0 + row; rb = rb < N ? rb : N - 1;
     asrc[i] = p.A + (long)ra * p.lda;
+  }
+#pragma unroll
+  for (int i = 0; i < B_PIECES; ++i) {
+    const int row = 8 * (B_PIECES * wid + i) + prow;
+    bkchunk[i] = (pslot ^ ((row >> 1) & 7)) * 8;
+    int rb = n0 + row; rb = rb < N ? rb : N - 1;
     bsrc[i] = p.B + (long)rb * p.ldb;
   }
 
@@ -77,25 +98,30 @@ __global__ __launch_bounds__(NTHREADS, 4) void gemm_nt_v2_kernel(const Params p)
   const int w_frag_off = A_TILE_BYTES + (wn * 64 + frow) * 128;    // weight rows (A operand)
 
   const int nk = (K + BK - 1) / BK;
-  for (int kt = 0; kt < nk; ++kt) {
+  auto issue = [&](int kt, char* stage) {
     const int k0 = kt * BK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int k = k0 + kchunk[i];
+    for (int i = 0; i < A_PIECES; ++i) {
+      int k = k0 + akchunk[i];
       k = k < K ? k : 0;                                 // K tail (K % 64 == 32): slot is never read, keep the address valid
-      char* dst = smem + (4 * wid + i) * 1024;
-      glds16(asrc[i] + k, dst);
-      glds16(bsrc[i] + k, dst + A_TILE_BYTES);
+      glds16(asrc[i] + k, stage + (A_PIECES * wid + i) * 1024);
     }
-    __syncthreads();                                     // drains the LDS-DMA (vmcnt(0)) and publishes the tile
-    const int ksub = (k0 + 32 < K) ? 2 : 1;
+#pragma unroll
+    for (int i = 0; i < B_PIECES; ++i) {
+      int k = k0 + bkchunk[i];
+      k = k < K ? k : 0;
+      glds16(bsrc[i] + k, stage + A_TILE_BYTES + (B_PIECES * wid + i) * 1024);
+    }
+  };
+  auto compute = [&](int kt, const char* stage) {
+    const int ksub = (kt * BK + 32 < K) ? 2 : 1;
     for (int kk = 0; kk < ksub; ++kk) {
       const int choff = (((kk * 4 + fch) ^ lane_sw) << 4);
       bf16x8 wf[4], xf[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        wf[t] = *reinterpret_cast<const bf16x8*>(smem + w_frag_off + t * 2048 + choff);
-        xf[t] = *reinterpret_cast<const bf16x8*>(smem + x_frag_off + t * 2048 + choff);
+        wf[t] = *reinterpret_cast<const bf16x8*>(stage + w_frag_off + t * 2048 + choff);
+        xf[t] = *reinterpret_cast<const bf16x8*>(stage + x_frag_off + t * 2048 + choff);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -103,7 +129,32 @@ __global__ __launch_bounds__(NTHREADS, 4) void gemm_nt_v2_kernel(const Params p)
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();                                     // everyone done reading before the next DMA lands
+  };
+  if (STAGES == 1) {
+    for (int kt = 0; kt < nk; ++kt) {
+      issue(kt, smem);
+      __syncthreads();                                   // drains the LDS-DMA (vmcnt(0)) and publishes the tile
+      compute(kt, smem);
+      __syncthreads();                                   // everyone done reading before the next DMA lands
+    }
+  } else {
+    // two stages: the LDS-DMA of step kt+1 stays in flight across the barrier while step kt's MFMAs run
+    // (counted vmcnt + raw s_barrier: __syncthreads() would drain it, cdna_hip_programming.md §5)
+    issue(0, smem);
+    for (int kt = 0; kt < nk; ++kt) {
+      char* cur = smem + (kt & 1) * STAGE_BYTES;
+      if (kt + 1 < nk) {
+        issue(kt + 1, smem + ((kt + 1) & 1) * STAGE_BYTES);
+        if (A_PIECES + B_PIECES == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();                      // step kt's tile is complete for every wave
+      compute(kt, cur);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                      // all fragment reads of this stage retired before it is refilled
+    }
   }
 
   // ---- epilogue, one 16-row m-tile at a time through a wave-private LDS slab [16 m][64 n (+4)] f32
@@ -202,8 +253,30 @@ extern "C" int clipk_gemm_nt_v2_launch(const clipk_gemm_args* a, void* stream) {
   p.dact_aux = (const unsigned short*)a->dact_aux; p.ldd = a->ldd; p.dact = a->dact;
   p.residual = a->residual; p.ldr = a->ldr; p.r_f32 = (a->r_dtype == CLIPK_F32);
   p.alpha = a->alpha;
-  const int ntm = (a->M + BM - 1) / BM, ntn = (a->N + BN - 1) / BN;
+  const int ntn = (a->N + BN - 1) / BN;
   p.ntn = ntn;
-  hipLaunchKernelGGL(gemm_nt_v2_kernel, dim3(ntm * ntn), dim3(NTHREADS), LDS_BYTES, (hipStream_t)stream, p);
+  { const char* sg = getenv("CLIPK_GEMM_STAGGER"); p.stagger = sg ? atoi(sg) : 0; }
+  const char* force = getenv("CLIPK_GEMM_BM");             // A/B switch for tools/bench_kernels.py
+  const bool big = force ? (atoi(force) == 256) : false;
+  const char* fs = getenv("CLIPK_GEMM_STAGES");
+  const int stages = fs ? atoi(fs) : 1;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_v2_kernel<256, 2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * BK * 2 + B_TILE_BYTES));
+    attr_set = true;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (big) {
+    const int ntm = (a->M + 255) / 256;
+    const int lds = 256 * BK * 2 + B_TILE_BYTES;
+    if (stages == 2) hipLaunchKernelGGL((gemm_nt_v2_kernel<256, 2>), dim3(ntm * ntn), dim3(512), 2 * lds, st, p);
+    else hipLaunchKernelGGL((gemm_nt_v2_kernel<256, 1>), dim3(ntm * ntn), dim3(512), lds, st, p);
+  } else {
+    const int ntm = (a->M + 127) / 128;
+    const int lds = 128 * BK * 2 + B_TILE_BYTES;
+    if (stages == 2) hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 2>), dim3(ntm * ntn), dim3(256), 2 * lds, st, p);
+    else hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1>), dim3(ntm * ntn), dim3(256), lds, st, p);
+  }
   return clipk_check_launch();
 }
