@@ -13,8 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libclipk.so")
 
 BF16, F32 = 0, 1
-ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
-ACT = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU}
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_CELU, ACT_SOFTPLUS = 0, 1, 2, 3, 4
+ACT = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU, "celu": ACT_CELU, "softplus": ACT_SOFTPLUS}
 
 
 class ClipkError(RuntimeError):
@@ -51,6 +51,7 @@ SIGNATURES = {
     "clipk_simce_lse": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "clipk_simce_grad": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _sz, _vp]),
     "clipk_sim_logits": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i64, _vp]),
+    "clipk_gemm_f32_nt": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "clipk_layernorm_fwd": (_i, [_vp, _i, _i64, _vp, _vp, _f, _i, _vp, _vp, _i64, _vp, _vp, _i, _i, _vp]),
     "clipk_layernorm_bwd_workspace": (_sz, [_i, _i]),
     "clipk_layernorm_bwd": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i64,

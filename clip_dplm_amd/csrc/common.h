@@ -51,11 +51,15 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 __device__ __forceinline__ float act_apply(float x, int act) {
   if (act == CLIPK_ACT_RELU) return x > 0.f ? x : 0.f;
   if (act == CLIPK_ACT_GELU) return gelu_erf(x);
+  if (act == CLIPK_ACT_CELU) return x > 0.f ? x : expm1f(x);                    // F.celu, alpha = 1
+  if (act == CLIPK_ACT_SOFTPLUS) return x > 20.f ? x : log1pf(expf(x));         // F.softplus (beta 1, threshold 20)
   return x;
 }
 __device__ __forceinline__ float act_grad(float x, int act) {
   if (act == CLIPK_ACT_RELU) return x > 0.f ? 1.f : 0.f;
   if (act == CLIPK_ACT_GELU) return gelu_erf_grad(x);
+  if (act == CLIPK_ACT_CELU) return x > 0.f ? 1.f : expf(x);
+  if (act == CLIPK_ACT_SOFTPLUS) return x > 20.f ? 1.f : 1.0f / (1.0f + expf(-x));
   return 1.f;
 }
 

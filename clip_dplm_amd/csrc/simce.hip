@@ -44,8 +44,9 @@ struct SP {
   float w_row, w_col, inv_bg;
   float* slab;         // [ksplit][Mx][P]
   float* dsc_part;     // [ksplit][Mx]
-  // logits
+  // logits / f32 Linear epilogue
   float* S; long lds_out;
+  const float* ep_bias; const float* ep_add; const float* ep_add_scale;
   int ksplit, tiles_per_split, ntiles;
 };
 
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(512) void simce_kernel(const SP p) {
   float* ylds = reinterpret_cast<float*>(smem) + w * KT * YLD;
   float* red = reinterpret_cast<float*>(smem) + NW * KT * YLD;     // [NW][16*64]
   const int pbeg = w * Pw;
-  const float scale = p.scale[0];
+  const float scale = p.scale ? p.scale[0] : 1.0f;
 
   // ---- this wave's slice of the query block, as B fragments of S^T = Y·X^T (kept in registers)
   f32x4 xf[PWMAX / 8];
@@ -192,7 +193,12 @@ __global__ __launch_bounds__(512) void simce_kernel(const SP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = j0 + keyrow(r, h);
-          if (key < Nkeys && qg < p.Mx) p.S[(long)key * p.lds_out + qg] = scale * s[r];
+          if (key < Nkeys && qg < p.Mx) {
+            float v = scale * s[r];
+            if (p.ep_bias) v += p.ep_bias[qg];
+            if (p.ep_add) v += (p.ep_add_scale ? p.ep_add_scale[0] : 1.0f) * p.ep_add[(long)key * p.lds_out + qg];
+            p.S[(long)key * p.lds_out + qg] = v;
+          }
         }
       }
     }
@@ -364,6 +370,21 @@ extern "C" int clipk_sim_logits(const float* X, int Mx, const float* Y, int Ny, 
   sp.X = Y; sp.Mx = Ny; sp.Y = X; sp.Ny = Mx; sp.Yc = X; sp.Nc = 0;
   sp.P = P; sp.Pw = pl.Pw; sp.NW = pl.NW; sp.scale = scale; sp.label_offset = 0;
   sp.S = S; sp.lds_out = lds;
+  sp.ksplit = pl.ksplit; sp.tiles_per_split = pl.tps; sp.ntiles = pl.ntiles;
+  return launch<MODE_LOGITS>(sp, pl, (hipStream_t)stream);
+}
+
+extern "C" int clipk_gemm_f32_nt(const float* X, int M, const float* W, int N, int K, const float* bias,
+                                 const float* addend, const float* addend_scale, float* out, void* stream) {
+  if (!X || !W || !out) return CLIPK_ERR_BAD_ARG;
+  Plan pl;
+  if (!make_plan(N, M, K, &pl)) return CLIPK_ERR_UNSUPPORTED;       // kernel "queries" = output columns (rows of W)
+  if (!aligned16(X) || !aligned16(W)) return CLIPK_ERR_BAD_ARG;
+  SP sp{};
+  sp.X = W; sp.Mx = N; sp.Y = X; sp.Ny = M; sp.Yc = X; sp.Nc = 0;
+  sp.P = K; sp.Pw = pl.Pw; sp.NW = pl.NW; sp.scale = nullptr; sp.label_offset = 0;
+  sp.S = out; sp.lds_out = N;
+  sp.ep_bias = bias; sp.ep_add = addend; sp.ep_add_scale = addend_scale;
   sp.ksplit = pl.ksplit; sp.tiles_per_split = pl.tps; sp.ntiles = pl.ntiles;
   return launch<MODE_LOGITS>(sp, pl, (hipStream_t)stream);
 }

@@ -185,3 +185,22 @@ class SimLogitsFn(torch.autograd.Function):
 
 def sim_logits(a, b, scale):
     return SimLogitsFn.apply(a, b, scale)
+
+
+class AttnFn(torch.autograd.Function):
+    """Self-attention on a fused qkv tensor [B*L, 3*H*D] (bf16) -> [B*L, H*D] (bf16), flash kernels fwd/bwd."""
+
+    @staticmethod
+    def forward(ctx, qkv, B, L, H, D, key_mask, q_scale):
+        qkv = qkv.contiguous()
+        out, lse = ops.attn_fwd(qkv, B, L, H, D, key_mask=key_mask, rope=None, q_scale=q_scale)
+        ctx.meta = (B, L, H, D, key_mask, q_scale)
+        ctx.save_for_backward(qkv, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        B, L, H, D, key_mask, q_scale = ctx.meta
+        dqkv = ops.attn_bwd(qkv, out, _bf16(dout), lse, B, L, H, D, key_mask=key_mask, rope=None, q_scale=q_scale)
+        return dqkv, None, None, None, None, None, None

@@ -188,6 +188,17 @@ def sim_logits(x, y, scale):
     return s
 
 
+def gemm_f32_nt(x, w, bias=None, addend=None, addend_scale=None):
+    """Exact-f32 out = x @ w.T (+ bias) (+ addend_scale * addend): the ICNN's Linear layers."""
+    _need_cuda(x, w, bias, addend, addend_scale)
+    M, K = x.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    check(_lib().clipk_gemm_f32_nt(x.data_ptr(), M, w.data_ptr(), N, K, ptr(bias), ptr(addend), ptr(addend_scale),
+                                   out.data_ptr(), _stream()), "clipk_gemm_f32_nt")
+    return out
+
+
 # --------------------------------------------------------------------------------------------------
 def layernorm_fwd(x, gamma, beta, eps, act=None, want_f32=True, want_bf16=False, want_stats=True):
     _need_cuda(x, gamma, beta)

@@ -34,7 +34,8 @@ typedef enum clipk_status {
 } clipk_status;
 
 typedef enum clipk_dtype { CLIPK_BF16 = 0, CLIPK_F32 = 1 } clipk_dtype;
-typedef enum clipk_act { CLIPK_ACT_NONE = 0, CLIPK_ACT_RELU = 1, CLIPK_ACT_GELU = 2 } clipk_act;
+typedef enum clipk_act { CLIPK_ACT_NONE = 0, CLIPK_ACT_RELU = 1, CLIPK_ACT_GELU = 2, CLIPK_ACT_CELU = 3,
+                         CLIPK_ACT_SOFTPLUS = 4 } clipk_act;
 
 int clipk_version(void);          /* ABI version, bumped on any signature change */
 const char* clipk_arch(void);     /* "gfx950" */
@@ -114,6 +115,15 @@ int clipk_simce_grad(const float* X, int Mx, const float* Y, int Ny, const float
  *   S[Mx,Ny] = scale * X·Y^T, exact f32. */
 int clipk_sim_logits(const float* X, int Mx, const float* Y, int Ny, int P, const float* scale,
                      float* S, int64_t lds, void* stream);
+
+/* Exact-f32 Linear for the ICNN transport maps (the reference forces f32 there: triple_flow/2_icnn_core.py:195):
+ *   out[M,N] = X[M,K] · W[N,K]^T (+ bias[N]) (+ addend_scale[0] * addend[M,N])
+ * Replaces self.linear(x) + scale * F.linear(z, softplus(W+)) at triple_flow/2_icnn_core.py:102-119 and the
+ * matching products of the analytic input gradient T(x) = dPsi/dx (:181-211).  Same f32-MFMA kernel as
+ * clipk_sim_logits.  K % 4 == 0, K <= 768. */
+int clipk_gemm_f32_nt(const float* X, int M, const float* W, int N, int K, const float* bias,
+                      const float* addend, const float* addend_scale /* device scalar or NULL (=1) */,
+                      float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row-wise normalisation kernels (one wave per row, f32 statistics).

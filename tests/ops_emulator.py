@@ -18,6 +18,10 @@ def _act(x, act):
         return torch.relu(x)
     if act == "gelu":
         return F.gelu(x)
+    if act == "celu":
+        return F.celu(x)
+    if act == "softplus":
+        return F.softplus(x)
     return x
 
 
@@ -28,6 +32,10 @@ def _act_grad(x, act):
         cdf = 0.5 * (1 + torch.erf(x / math.sqrt(2)))
         pdf = torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
         return cdf + x * pdf
+    if act == "celu":
+        return torch.where(x > 0, torch.ones_like(x), torch.exp(x))
+    if act == "softplus":
+        return torch.sigmoid(x)
     return torch.ones_like(x)
 
 
@@ -87,6 +95,15 @@ def simce_grad(x, y, scale, lse_x, lse_y, w_row, w_col, inv_bg, label_offset=0, 
     dx = (g @ keys.double()) * scale.double()
     dsc = (g * (s / scale.double())).sum(1)
     return dx.float(), dsc.float()
+
+
+def gemm_f32_nt(x, w, bias=None, addend=None, addend_scale=None):
+    out = x @ w.t()
+    if bias is not None:
+        out = out + bias
+    if addend is not None:
+        out = out + (addend_scale if addend_scale is not None else 1.0) * addend
+    return out
 
 
 def sim_logits(x, y, scale):

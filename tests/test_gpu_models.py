@@ -250,3 +250,46 @@ def test_fused_adamw_training_reduces_loss(dev):
         losses.append(loss.item())
     assert losses[-1] < losses[0] - 0.05, losses
     assert m.logit_scale.data_ptr() >= opt.flat.data.data_ptr()
+
+
+def test_icnn_transport_golden(dev):
+    """BASELINE config 5 (eval): T(x) = dPsi/dx from the hand-derived gradient on exact-f32 MFMA kernels vs the
+    reference's autograd-of-autograd output (golden); f32 path, tolerance 2e-4."""
+    from clip_dplm_amd import icnn
+    z, sd = load("icnn_transport.npz")
+    model = icnn.create_transport_system(64, 64, 64, hidden_dims=[64, 64, 32])
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    out = model(t(z, "cell", dev), t(z, "pert", dev), t(z, "protein", dev))
+    assert set(out) == {"cell_to_pert", "cell_to_protein", "pert_to_protein"}
+    for k, v in out.items():
+        ref = t(z, "out_" + k, dev)
+        assert (v - ref).abs().max().item() < 2e-4, (k, (v - ref).abs().max().item())
+    psi, _ = model.cell_to_pert.transport_net(torch.nn.functional.layer_norm(
+        t(z, "cell", dev), (64,), model.cell_to_pert.input_norm.weight, model.cell_to_pert.input_norm.bias))
+    assert torch.allclose(psi, t(z, "psi_cell_to_pert", dev), atol=1e-4)
+    c = model.cell_to_pert.cost(t(z, "cell", dev), t(z, "pert", dev))
+    from oracle import icnn_ref, clip_ref
+    tgt = clip_ref._ln(t(z, "pert"), sd, "cell_to_pert.output_norm", 1e-5)
+    cref, _, _ = icnn_ref.transport_cost(t(z, "out_cell_to_pert"), tgt)
+    assert abs(c.cost.item() - cref.item()) < 1e-3
+    model.train()
+    with pytest.raises(NotImplementedError):
+        model(t(z, "cell", dev), t(z, "pert", dev))
+
+
+def test_esm_projections_golden(dev):
+    """ProteinProjection / GeneProjection (3_esm_integration.py:137-213) vs the reference (golden)."""
+    from clip_dplm_amd import esm_integration as E
+    z, sd = load("esm_projections.npz")
+    x = t(z, "x", dev)
+    for name, cls in (("protein", E.ProteinProjection), ("gene", E.GeneProjection)):
+        m = cls(esm_dim=64, output_dim=32)
+        m.load_state_dict({k[len(name) + 1:]: v for k, v in sd.items() if k.startswith(name + ".")})
+        m = m.to(dev).eval()
+        y = m(x)
+        ref = t(z, "y_" + name, dev)
+        assert (y - ref).abs().max().item() < 0.06, (name, (y - ref).abs().max().item())   # LN output, bf16 GEMMs
+        y.sum().backward()
+    ids, mask = E.tokenize(["MKV", "ACDEFGHIK"])
+    assert ids.tolist()[0] == [0, 20, 15, 7, 2, 1, 1, 1, 1, 1, 1] and mask.sum().item() == 5 + 11

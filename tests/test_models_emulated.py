@@ -17,6 +17,8 @@ CASES = [
     ("esm_tiny", T.test_esm_tiny_golden, {}),
     ("protein_rna", T.test_protein_rna_clip_vs_oracle, {}),
     ("adamw_train", T.test_fused_adamw_training_reduces_loss, {}),
+    ("icnn", T.test_icnn_transport_golden, {}),
+    ("esm_proj", T.test_esm_projections_golden, {}),
 ]
 
 

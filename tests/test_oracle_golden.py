@@ -119,3 +119,15 @@ def test_analytic_properties():
     s = (a @ b.t()) * 14.2849
     assert abs(clip_ref.clip_loss_symmetric(s).item() - clip_ref.clip_loss_symmetric(s.t()).item()) < 1e-6
     assert abs(clip_ref.clip_loss_symmetric(s * 0).item() - np.log(64)) < 1e-6
+
+
+def test_icnn_transport_maps():
+    """triple_flow ICNN transport maps (eval): oracle vs the reference's autograd-of-autograd outputs."""
+    from oracle import icnn_ref
+    z, sd = load("icnn_transport.npz")
+    for name, src in (("cell_to_pert", "cell"), ("cell_to_protein", "cell"), ("pert_to_protein", "pert")):
+        o = icnn_ref.single_cell_transport(t(z, src), sd, name, 3)
+        assert torch.allclose(o, t(z, "out_" + name), atol=2e-5), name
+    s = encoder_ref._ln(t(z, "cell"), sd, "cell_to_pert.input_norm", 1e-5)
+    psi = icnn_ref.icnn_potential(s, sd, "cell_to_pert.transport_net", 3)
+    assert torch.allclose(psi, t(z, "psi_cell_to_pert"), atol=2e-5)

@@ -212,10 +212,70 @@ def gen_esm():
     save("esm_tiny_grads.npz", dy=dy.numpy(), **arrays)
 
 
+# ------------------------------------------------------------------------------------------------ ICNN transport
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def gen_icnn():
+    from oracle import icnn_ref
+    _load("config", REF + "/triple_flow/1_config.py")
+    _load("core", REF + "/triple_flow/2_icnn_core.py")
+    tm = _load("transport_maps", REF + "/triple_flow/4_transport_maps.py")
+    torch.manual_seed(0)
+    model = tm.create_transport_system(64, 64, 64, hidden_dims=[64, 64, 32]).eval()
+    with torch.no_grad():                                     # make the positive path matter
+        for m in model.modules():
+            if hasattr(m, "pos_weights"):
+                m.pos_weights.normal_(0, 0.5)
+                m.scale.fill_(0.3)
+    g = torch.Generator().manual_seed(21)
+    cell, pert, prot = (torch.randn(24, 64, generator=g) for _ in range(3))
+    out = model(cell, pert, prot)
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    for name, src in (("cell_to_pert", cell), ("cell_to_protein", cell), ("pert_to_protein", pert)):
+        o = icnn_ref.single_cell_transport(src, sd, name, 3)
+        check(f"icnn {name}", o, out[name].detach(), 2e-5)
+    psi = model.cell_to_pert.transport_net(model.cell_to_pert.input_norm(cell))[0].detach()
+    save("icnn_transport.npz", cell=cell.numpy(), pert=pert.numpy(), protein=prot.numpy(), psi_cell_to_pert=psi.numpy(),
+         **{"out_" + k: v.detach().numpy() for k, v in out.items()}, **sd_np(model))
+
+
+def gen_esm_projections():
+    esmi = _load("esm_integration", REF + "/triple_flow/3_esm_integration.py")   # projection classes only
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(3, 10, 64, generator=g)
+    out = {}
+    for name, cls in (("protein", esmi.ProteinProjection), ("gene", esmi.GeneProjection)):
+        m = cls(esm_dim=64, output_dim=32).eval()
+        with torch.no_grad():
+            y = m(x)
+        out[name] = (m, y)
+    arrays = {"x": x.numpy()}
+    for name, (m, y) in out.items():
+        arrays["y_" + name] = y.numpy()
+        arrays.update(sd_np({name + "." + k: v for k, v in m.state_dict().items()}))
+    save("esm_projections.npz", **arrays)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "proj":
+        _load("config", REF + "/triple_flow/1_config.py")
+        gen_esm_projections()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "icnn":
+        gen_icnn()
+        sys.exit(0)
     rc = gen_clip_c1()
     gen_clip_opt(rc)
     gen_notebook()
     gen_tlayer()
     gen_esm()
+    gen_icnn()
+    gen_esm_projections()
     print("all golden fixtures written and the oracle agrees with the reference on each")
