@@ -38,6 +38,25 @@ struct AP {
 
 constexpr float LOG2E = 1.4426950408889634f;
 
+// v_exp_f32 directly: every argument here is <= 0 (or -inf), so the denormal-range fix-up of exp2f() is dead weight
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// Work-item order: the G = (blocks per sequence) x H workgroups of one batch element read the same token rows
+// (each head only D*2 bytes of a 3*H*D*2-byte row), so keep them on ONE XCD's L2: blocks b and b+8 share an XCD
+// (round-robin dispatch), hence XCD x gets batch elements x, x+8, ...  Falls back to the plain order when B % 8 != 0.
+__device__ __forceinline__ void work_item(int nblk, int H, int B, int& blk, int& h, int& b) {
+  const int G = nblk * H;
+  int w = blockIdx.x;
+  if ((B & 7) == 0) {
+    const int xcd = w & 7, slot = w >> 3;
+    w = ((slot / G) * 8 + xcd) * G + (slot % G);
+  }
+  b = w / G;
+  const int r = w - b * G;
+  h = r / nblk;
+  blk = r - h * nblk;
+}
+
 template <int DP> struct Geo {
   static constexpr int RS = DP * 2 + 32;     // LDS row stride in bytes
   static constexpr int KS = DP / 32;         // contraction steps over the head dim
@@ -158,8 +177,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AP p) {
   unsigned char* mask_l = reinterpret_cast<unsigned char*>(smem + 2 * KVB * RS);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
-  const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int D = p.D, L = p.L, H = p.H;
+  int qb, h, b;
+  work_item((L + 127) / 128, H, p.B, qb, h, b);
   const int cpr = D >> 3;
   const long tokstride = 3L * H * D;
   const unsigned short* qbase = p.qkv + (long)b * L * tokstride + (long)h * D;
@@ -223,12 +243,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AP p) {
           s[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[kt][0], 0, 0, 0);
           s[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[kt][1], 0, 0, 0);
         }
+      if (p.key_mask != nullptr || kb * KVB + sub * 64 + 64 > L) {     // wave-uniform: full, unmasked blocks skip this
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        const unsigned int mk = *reinterpret_cast<const unsigned int*>(mask_l + sub * 64 + kt * 16 + 4 * g);
+        for (int kt = 0; kt < 4; ++kt) {
+          const unsigned int mk = *reinterpret_cast<const unsigned int*>(mask_l + sub * 64 + kt * 16 + 4 * g);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (!((mk >> (8 * r)) & 0xffu)) { s[kt][0][r] = -INFINITY; s[kt][1][r] = -INFINITY; }
+          for (int r = 0; r < 4; ++r)
+            if (!((mk >> (8 * r)) & 0xffu)) { s[kt][0][r] = -INFINITY; s[kt][1][r] = -INFINITY; }
+        }
       }
       bf16x8 pb[2][2];
 #pragma unroll
@@ -241,13 +263,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AP p) {
         mx = group_max(mx);
         const float m_new = fmaxf(m_run[qt], mx);
         const bool dead = (m_new == -INFINITY);
-        const float alpha = dead ? 1.f : exp2f((m_run[qt] - m_new) * c2);
+        const float alpha = dead ? 1.f : fast_exp2((m_run[qt] - m_new) * c2);
         float ls = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pv = dead ? 0.f : exp2f((s[kt][qt][r] - m_new) * c2);
+            const float pv = dead ? 0.f : fast_exp2((s[kt][qt][r] - m_new) * c2);
             s[kt][qt][r] = pv;
             ls += pv;
           }
@@ -349,8 +371,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AP p) {
   unsigned char* mask_l = reinterpret_cast<unsigned char*>(delta_l + 128);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
-  const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int D = p.D, L = p.L, H = p.H;
+  int qb, h, b;
+  work_item((L + 127) / 128, H, p.B, qb, h, b);
   const int cpr = D >> 3;
   const long tokstride = 3L * H * D, ostride = (long)H * D;
   const unsigned short* qbase = p.qkv + (long)b * L * tokstride + (long)h * D;
@@ -444,7 +467,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AP p) {
           const bool ok = ((mk >> (8 * r)) & 0xffu) != 0;
 #pragma unroll
           for (int qt = 0; qt < 2; ++qt) {
-            const float pv = ok ? exp2f(s[kt][qt][r] * c2 - lse2[qt]) : 0.f;
+            const float pv = ok ? fast_exp2(s[kt][qt][r] * c2 - lse2[qt]) : 0.f;
             s[kt][qt][r] = pv * (dp[kt][qt][r] - dl[qt]);          // dS^T (w.r.t. the scaled score)
           }
         }
@@ -505,8 +528,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AP p) {
   float* dl_l = lse_l + QB;                                      // [QB]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
-  const int kbk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int D = p.D, L = p.L, H = p.H;
+  int kbk, h, b;
+  work_item((L + KVB - 1) / KVB, H, p.B, kbk, h, b);
   const int cpr = D >> 3;
   const long tokstride = 3L * H * D, ostride = (long)H * D;
   const unsigned short* qbase = p.qkv + (long)b * L * tokstride + (long)h * D;
@@ -590,7 +614,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AP p) {
         for (int kt = 0; kt < KTW; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pv = kvalid[kt] ? exp2f(s[qq][kt][r] * c2 - ls[r]) : 0.f;
+            const float pv = kvalid[kt] ? fast_exp2(s[qq][kt][r] * c2 - ls[r]) : 0.f;
             s[qq][kt][r] = pv;                                  // P
             dp[qq][kt][r] = pv * (dp[qq][kt][r] - dd[r]);       // dS
           }
@@ -655,7 +679,7 @@ int launch_fwd(const AP& p, hipStream_t st) {
   if (lds > 65536)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<DP, DR>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  dim3 grid((p.L + 127) / 128, p.H, p.B);
+  dim3 grid(((p.L + 127) / 128) * p.H * p.B);
   hipLaunchKernelGGL((attn_fwd_kernel<DP, DR>), grid, dim3(256), lds, st, p);
   return clipk_check_launch();
 }
@@ -669,10 +693,10 @@ int launch_bwd(const AP& p, hipStream_t st) {
   if (l2 > 65536)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<DP, DR>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
-  dim3 gq((p.L + 127) / 128, p.H, p.B);
+  dim3 gq(((p.L + 127) / 128) * p.H * p.B);
   hipLaunchKernelGGL((attn_bwd_dq_kernel<DP, DR>), gq, dim3(256), l1, st, p);
   constexpr int KVB = Geo<DP>::KVB;
-  dim3 gk((p.L + KVB - 1) / KVB, p.H, p.B);
+  dim3 gk(((p.L + KVB - 1) / KVB) * p.H * p.B);
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, DR>), gk, dim3(256), l2, st, p);
   return clipk_check_launch();
 }

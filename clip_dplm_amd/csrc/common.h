@@ -27,26 +27,31 @@ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
   return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
 }
 
-// erf(x) by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. f32-rounding level, far below the bf16 rounding of
-// every consumer): one v_rcp, one v_exp and a degree-5 Horner instead of ocml erff's ~25-instruction branchy path.
-// Used by the fused GEMM / LayerNorm epilogues, where the activation runs on every output element.
-__device__ __forceinline__ float fast_erf(float x) {
+// erf-GELU with erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7: f32-rounding level, far below the bf16
+// rounding of every consumer), written for the raw v_rcp_f32 / v_exp_f32 instructions: ~15 VALU per element
+// instead of ocml erff's branchy ~40.  The GEMM epilogues that apply it are VALU-bound (profiles/).
+//   erf(|x|/sqrt2) = 1 - (a1 t + ... + a5 t^5) * exp(-x^2/2),  t = 1 / (1 + p |x| / sqrt2)
+// exp(-x^2/2) is shared by the erf and by the Gaussian pdf of the derivative.
+__device__ __forceinline__ void gelu_parts(float x, float& erf_abs, float& e) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+  e = __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);        // exp(-x^2/2) = 2^(-x^2 * log2(e) / 2)
   float poly = fmaf(1.061405429f, t, -1.453152027f);
   poly = fmaf(poly, t, 1.421413741f);
   poly = fmaf(poly, t, -0.284496736f);
   poly = fmaf(poly, t, 0.254829592f);
-  const float y = 1.0f - poly * t * __expf(-ax * ax);
-  return copysignf(y, x);
+  erf_abs = fmaf(-poly * t, e, 1.0f);                                  // erf(|x| / sqrt 2)
 }
 __device__ __forceinline__ float gelu_erf(float x) {          // transformers modeling_esm.py:82-86 / nn.GELU()
-  return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f));
+  float erf_abs, e;
+  gelu_parts(x, erf_abs, e);
+  return fmaf(0.5f * fabsf(x), erf_abs, 0.5f * x);            // 0.5 x (1 + sign(x) erf|.|)
 }
-__device__ __forceinline__ float gelu_erf_grad(float x) {
-  const float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+__device__ __forceinline__ float gelu_erf_grad(float x) {     // Phi(x) + x phi(x)
+  float erf_abs, e;
+  gelu_parts(x, erf_abs, e);
+  const float cdf = fmaf(copysignf(0.5f, x), erf_abs, 0.5f);
+  return fmaf(x * 0.39894228040143267794f, e, cdf);
 }
 __device__ __forceinline__ float act_apply(float x, int act) {
   if (act == CLIPK_ACT_RELU) return x > 0.f ? x : 0.f;

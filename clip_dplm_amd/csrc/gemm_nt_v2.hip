@@ -41,7 +41,9 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(gptr, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int STAGES>
+// ACT_T / DACT_T: compile-time activation of the epilogue (-1 = take p.act / p.dact at run time).  The GELU
+// epilogues are VALU-bound (one erf per output element), so the hot combinations get branch-free specialisations.
+template <int BM, int STAGES, int ACT_T = -1, int DACT_T = -1>
 __global__ __launch_bounds__(BM * 2, (STAGES == 1 ? 4 : 2)) void gemm_nt_v2_kernel(const Params p) {
   constexpr int A_TILE_BYTES = BM * BK * 2;             // activations  [BM m][64 k]
   constexpr int STAGE_BYTES = A_TILE_BYTES + B_TILE_BYTES;
@@ -195,16 +197,18 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 ? 4 : 2)) void gemm_nt_v2_kern
           for (int c = 0; c < 4; ++c) o[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
           *reinterpret_cast<u32x4*>(p.out_preact + (long)gm * p.ldp + gn) = o;
         }
-        if (p.act != CLIPK_ACT_NONE) {
+        const int act = (ACT_T >= 0) ? ACT_T : p.act;
+        const int dact = (DACT_T >= 0) ? DACT_T : p.dact;
+        if (act != CLIPK_ACT_NONE) {
 #pragma unroll
-          for (int c = 0; c < 8; ++c) v[c] = act_apply(v[c], p.act);
+          for (int c = 0; c < 8; ++c) v[c] = act_apply(v[c], act);
         }
-        if (p.dact_aux) {
+        if ((DACT_T < 0 || DACT_T != CLIPK_ACT_NONE) && p.dact_aux) {
           const u32x4 a = *reinterpret_cast<const u32x4*>(p.dact_aux + (long)gm * p.ldd + gn);
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            v[2 * c] *= act_grad(bf16_to_f32((unsigned short)(a[c] & 0xffffu)), p.dact);
-            v[2 * c + 1] *= act_grad(bf16_to_f32((unsigned short)(a[c] >> 16)), p.dact);
+            v[2 * c] *= act_grad(bf16_to_f32((unsigned short)(a[c] & 0xffffu)), dact);
+            v[2 * c + 1] *= act_grad(bf16_to_f32((unsigned short)(a[c] >> 16)), dact);
           }
         }
         if (p.residual) {
@@ -275,8 +279,16 @@ extern "C" int clipk_gemm_nt_v2_launch(const clipk_gemm_args* a, void* stream) {
   } else {
     const int ntm = (a->M + 127) / 128;
     const int lds = 128 * BK * 2 + B_TILE_BYTES;
-    if (stages == 2) hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 2>), dim3(ntm * ntn), dim3(256), 2 * lds, st, p);
-    else hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1>), dim3(ntm * ntn), dim3(256), lds, st, p);
+    const dim3 grid(ntm * ntn), blk(256);
+    const bool has_dact = a->dact_aux != nullptr;
+    if (stages == 2) hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 2>), grid, blk, 2 * lds, st, p);
+    else if (a->act == CLIPK_ACT_GELU && !has_dact)
+      hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, CLIPK_ACT_GELU, CLIPK_ACT_NONE>), grid, blk, lds, st, p);
+    else if (a->act == CLIPK_ACT_NONE && has_dact && a->dact == CLIPK_ACT_GELU)
+      hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, CLIPK_ACT_NONE, CLIPK_ACT_GELU>), grid, blk, lds, st, p);
+    else if (a->act == CLIPK_ACT_NONE && !has_dact)
+      hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, CLIPK_ACT_NONE, CLIPK_ACT_NONE>), grid, blk, lds, st, p);
+    else hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1>), grid, blk, lds, st, p);
   }
   return clipk_check_launch();
 }
