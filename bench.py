@@ -86,8 +86,6 @@ def main():
     ap.add_argument("--seq-len", type=int, default=256)
     ap.add_argument("--esm", default="esm2_t12_35M_UR50D")
     ap.add_argument("--freeze-esm", action="store_true", help="reference behaviour (3_esm_integration.py:83-84)")
-    ap.add_argument("--residual", choices=["f32", "bf16"], default="f32",
-                    help="dtype of the forward residual stream (f32 = parity default; bf16 = less HBM traffic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     args = ap.parse_args()
@@ -109,9 +107,6 @@ def main():
     for m in model.modules():                             # training-step timing with dropout p = 0
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
-    if args.residual == "bf16":
-        model.protein_model.residual_dtype = torch.bfloat16
-        model.rna_model.residual_dtype = torch.bfloat16
     sd_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if rank == 0 else None
     opt = K.FusedAdamW(model, lr=1e-4, weight_decay=0.01, max_grad_norm=1.0, group=group)
     B, L = args.batch, args.seq_len
@@ -168,7 +163,7 @@ def main():
                                f"B={B} pairs/GPU, L={L}, full training step (fwd + fused InfoNCE + bwd + fused AdamW/clip), "
                                + ("ESM frozen" if args.freeze_esm else "both encoders trained"),
                    "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}",
-                   "projection_dim": 512, "residual_stream": args.residual},
+                   "projection_dim": 512},
         "loss": round(float(loss.item()), 5),
     }
     if timer is not None:

@@ -46,10 +46,10 @@ def _esm_layer_fwd(x, p, meta):
     _, h1, m1, r1 = ops.layernorm_fwd(x, p["ln1_w"], p["ln1_b"], eps, want_f32=False, want_bf16=True)
     qkv = ops.gemm_nt(h1, p["qkv"].wb, bias=p["qkv"].b)
     ctx, lse = ops.attn_fwd(qkv, B, L, H, D, key_mask=mask, rope=rope, q_scale=D ** -0.5)
-    x2 = ops.gemm_nt(ctx, p["out"].wb, bias=p["out"].b, residual=x, out_dtype=x.dtype)   # residual stream dtype = x's
+    x2 = ops.gemm_nt(ctx, p["out"].wb, bias=p["out"].b, residual=x, out_dtype=torch.float32)
     _, h2, m2, r2 = ops.layernorm_fwd(x2, p["ln2_w"], p["ln2_b"], eps, want_f32=False, want_bf16=True)
     g, u = ops.gemm_nt(h2, p["fc1"].wb, bias=p["fc1"].b, act="gelu", out_preact=True)
-    y = ops.gemm_nt(g, p["fc2"].wb, bias=p["fc2"].b, residual=x2, out_dtype=x.dtype)
+    y = ops.gemm_nt(g, p["fc2"].wb, bias=p["fc2"].b, residual=x2, out_dtype=torch.float32)
     return y, (x, h1, m1, r1, qkv, ctx, lse, x2, h2, m2, r2, g, u)
 
 
@@ -93,8 +93,6 @@ class EsmStackFn(torch.autograd.Function):
         meta = (B, L, H, D, mask_u8, rope, module.eps)
         x = ops.embed_fwd(ids, table, row_scale=row_scale, mask=mask_u8.view(-1) if mask_u8 is not None else None,
                           mask_token_id=module.mask_token_id if module.token_dropout else -1)
-        if module.residual_dtype == torch.bfloat16:      # opt-in: bf16 residual stream
-            x = ops.to_bf16(x)
         layers, saved = [], []
         for i in range(nl):
             t = flat[3 + 12 * i: 3 + 12 * (i + 1)]
@@ -201,7 +199,6 @@ class ESM2Encoder(nn.Module):
         self.embeddings = _EsmEmbeddings(vocab_size, hidden_size, pad_token_id)
         self.encoder = _EsmEncoderModules(num_layers, hidden_size, intermediate_size, layer_norm_eps)
         self.layer_caches = [[KF.WeightCache() for _ in range(4)] for _ in range(num_layers)]
-        self.residual_dtype = torch.float32      # torch.bfloat16 halves the residual-stream traffic (opt-in)
         self._rope = {}
         self._fused = None
         self._init(initializer_range)
@@ -266,21 +263,15 @@ def _post_layer_fwd(x, xb, p, meta):
     B, L, H, D, mask, act, eps, qs = meta
     qkv = ops.gemm_nt(xb, p["in"].wb, bias=p["in"].b)
     ctx, lse = ops.attn_fwd(qkv, B, L, H, D, key_mask=mask, rope=None, q_scale=qs)
-    lowp = xb is x                                           # bf16 residual stream: x IS its bf16 copy
-    rdt = torch.bfloat16 if lowp else torch.float32
-    s1 = ops.gemm_nt(ctx, p["out"].wb, bias=p["out"].b, residual=x, out_dtype=rdt)
-    x1, x1b, m1, r1 = ops.layernorm_fwd(s1, p["n1_w"], p["n1_b"], eps, want_f32=not lowp, want_bf16=True)
-    if lowp:
-        x1 = x1b
+    s1 = ops.gemm_nt(ctx, p["out"].wb, bias=p["out"].b, residual=x, out_dtype=torch.float32)
+    x1, x1b, m1, r1 = ops.layernorm_fwd(s1, p["n1_w"], p["n1_b"], eps, want_f32=True, want_bf16=True)
     if act == "gelu":
         g, u = ops.gemm_nt(x1b, p["fc1"].wb, bias=p["fc1"].b, act="gelu", out_preact=True)
     else:
         g = ops.gemm_nt(x1b, p["fc1"].wb, bias=p["fc1"].b, act="relu")
         u = g                                                   # relu'(pre) == relu'(relu(pre))
-    s2 = ops.gemm_nt(g, p["fc2"].wb, bias=p["fc2"].b, residual=x1, out_dtype=rdt)
-    y, yb, m2, r2 = ops.layernorm_fwd(s2, p["n2_w"], p["n2_b"], eps, want_f32=not lowp, want_bf16=True)
-    if lowp:
-        y = yb
+    s2 = ops.gemm_nt(g, p["fc2"].wb, bias=p["fc2"].b, residual=x1, out_dtype=torch.float32)
+    y, yb, m2, r2 = ops.layernorm_fwd(s2, p["n2_w"], p["n2_b"], eps, want_f32=True, want_bf16=True)
     return y, yb, (xb, qkv, ctx, lse, s1, x1b, m1, r1, g, u, s2, m2, r2)
 
 
@@ -316,8 +307,6 @@ class PostLNStackFn(torch.autograd.Function):
         meta = (B, L, H, D, mask_u8, module.activation, module.eps, float(E // H) ** -0.5)
         x = x.contiguous()
         xb = ops.to_bf16(x)
-        if module.residual_dtype == torch.bfloat16:
-            x = xb
         fin_w, fin_b = flat[0], flat[1]
         layers, saved = [], []
         for i in range(nl):
@@ -389,7 +378,6 @@ class TransformerSeqEncoder(nn.Module):
                                      for _ in range(num_layers)])
         self.layernorm = nn.LayerNorm(embed_dim, eps=self.final_eps)
         self.layer_caches = [[KF.WeightCache() for _ in range(4)] for _ in range(num_layers)]
-        self.residual_dtype = torch.float32      # torch.bfloat16: keep the (re-normalised) stream in bf16 (opt-in)
         hd = embed_dim // nhead
         self.head_dim_padded = (hd + 7) // 8 * 8          # kernels want head_dim % 8 == 0 (notebook: 120/8 = 15)
 

@@ -15,8 +15,7 @@ CASES = [
     ("tlayer_gelu", T.test_transformer_layer_golden, {"act": "gelu"}),
     ("notebook", T.test_notebook_model_golden, {}),
     ("esm_tiny", T.test_esm_tiny_golden, {}),
-    ("protein_rna", T.test_protein_rna_clip_vs_oracle, {"residual": "f32"}),
-    ("protein_rna_bf16res", T.test_protein_rna_clip_vs_oracle, {"residual": "bf16"}),
+    ("protein_rna", T.test_protein_rna_clip_vs_oracle, {}),
     ("adamw_train", T.test_fused_adamw_training_reduces_loss, {}),
     ("icnn", T.test_icnn_transport_golden, {}),
     ("esm_proj", T.test_esm_projections_golden, {}),
