@@ -34,8 +34,16 @@ struct Params {
   const void* residual; long ldr; int r_f32;
   float alpha;
   int ntn;
+  int nt;           // 1: non-temporal output stores
   int stagger;      // s_sleep(127) units (~3.4 us each) per quarter-phase, 0 = off
 };
+
+// output stores: optionally non-temporal (streamed once, keep the XCD's L2 for the operand panels)
+template <typename V>
+__device__ __forceinline__ void st_out(V* ptr, V v, int nt) {
+  if (nt) __builtin_nontemporal_store(v, ptr);
+  else *ptr = v;
+}
 
 __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(gptr, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
@@ -195,7 +203,7 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 ? 4 : 2)) void gemm_nt_v2_kern
           u32x4 o;
 #pragma unroll
           for (int c = 0; c < 4; ++c) o[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
-          *reinterpret_cast<u32x4*>(p.out_preact + (long)gm * p.ldp + gn) = o;
+          st_out(reinterpret_cast<u32x4*>(p.out_preact + (long)gm * p.ldp + gn), o, p.nt);
         }
         const int act = (ACT_T >= 0) ? ACT_T : p.act;
         const int dact = (DACT_T >= 0) ? DACT_T : p.dact;
@@ -230,13 +238,13 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 ? 4 : 2)) void gemm_nt_v2_kern
         }
         if (p.c_f32) {
           float* c = reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn;
-          *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<f32x4*>(c + 4) = f32x4{v[4], v[5], v[6], v[7]};
+          st_out(reinterpret_cast<f32x4*>(c), f32x4{v[0], v[1], v[2], v[3]}, p.nt);
+          st_out(reinterpret_cast<f32x4*>(c + 4), f32x4{v[4], v[5], v[6], v[7]}, p.nt);
         } else {
           u32x4 o;
 #pragma unroll
           for (int c = 0; c < 4; ++c) o[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
-          *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.C) + (long)gm * p.ldc + gn) = o;
+          st_out(reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.C) + (long)gm * p.ldc + gn), o, p.nt);
         }
       }
     }
@@ -260,6 +268,7 @@ extern "C" int clipk_gemm_nt_v2_launch(const clipk_gemm_args* a, void* stream) {
   const int ntn = (a->N + BN - 1) / BN;
   p.ntn = ntn;
   { const char* sg = getenv("CLIPK_GEMM_STAGGER"); p.stagger = sg ? atoi(sg) : 0; }
+  { const char* e = getenv("CLIPK_GEMM_NT"); p.nt = e ? atoi(e) : 0; }
   const char* force = getenv("CLIPK_GEMM_BM");             // A/B switch for tools/bench_kernels.py
   const bool big = force ? (atoi(force) == 256) : false;
   const char* fs = getenv("CLIPK_GEMM_STAGES");
