@@ -100,7 +100,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    group = dist.group.WORLD if world > 1 else None
+    force_dist = bool(os.environ.get("CLIPK_FORCE_DIST"))     # rehearse the RCCL code path with a 1-rank group
+    if force_dist and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    group = dist.group.WORLD if (world > 1 or force_dist) else None
 
     torch.manual_seed(0)                                  # identical weights on every rank
     model = K.ProteinRNACLIP(esm=args.esm, freeze_protein_encoder=args.freeze_esm).to(device).train()

@@ -13,6 +13,7 @@ summed across ranks afterwards by the optimiser's reduce-scatter.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -91,6 +92,6 @@ def clip_loss(a_embeds: torch.Tensor, b_embeds: torch.Tensor, logit_scale_exp: t
         w_row, w_col = (0.5, 0.5) if symmetric else (1.0, 0.0)
     if group is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         group = dist.group.WORLD
-    if group is not None and dist.get_world_size(group) == 1:
-        group = None
+    if group is not None and dist.get_world_size(group) == 1 and not os.environ.get("CLIPK_FORCE_DIST"):
+        group = None                         # (CLIPK_FORCE_DIST keeps the collective path for 1-rank RCCL rehearsals)
     return ClipLossFn.apply(a_embeds, b_embeds, logit_scale_exp, float(w_row), float(w_col), cache, group)

@@ -76,7 +76,7 @@ class FusedAdamW:
         dev = self.flat.data.device
         self.m = torch.zeros(self.shard, dtype=torch.float32, device=dev)
         self.v = torch.zeros(self.shard, dtype=torch.float32, device=dev)
-        self.gshard = torch.empty(self.shard, dtype=torch.float32, device=dev) if self.world > 1 else None
+        self.gshard = torch.empty(self.shard, dtype=torch.float32, device=dev) if group is not None else None
         self.norm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
 
     def zero_grad(self):
@@ -88,7 +88,7 @@ class FusedAdamW:
         self.step_count += 1
         lr = self.lr if lr is None else lr
         lo = self.rank * self.shard
-        if self.world > 1:
+        if self.gshard is not None:
             if dist.get_backend(self.group) == "gloo":
                 dist.all_reduce(self.flat.grad, group=self.group)
                 self.gshard.copy_(self.flat.grad[lo:lo + self.shard])
@@ -99,13 +99,13 @@ class FusedAdamW:
             g = self.flat.grad
         w = self.flat.data[lo:lo + self.shard]
         _kernels.sumsq(g, out=self.norm_sq)
-        if self.world > 1:
+        if self.group is not None:
             dist.all_reduce(self.norm_sq, group=self.group)
         clip = self.max_grad_norm is not None and self.max_grad_norm > 0
         _kernels.adamw_step(w, g, self.m, self.v, lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count,
                             grad_norm_sq=self.norm_sq if clip else None,
                             max_norm=self.max_grad_norm if clip else 0.0)
-        if self.world > 1:
+        if self.group is not None:
             dist.all_gather_into_tensor(self.flat.data, w.clone() if dist.get_backend(self.group) == "gloo" else w,
                                         group=self.group)
         KF.mark_weights_dirty()              # bf16 W / W^T copies are refreshed lazily at the next forward
