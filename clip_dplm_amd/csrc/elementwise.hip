@@ -127,14 +127,16 @@ __global__ void embed_fwd_kernel(const int64_t* ids, const float* table, const f
   }
 }
 
-// dtable[v,:] += sum over tokens with ids == v.  Per-block private [V][d] table in LDS (ds_add_f32),
-// then one global atomic per (block, v, column) — V*d*4 bytes must fit the LDS budget.
+// dtable[v,:] += sum over tokens with ids == v.  Per-block private [V][dc] table in LDS (ds_add_f32) for a chunk
+// of dc columns (blockIdx.y), then one global atomic per (block, v, column).
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* ids, const float* dx, const float* row_scale,
                                                         const uint8_t* mask, int mask_token_id, float* dtable,
-                                                        int B, int L, int d, int V) {
+                                                        int B, int L, int d, int V, int dc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* tab = reinterpret_cast<float*>(smem);
-  for (int i = threadIdx.x; i < V * d; i += blockDim.x) tab[i] = 0.f;
+  const int c0 = blockIdx.y * dc;
+  const int ncol = (c0 + dc <= d) ? dc : d - c0;
+  for (int i = threadIdx.x; i < V * dc; i += blockDim.x) tab[i] = 0.f;
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -146,12 +148,13 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* ids, cons
     if (mask && !mask[t]) sc = 0.f;
     if (id == mask_token_id) sc = 0.f;
     if (sc == 0.f) continue;
-    for (int c = lane; c < d; c += 64) atomicAdd(&tab[id * d + c], dx[t * d + c] * sc);
+    for (int c = lane; c < ncol; c += 64) atomicAdd(&tab[id * dc + c], dx[t * d + c0 + c] * sc);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < V * d; i += blockDim.x) {
-    const float v = tab[i];
-    if (v != 0.f) atomicAdd(&dtable[i], v);
+  for (int i = threadIdx.x; i < V * dc; i += blockDim.x) {
+    const int v = i / dc, c = i - v * dc;
+    const float val = tab[i];
+    if (c < ncol && val != 0.f) atomicAdd(&dtable[(long)v * d + c0 + c], val);
   }
 }
 
@@ -299,15 +302,16 @@ extern "C" int clipk_embed_fwd(const int64_t* ids, const float* table, const flo
 extern "C" int clipk_embed_bwd(const int64_t* ids, const float* dx, const float* row_scale, const uint8_t* mask,
                                int mask_token_id, float* dtable, int B, int L, int d, int V, void* stream) {
   if (!ids || !dx || !dtable || B <= 0 || L <= 0 || d <= 0 || V <= 0) return CLIPK_ERR_BAD_ARG;
-  const size_t lds = (size_t)V * d * sizeof(float);
-  if (lds > 144 * 1024) return CLIPK_ERR_UNSUPPORTED;
-  if (lds > 65536)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
+  int dc = (48 * 1024) / (V * (int)sizeof(float));           // columns per block so the private table is <= 48 KiB
+  dc &= ~3;
+  if (dc < 4) return CLIPK_ERR_UNSUPPORTED;                  // vocabulary too large for the LDS-table scheme
+  if (dc > d) dc = d;
+  const size_t lds = (size_t)V * dc * sizeof(float);
+  const int nchunks = (d + dc - 1) / dc;
   long waves = (long)B * L;
-  int blocks = (int)((waves + 3) / 4); if (blocks > 256) blocks = 256; if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, ids, dx, row_scale, mask,
-                     mask_token_id, dtable, B, L, d, V);
+  int blocks = (int)((waves + 3) / 4); if (blocks > 256 / nchunks + 1) blocks = 256 / nchunks + 1; if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks, nchunks), dim3(256), lds, (hipStream_t)stream, ids, dx, row_scale, mask,
+                     mask_token_id, dtable, B, L, d, V, dc);
   return clipk_check_launch();
 }
 

@@ -94,6 +94,7 @@ class EsmStackFn(torch.autograd.Function):
         x = ops.embed_fwd(ids, table, row_scale=row_scale, mask=mask_u8.view(-1) if mask_u8 is not None else None,
                           mask_token_id=module.mask_token_id if module.token_dropout else -1)
         layers, saved = [], []
+        need_bwd = any(ctx.needs_input_grad)        # frozen encoder (3_esm_integration.py:83-84): keep no activations
         for i in range(nl):
             t = flat[3 + 12 * i: 3 + 12 * (i + 1)]
             caches = module.layer_caches[i]
@@ -101,7 +102,7 @@ class EsmStackFn(torch.autograd.Function):
                  "ln2_w": t[6], "ln2_b": t[7], "fc1": _Lin(t[8], t[9], caches[2]), "fc2": _Lin(t[10], t[11], caches[3])}
             x, s = _esm_layer_fwd(x, p, meta)
             layers.append(p)
-            saved.append(s)
+            saved.append(s if need_bwd else None)
         y, _, mf, rf = ops.layernorm_fwd(x, fin_w, fin_b, module.eps, want_f32=True)
         ctx.module, ctx.meta, ctx.layers, ctx.saved = module, meta, layers, saved
         ctx.fin = (x, fin_w, mf, rf)
@@ -309,6 +310,7 @@ class PostLNStackFn(torch.autograd.Function):
         xb = ops.to_bf16(x)
         fin_w, fin_b = flat[0], flat[1]
         layers, saved = [], []
+        need_bwd = any(ctx.needs_input_grad)
         for i in range(nl):
             t = flat[2 + 12 * i: 2 + 12 * (i + 1)]
             c = module.layer_caches[i]
@@ -316,7 +318,7 @@ class PostLNStackFn(torch.autograd.Function):
                  "fc1": _Lin(t[6], t[7], c[2]), "fc2": _Lin(t[8], t[9], c[3]), "n2_w": t[10], "n2_b": t[11]}
             x, xb, s = _post_layer_fwd(x, xb, p, meta)
             layers.append(p)
-            saved.append(s)
+            saved.append(s if need_bwd else None)
         y, _, mf, rf = ops.layernorm_fwd(x, fin_w, fin_b, module.final_eps, want_f32=True)
         ctx.module, ctx.meta, ctx.layers, ctx.saved = module, meta, layers, saved
         ctx.fin = (x, fin_w, mf, rf)
