@@ -86,6 +86,9 @@ def main():
     ap.add_argument("--seq-len", type=int, default=256)
     ap.add_argument("--esm", default="esm2_t12_35M_UR50D")
     ap.add_argument("--freeze-esm", action="store_true", help="reference behaviour (3_esm_integration.py:83-84)")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="enqueue both encoder towers on one HIP stream (default: one stream per tower)")
+    ap.add_argument("--wgrad-stream", action="store_true", help="weight-gradient GEMMs on a side stream per tower")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     args = ap.parse_args()
@@ -112,6 +115,9 @@ def main():
     for m in model.modules():                             # training-step timing with dropout p = 0
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
+    model.dual_stream = not args.single_stream
+    import clip_dplm_amd.encoders as _enc
+    _enc.WGRAD_SIDE_STREAM = args.wgrad_stream
     sd_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if rank == 0 else None
     opt = K.FusedAdamW(model, lr=1e-4, weight_decay=0.01, max_grad_norm=1.0, group=group)
     B, L = args.batch, args.seq_len
@@ -168,7 +174,7 @@ def main():
                                f"B={B} pairs/GPU, L={L}, full training step (fwd + fused InfoNCE + bwd + fused AdamW/clip), "
                                + ("ESM frozen" if args.freeze_esm else "both encoders trained"),
                    "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}",
-                   "projection_dim": 512},
+                   "projection_dim": 512, "hip_streams": 1 if args.single_stream else 2},
         "loss": round(float(loss.item()), 5),
     }
     if timer is not None:

@@ -29,6 +29,41 @@ def _rope_tables(L: int, hd: int, device, theta: float = 10000.0):
     return fr.cos().contiguous().to(device), fr.sin().contiguous().to(device)
 
 
+# Weight-gradient GEMMs are off the backward's critical path (only the optimiser consumes them), so they can run on
+# a side HIP stream next to the dgrad / attention / LayerNorm chain of the same tower.  Off unless enabled.
+WGRAD_SIDE_STREAM = False
+_SIDE = {}
+
+
+def _wgrad(dy, x):
+    """dW, db = wgrad(dy, x), optionally enqueued on the calling stream's side stream."""
+    if not (WGRAD_SIDE_STREAM and dy.is_cuda):
+        return ops.gemm_wgrad(dy, x, want_bias=True)
+    cur = torch.cuda.current_stream()
+    side = _SIDE.get(cur.cuda_stream)
+    if side is None:
+        side = _SIDE[cur.cuda_stream] = torch.cuda.Stream()
+    side.wait_event(cur.record_event())            # dy / x are ready at this point of the calling stream
+    with torch.cuda.stream(side):
+        dw, db = ops.gemm_wgrad(dy, x, want_bias=True)
+    dy.record_stream(side)
+    x.record_stream(side)
+    return dw, db
+
+
+def _join_side(*tensors):
+    """Make the calling stream wait for its side stream (end of a stack's backward)."""
+    if not WGRAD_SIDE_STREAM:
+        return
+    cur = torch.cuda.current_stream()
+    side = _SIDE.get(cur.cuda_stream)
+    if side is not None:
+        cur.wait_stream(side)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(cur)
+
+
 class _Lin:
     """Kernel-side view of one Linear: f32 master params + cached bf16 W / W^T."""
 
@@ -61,16 +96,16 @@ def _esm_layer_bwd(dy, dyb, p, saved, meta, need_dx_bf16):
         dyb = ops.to_bf16(dy)
     gr = {}
     du = ops.gemm_nt(dyb, p["fc2"].wtb, dact_aux=u, dact="gelu")               # dgrad fused with GELU'
-    gr["fc2_w"], gr["fc2_b"] = ops.gemm_wgrad(dyb, g, want_bias=True)
+    gr["fc2_w"], gr["fc2_b"] = _wgrad(dyb, g)
     dh2 = ops.gemm_nt(du, p["fc1"].wtb)
-    gr["fc1_w"], gr["fc1_b"] = ops.gemm_wgrad(du, h2, want_bias=True)
+    gr["fc1_w"], gr["fc1_b"] = _wgrad(du, h2)
     dx2, dx2b, gr["ln2_w"], gr["ln2_b"] = ops.layernorm_bwd(dh2, x2, p["ln2_w"], None, m2, r2, dx_add=dy,
                                                             want_f32=True, want_bf16=True)
     dctx = ops.gemm_nt(dx2b, p["out"].wtb)
-    gr["out_w"], gr["out_b"] = ops.gemm_wgrad(dx2b, ctx, want_bias=True)
+    gr["out_w"], gr["out_b"] = _wgrad(dx2b, ctx)
     dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, H, D, key_mask=mask, rope=rope, q_scale=D ** -0.5)
     dh1 = ops.gemm_nt(dqkv, p["qkv"].wtb)
-    gr["qkv_w"], gr["qkv_b"] = ops.gemm_wgrad(dqkv, h1, want_bias=True)
+    gr["qkv_w"], gr["qkv_b"] = _wgrad(dqkv, h1)
     dx, dxb, gr["ln1_w"], gr["ln1_b"] = ops.layernorm_bwd(dh1, x, p["ln1_w"], None, m1, r1, dx_add=dx2,
                                                           want_f32=True, want_bf16=need_dx_bf16)
     return dx, dxb, gr
@@ -131,6 +166,7 @@ class EsmStackFn(torch.autograd.Function):
                           mask_token_id=module.mask_token_id if module.token_dropout else -1)
             grads[0] = dtable
         ctx.layers = ctx.saved = None
+        _join_side(*grads)
         return (None, None, None, None, *grads)
 
 
@@ -282,15 +318,15 @@ def _post_layer_bwd(dy, p, saved, meta):
     gr = {}
     ds2, ds2b, gr["n2_w"], gr["n2_b"] = ops.layernorm_bwd(dy, s2, p["n2_w"], None, m2, r2, want_f32=True, want_bf16=True)
     du = ops.gemm_nt(ds2b, p["fc2"].wtb, dact_aux=u, dact=act)
-    gr["fc2_w"], gr["fc2_b"] = ops.gemm_wgrad(ds2b, g, want_bias=True)
+    gr["fc2_w"], gr["fc2_b"] = _wgrad(ds2b, g)
     dx1 = ops.gemm_nt(du, p["fc1"].wtb, residual=ds2, out_dtype=torch.float32)      # + residual-path gradient
-    gr["fc1_w"], gr["fc1_b"] = ops.gemm_wgrad(du, x1b, want_bias=True)
+    gr["fc1_w"], gr["fc1_b"] = _wgrad(du, x1b)
     ds1, ds1b, gr["n1_w"], gr["n1_b"] = ops.layernorm_bwd(dx1, s1, p["n1_w"], None, m1, r1, want_f32=True, want_bf16=True)
     dctx = ops.gemm_nt(ds1b, p["out"].wtb)
-    gr["out_w"], gr["out_b"] = ops.gemm_wgrad(ds1b, ctx, want_bias=True)
+    gr["out_w"], gr["out_b"] = _wgrad(ds1b, ctx)
     dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, H, D, key_mask=mask, rope=None, q_scale=qs)
     dx = ops.gemm_nt(dqkv, p["in"].wtb, residual=ds1, out_dtype=torch.float32)
-    gr["in_w"], gr["in_b"] = ops.gemm_wgrad(dqkv, xb, want_bias=True)
+    gr["in_w"], gr["in_b"] = _wgrad(dqkv, xb)
     return dx, gr
 
 
@@ -337,6 +373,7 @@ class PostLNStackFn(torch.autograd.Function):
             for j, k in enumerate(_POST_KEYS):
                 grads[2 + 12 * i + j] = gr[k]
         ctx.layers = ctx.saved = None
+        _join_side(*grads)
         return (None, dx if ctx.needs_input_grad[1] else None, None, None, None, *grads)
 
 

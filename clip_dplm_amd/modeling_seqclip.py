@@ -91,17 +91,43 @@ class ProteinRNACLIP(nn.Module):
                                                  hidden_dim=projection_dim * 2)
         self.logit_scale = nn.Parameter(torch.ones([]) * logit_scale_init_value)
         self.pooling = pooling
+        self.dual_stream = False           # opt-in: enqueue the two towers on separate HIP streams
+        self._streams = None
         if freeze_protein_encoder:                       # triple_flow/3_esm_integration.py:83-84
             for p in self.protein_model.parameters():
                 p.requires_grad_(False)
 
-    def embed(self, rna_values, protein_ids, rna_mask=None, protein_mask=None):
-        """rna_values [B, Lr, rna_dim] f32; protein_ids [B, Lp] int64; masks [B, L] with 1 = valid."""
+    def _embed_rna(self, rna_values, rna_mask):
         hr = self.rna_model(rna_values, src_key_padding_mask=None if rna_mask is None else ~rna_mask.bool())
+        return KF.l2_normalize(self.rna_projection(pool(hr, rna_mask, self.pooling)))
+
+    def _embed_protein(self, protein_ids, protein_mask):
         hp = self.protein_model(protein_ids, attention_mask=protein_mask)
-        er = self.rna_projection(pool(hr, rna_mask, self.pooling))
-        ep = self.protein_projection(pool(hp, protein_mask, self.pooling))
-        return KF.l2_normalize(er), KF.l2_normalize(ep)
+        return KF.l2_normalize(self.protein_projection(pool(hp, protein_mask, self.pooling)))
+
+    def embed(self, rna_values, protein_ids, rna_mask=None, protein_mask=None):
+        """rna_values [B, Lr, rna_dim] f32; protein_ids [B, Lp] int64; masks [B, L] with 1 = valid.
+
+        The two towers are independent until the loss, so they are enqueued on two HIP streams: the memory-bound
+        kernels of one tower (LayerNorm, attention, GEMM epilogues) overlap the MFMA-bound phases of the other, in the
+        forward and — because autograd replays each node on its forward stream — in the backward."""
+        if not (self.dual_stream and rna_values.is_cuda):
+            return self._embed_rna(rna_values, rna_mask), self._embed_protein(protein_ids, protein_mask)
+        main = torch.cuda.current_stream()
+        if self._streams is None:
+            self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        s1, s2 = self._streams
+        s1.wait_stream(main)
+        s2.wait_stream(main)
+        with torch.cuda.stream(s1):
+            er = self._embed_rna(rna_values, rna_mask)
+        with torch.cuda.stream(s2):
+            ep = self._embed_protein(protein_ids, protein_mask)
+        main.wait_stream(s1)
+        main.wait_stream(s2)
+        er.record_stream(main)
+        ep.record_stream(main)
+        return er, ep
 
     def forward(self, rna_values, protein_ids, rna_mask=None, protein_mask=None):
         er, ep = self.embed(rna_values, protein_ids, rna_mask, protein_mask)
