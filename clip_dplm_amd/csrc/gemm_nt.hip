@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 extern "C" int clipk_gemm_nt_v2_launch(const clipk_gemm_args* a, void* stream);
+extern "C" int clipk_gemm_nt_v3_launch(const clipk_gemm_args* a, void* stream);
 
 namespace {
 
@@ -223,6 +224,8 @@ extern "C" int clipk_gemm_nt(const clipk_gemm_args* a, void* stream) {
   if (a->residual && (!aligned16(a->residual) || (a->ldr & 7))) return CLIPK_ERR_BAD_ARG;
   // fast path: LDS-DMA staged, 4 workgroups per CU (gemm_nt_v2.hip); needs whole 32-deep K steps
   const bool force_v1 = getenv("CLIPK_GEMM_V1") != nullptr;     // A/B switch for tools/bench_kernels.py
+  const char* v3 = getenv("CLIPK_GEMM_V3");                      // 256x256-tile kernel: A/B switch
+  if (!force_v1 && (a->K & 31) == 0 && v3 && atoi(v3) == 1 && a->M >= 2048) return clipk_gemm_nt_v3_launch(a, stream);
   if (!force_v1 && (a->K & 31) == 0) return clipk_gemm_nt_v2_launch(a, stream);
   Params p;
   p.A = (const unsigned short*)a->A; p.lda = a->lda;

@@ -50,7 +50,7 @@ GEMM_SHAPES = [  # (name, M, N, K, epilogue)
 
 
 def bench_gemm():
-    print(f"{'shape':12s} {'M':>7s} {'N':>5s} {'K':>5s} {'epi':9s} | plain st us TF/s | nt store us TF/s | ratio")
+    print(f"{'shape':12s} {'M':>7s} {'N':>5s} {'K':>5s} {'epi':9s} | v2 128^2 us TF/s | v3 256^2 us TF/s | ratio")
     tot = {"v1": 0.0, "v2": 0.0}
     for name, M, N, K, epi in GEMM_SHAPES:
         a, b = rnd((M, K)), rnd((N, K), scale=0.05)
@@ -64,7 +64,7 @@ def bench_gemm():
             kw = {"dact_aux": rnd((M, N)), "dact": "gelu"}
         out = {}
         for ver in ("v1", "v2"):
-            os.environ["CLIPK_GEMM_NT"] = "0" if ver == "v1" else "1"
+            os.environ["CLIPK_GEMM_V3"] = "0" if ver == "v1" else "1"
             med, mn = timeit(lambda: ops.gemm_nt(a, b, **kw))
             out[ver] = med
             tot[ver] += med
@@ -72,7 +72,7 @@ def bench_gemm():
         print(f"{name:12s} {M:7d} {N:5d} {K:5d} {epi:9s} | {out['v1'] * 1e3:7.1f} {fl / out['v1'] / 1e9:6.0f} | "
               f"{out['v2'] * 1e3:7.1f} {fl / out['v2'] / 1e9:6.0f} | {out['v1'] / out['v2']:.2f}x")
         del a, b, kw
-    os.environ.pop("CLIPK_GEMM_NT", None)
+    os.environ.pop("CLIPK_GEMM_V3", None)
     print(f"sum: bm128 {tot['v1']:.2f} ms, bm256 {tot['v2']:.2f} ms")
 
 
