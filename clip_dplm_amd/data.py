@@ -1,0 +1,34 @@
+"""Input format of the notebook pipeline: per-sequence [L_i, D] float arrays, NaN-padded into
+[B, L_max, D] batches whose padding is recovered as a mask.  Host-side mirror of
+current/rna_clip_codes.ipynb:1800-1857 (RNARBPDataset, collate_fn, create_padding_mask): same names / behaviour.
+Pure data plumbing (no arithmetic on the path), so it is ordinary PyTorch host code."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch.nn.utils.rnn import pad_sequence
+from torch.utils.data import Dataset
+
+from .modeling_seqclip import create_padding_mask  # noqa: F401  (re-export, same name as the notebook)
+
+
+class RNARBPDataset(Dataset):
+    """rna_clip_codes.ipynb:1806-1822: lists/arrays of per-sample [seq_len, emb_dim] embeddings."""
+
+    def __init__(self, rna_embeddings, rbp_embeddings):
+        self.rna_embeddings = rna_embeddings
+        self.rbp_embeddings = rbp_embeddings
+
+    def __len__(self):
+        return len(self.rna_embeddings)
+
+    def __getitem__(self, idx):
+        return (torch.from_numpy(np.asarray(self.rna_embeddings[idx])).float(),
+                torch.from_numpy(np.asarray(self.rbp_embeddings[idx])).float())
+
+
+def collate_fn(batch):
+    """rna_clip_codes.ipynb:1824-1838: pad both modalities to the batch maximum with NaN (masked later)."""
+    rna_embs, rbp_embs = zip(*batch)
+    return (pad_sequence(rna_embs, batch_first=True, padding_value=float("nan")),
+            pad_sequence(rbp_embs, batch_first=True, padding_value=float("nan")))

@@ -95,3 +95,14 @@ def clip_loss(a_embeds: torch.Tensor, b_embeds: torch.Tensor, logit_scale_exp: t
     if group is not None and dist.get_world_size(group) == 1 and not os.environ.get("CLIPK_FORCE_DIST"):
         group = None                         # (CLIPK_FORCE_DIST keeps the collective path for 1-rank RCCL rehearsals)
     return ClipLossFn.apply(a_embeds, b_embeds, logit_scale_exp, float(w_row), float(w_col), cache, group)
+
+
+def tri_modal_loss(cell_embed: torch.Tensor, pert_embed: torch.Tensor, protein_embed: torch.Tensor,
+                   logit_scale_exp: torch.Tensor, group=None):
+    """Tri-modal contrastive objective of current/tf_clip_codes (1).ipynb:13150-13176: three pairwise symmetric
+    InfoNCE losses sharing one logit_scale, each on the fused similarity + CE kernels (no B x B logits).
+    Returns the dict of the reference's ContrastiveModel.forward (loss terms only)."""
+    cp = clip_loss(cell_embed, pert_embed, logit_scale_exp, symmetric=True, group=group)
+    ce = clip_loss(cell_embed, protein_embed, logit_scale_exp, symmetric=True, group=group)
+    pe = clip_loss(pert_embed, protein_embed, logit_scale_exp, symmetric=True, group=group)
+    return {"loss": cp + ce + pe, "cell_pert_loss": cp, "cell_protein_loss": ce, "pert_protein_loss": pe}

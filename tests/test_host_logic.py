@@ -117,3 +117,22 @@ def test_fused_adamw_matches_torch(monkeypatch):
         torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0); topt.step()
     for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
         assert torch.allclose(p, q, rtol=1e-4, atol=1e-5), n
+
+
+def test_tri_modal_loss_and_collate(monkeypatch):
+    ops_emulator.install(monkeypatch)
+    from clip_dplm_amd.data import RNARBPDataset, collate_fn, create_padding_mask
+    from clip_dplm_amd.loss import tri_modal_loss
+    g = torch.Generator().manual_seed(0)
+    embs = [clip_ref.l2_normalize(torch.randn(20, 16, generator=g)) for _ in range(3)]
+    s = torch.tensor(14.2857)
+    out = tri_modal_loss(*embs, s)
+    ref = sum(clip_ref.clip_loss_symmetric((a @ b.t()) * s) for a, b in ((embs[0], embs[1]), (embs[0], embs[2]), (embs[1], embs[2])))
+    assert abs(out["loss"].item() - ref.item()) < 1e-5
+    assert set(out) == {"loss", "cell_pert_loss", "cell_protein_loss", "pert_protein_loss"}
+    ds = RNARBPDataset([np.ones((3, 4), np.float32), np.ones((5, 4), np.float32)],
+                       [np.ones((7, 6), np.float32), np.ones((2, 6), np.float32)])
+    rna, rbp = collate_fn([ds[0], ds[1]])
+    assert rna.shape == (2, 5, 4) and rbp.shape == (2, 7, 6)
+    assert create_padding_mask(rna).tolist() == [[True] * 3 + [False] * 2, [True] * 5]
+    assert torch.isnan(rbp[1, 2:]).all()
