@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--freeze-esm", action="store_true", help="reference behaviour (3_esm_integration.py:83-84)")
     ap.add_argument("--single-stream", action="store_true",
                     help="enqueue both encoder towers on one HIP stream (default: one stream per tower)")
+    ap.add_argument("--micro-batches", type=int, default=1, help="stream pairs per step (batch split over them)")
     ap.add_argument("--wgrad-stream", action="store_true", help="weight-gradient GEMMs on a side stream per tower")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
@@ -116,6 +117,7 @@ def main():
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
     model.dual_stream = not args.single_stream
+    model.micro_batches = args.micro_batches
     import clip_dplm_amd.encoders as _enc
     _enc.WGRAD_SIDE_STREAM = args.wgrad_stream
     sd_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if rank == 0 else None

@@ -144,13 +144,25 @@ class HybridCLIPConfig:
         return cls(**d)
 
     def create_experiment_config(self, experiment_type: str, **override_kwargs) -> "HybridCLIPConfig":
-        config = copy.deepcopy(self)
-        if experiment_type == "embedding_sweep":
-            config.projection_dim = override_kwargs.get("projection_dim", self.projection_dim)
-            config.embedding_dim = override_kwargs.get("embedding_dim", self.embedding_dim)
-        elif experiment_type == "architecture_search":
-            arch_type = override_kwargs.get("architecture_type", "mlp")
-            config.architectures[arch_type] = ModelArchitectureConfig(**override_kwargs.get("architecture_config", {}))
-        elif experiment_type == "training_sweep":
-            config.training = TrainingConfig(**{**asdict(self.training), **override_kwargs})
-        return config
+        """Derived config for one experiment family (same three families and override keys as the reference's
+        create_experiment_config, run1/configuration_hybrid_clip.py:195-218); unknown families return a plain copy."""
+        derived = copy.deepcopy(self)
+
+        def _embedding_sweep(c):
+            for key in ("projection_dim", "embedding_dim"):
+                setattr(c, key, override_kwargs.get(key, getattr(self, key)))
+
+        def _architecture_search(c):
+            name = override_kwargs.get("architecture_type", "mlp")
+            c.architectures[name] = ModelArchitectureConfig(**override_kwargs.get("architecture_config", {}))
+
+        def _training_sweep(c):
+            merged = asdict(self.training)
+            merged.update(override_kwargs)
+            c.training = TrainingConfig(**merged)
+
+        handlers = {"embedding_sweep": _embedding_sweep, "architecture_search": _architecture_search,
+                    "training_sweep": _training_sweep}
+        if experiment_type in handlers:
+            handlers[experiment_type](derived)
+        return derived

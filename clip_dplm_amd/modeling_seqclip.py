@@ -92,6 +92,7 @@ class ProteinRNACLIP(nn.Module):
         self.logit_scale = nn.Parameter(torch.ones([]) * logit_scale_init_value)
         self.pooling = pooling
         self.dual_stream = False           # opt-in: enqueue the two towers on separate HIP streams
+        self.micro_batches = 1             # with dual_stream: split the batch into this many stream pairs
         self._streams = None
         if freeze_protein_encoder:                       # triple_flow/3_esm_integration.py:83-84
             for p in self.protein_model.parameters():
@@ -114,19 +115,27 @@ class ProteinRNACLIP(nn.Module):
         if not (self.dual_stream and rna_values.is_cuda):
             return self._embed_rna(rna_values, rna_mask), self._embed_protein(protein_ids, protein_mask)
         main = torch.cuda.current_stream()
-        if self._streams is None:
-            self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
-        s1, s2 = self._streams
-        s1.wait_stream(main)
-        s2.wait_stream(main)
-        with torch.cuda.stream(s1):
-            er = self._embed_rna(rna_values, rna_mask)
-        with torch.cuda.stream(s2):
-            ep = self._embed_protein(protein_ids, protein_mask)
-        main.wait_stream(s1)
-        main.wait_stream(s2)
-        er.record_stream(main)
-        ep.record_stream(main)
+        nmb = max(1, int(self.micro_batches))
+        if self._streams is None or len(self._streams) != 2 * nmb:
+            self._streams = tuple(torch.cuda.Stream() for _ in range(2 * nmb))
+        B = rna_values.shape[0]
+        cuts = [(i * B) // nmb for i in range(nmb + 1)]
+        ers, eps = [], []
+        for i in range(nmb):                      # samples are independent up to the loss: micro-batches on own streams
+            lo, hi = cuts[i], cuts[i + 1]
+            s1, s2 = self._streams[2 * i], self._streams[2 * i + 1]
+            s1.wait_stream(main)
+            s2.wait_stream(main)
+            with torch.cuda.stream(s1):
+                ers.append(self._embed_rna(rna_values[lo:hi], None if rna_mask is None else rna_mask[lo:hi]))
+            with torch.cuda.stream(s2):
+                eps.append(self._embed_protein(protein_ids[lo:hi], None if protein_mask is None else protein_mask[lo:hi]))
+        for s in self._streams:
+            main.wait_stream(s)
+        for t in ers + eps:
+            t.record_stream(main)
+        er = ers[0] if nmb == 1 else torch.cat(ers, 0)
+        ep = eps[0] if nmb == 1 else torch.cat(eps, 0)
         return er, ep
 
     def forward(self, rna_values, protein_ids, rna_mask=None, protein_mask=None):
