@@ -10,7 +10,7 @@ LIB := clip_dplm_amd/lib/libclipk.so
 
 all: $(LIB)
 
-build/%.o: clip_dplm_amd/csrc/%.hip clip_dplm_amd/csrc/common.h include/clipk.h
+build/%.o: clip_dplm_amd/csrc/%.hip clip_dplm_amd/csrc/common.h clip_dplm_amd/csrc/gemm_epilogue.h include/clipk.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

@@ -1,0 +1,236 @@
+// gemm_epilogue.h — epilogue shared by the clipk_gemm_nt kernels (gemm_nt_v2.hip, gemm_nt_v3.hip).
+//
+// Each wave owns a [16*NJ m][64 n] block of the output as accumulators acc[n-tile i][m-tile j] (swapped operand
+// roles: lane holds rows n = 16i + 4g + r of column m = 16j + (lane & 15)).  One 16-row m-tile at a time goes through a
+// wave-private LDS slab [16 m][64 n (+4)] f32 so that every lane then owns 8 consecutive columns of one row and all
+// global accesses are 16 / 32 bytes per lane.
+//
+// The hot argument combinations are compile-time MODEs with a STRAIGHT-LINE body: on gfx9 loads and stores share
+// the vmcnt counter, and with run-time `if (p.residual)` / `if (gm < M)` branches hipcc falls back to
+// `s_waitcnt vmcnt(0)` in every half-iteration, i.e. each 8-row slice waits for the previous slice's stores to
+// reach memory.  In the specialised modes the operand loads (residual, GELU' argument) are issued one slice ahead
+// of their use with clamped addresses, only the stores are predicated, and the compiler's counted vmcnt(N) leaves
+// the stores in flight.
+#pragma once
+#include "common.h"
+
+struct EpiArgs {
+  void* C; long ldc; int c_f32;
+  int M, N;
+  const float* bias;
+  int act;
+  unsigned short* out_preact; long ldp;
+  const unsigned short* dact_aux; long ldd; int dact;
+  const void* residual; long ldr; int r_f32;
+  float alpha;
+};
+
+enum {
+  EPI_GENERIC = -1,   // everything decided at run time
+  EPI_PLAIN = 0,      // bf16 out (+bias)
+  EPI_RES32 = 1,      // f32 out = acc (+bias) + f32 residual
+  EPI_GELU_PRE = 2,   // bf16 pre-activation out and bf16 GELU out (+bias)
+  EPI_DGELU = 3,      // bf16 out = acc * GELU'(aux)
+};
+
+// which specialised mode (if any) matches a request
+static inline int epi_mode_for(const clipk_gemm_args* a) {
+  const bool c_f32 = a->c_dtype == CLIPK_F32, has_res = a->residual != nullptr, has_aux = a->dact_aux != nullptr;
+  const bool has_pre = a->out_preact != nullptr;
+  const long lim = 0x7fffffffL;                          // buffer-descriptor stores: byte extents must stay < 2 GiB
+  if (((long)(a->M - 1) * a->ldc + a->N) * (c_f32 ? 4 : 2) > lim) return EPI_GENERIC;
+  if (has_pre && ((long)(a->M - 1) * a->ldp + a->N) * 2 > lim) return EPI_GENERIC;
+  if (a->act == CLIPK_ACT_NONE && !has_aux && !has_res && !has_pre && !c_f32) return EPI_PLAIN;
+  if (a->act == CLIPK_ACT_NONE && !has_aux && has_res && a->r_dtype == CLIPK_F32 && !has_pre && c_f32) return EPI_RES32;
+  if (a->act == CLIPK_ACT_GELU && !has_aux && !has_res && has_pre && !c_f32) return EPI_GELU_PRE;
+  if (a->act == CLIPK_ACT_NONE && has_aux && a->dact == CLIPK_ACT_GELU && !has_res && !has_pre && !c_f32) return EPI_DGELU;
+  return EPI_GENERIC;
+}
+
+constexpr int EPI_LD = 68;                              // f32 per staged row (16 rows x 64 cols per wave + pad)
+
+// eb: wave-private slab (16 * EPI_LD floats); mbase: first output row of this wave; gn: this lane's first column
+template <int MODE, int NJ>
+__device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][NJ], float* eb, int lane, int mbase,
+                                              int gn) {
+  const int M = p.M, N = p.N;
+  const float alpha = p.alpha;
+  const int g = lane >> 4, li = lane & 15;
+  const int ecol = (lane & 7) * 8;
+  float bv[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) bv[c] = 0.f;
+  if (p.bias && gn < N) {
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + gn);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + gn + 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { bv[c] = b0[c]; bv[4 + c] = b1[c]; }
+  }
+
+  if constexpr (MODE != EPI_GENERIC) {
+    // retire the bias loads here, outside the slice loop, so no load is pending on any path into it
+#pragma unroll
+    for (int c = 0; c < 8; ++c) asm volatile("" ::"v"(bv[c]));
+    const bool col_ok = gn < N;
+    const long gnc = col_ok ? gn : 0;
+    // stores go through buffer descriptors: an out-of-range lane gets an offset past num_records and the hardware
+    // drops its store, so the slice loop has no exec-masked blocks at all (epi_mode_for keeps the extents < 2 GiB)
+    constexpr unsigned OOB = 0x80000000u;
+    const int c_elt = (MODE == EPI_RES32) ? 4 : 2;
+    const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(((long)(M - 1) * p.ldc + N) * c_elt), 0x00020000);
+    const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        MODE == EPI_GELU_PRE ? (void*)p.out_preact : p.C, 0,
+        MODE == EPI_GELU_PRE ? (int)(((long)(M - 1) * p.ldp + N) * 2) : 0, 0x00020000);
+    constexpr int S = 2 * NJ;
+    f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f};       // residual of the current slice
+    u32x4 ax = {0u, 0u, 0u, 0u};                                       // GELU' argument of the current slice
+    auto row_of = [&](int s) { return mbase + (s >> 1) * 16 + (s & 1) * 8 + (lane >> 3); };
+    auto fetch = [&](int s, f32x4& a0, f32x4& a1, u32x4& b) {
+      int gm = row_of(s);
+      gm = gm < M ? gm : M - 1;
+      if constexpr (MODE == EPI_RES32) {
+        const float* r = reinterpret_cast<const float*>(p.residual) + (long)gm * p.ldr + gnc;
+        a0 = *reinterpret_cast<const f32x4*>(r);
+        a1 = *reinterpret_cast<const f32x4*>(r + 4);
+      }
+      if constexpr (MODE == EPI_DGELU) b = *reinterpret_cast<const u32x4*>(p.dact_aux + (long)gm * p.ldd + gnc);
+    };
+    fetch(0, r0, r1, ax);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int j = s >> 1;
+      if ((s & 1) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(eb + li * EPI_LD + i * 16 + 4 * g) = acc[i][j] * alpha;
+      }
+      f32x4 n0 = r0, n1 = r1;
+      u32x4 nx = ax;
+      if (s + 1 < S) fetch(s + 1, n0, n1, nx);                         // one slice ahead of its use
+      const int row = (s & 1) * 8 + (lane >> 3);
+      const int gm = row_of(s);
+      float v[8];
+      {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(eb + row * EPI_LD + ecol);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(eb + row * EPI_LD + ecol + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { v[c] = v0[c] + bv[c]; v[4 + c] = v1[c] + bv[4 + c]; }
+      }
+      const bool ok = col_ok && gm < M;
+      if constexpr (MODE == EPI_PLAIN) {
+        u32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
+        const unsigned off = ok ? (unsigned)(((long)gm * p.ldc + gn) * 2) : OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(o, c_rsrc, off, 0, 0);
+      } else if constexpr (MODE == EPI_RES32) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { v[c] += r0[c]; v[4 + c] += r1[c]; }
+        const unsigned off = ok ? (unsigned)(((long)gm * p.ldc + gn) * 4) : OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
+                                                     __float_as_uint(v[3])}, c_rsrc, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]),
+                                                     __float_as_uint(v[7])}, c_rsrc, off + 16, 0, 0);
+      } else if constexpr (MODE == EPI_GELU_PRE) {
+        u32x4 u, o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) u[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = gelu_erf(v[c]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
+        const unsigned offu = ok ? (unsigned)(((long)gm * p.ldp + gn) * 2) : OOB;
+        const unsigned off = ok ? (unsigned)(((long)gm * p.ldc + gn) * 2) : OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(u, u_rsrc, offu, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o, c_rsrc, off, 0, 0);
+      } else {  // EPI_DGELU
+        u32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          v[2 * c] *= gelu_erf_grad(bf16_to_f32((unsigned short)(ax[c] & 0xffffu)));
+          v[2 * c + 1] *= gelu_erf_grad(bf16_to_f32((unsigned short)(ax[c] >> 16)));
+          o[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
+        }
+        const unsigned off = ok ? (unsigned)(((long)gm * p.ldc + gn) * 2) : OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(o, c_rsrc, off, 0, 0);
+      }
+      r0 = n0; r1 = n1; ax = nx;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(eb + li * EPI_LD + i * 16 + 4 * g) = acc[i][j] * alpha;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int row = half * 8 + (lane >> 3);
+        const int gm = mbase + j * 16 + row;
+        float v[8];
+        {
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(eb + row * EPI_LD + ecol);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(eb + row * EPI_LD + ecol + 4);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { v[c] = v0[c] + bv[c]; v[4 + c] = v1[c] + bv[4 + c]; }
+        }
+        if (gm < M && gn < N) {
+          if (p.out_preact) {
+            u32x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
+            *reinterpret_cast<u32x4*>(p.out_preact + (long)gm * p.ldp + gn) = o;
+          }
+          if (p.act != CLIPK_ACT_NONE) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = act_apply(v[c], p.act);
+          }
+          if (p.dact_aux) {
+            const u32x4 a = *reinterpret_cast<const u32x4*>(p.dact_aux + (long)gm * p.ldd + gn);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              v[2 * c] *= act_grad(bf16_to_f32((unsigned short)(a[c] & 0xffffu)), p.dact);
+              v[2 * c + 1] *= act_grad(bf16_to_f32((unsigned short)(a[c] >> 16)), p.dact);
+            }
+          }
+          if (p.residual) {
+            if (p.r_f32) {
+              const float* r = reinterpret_cast<const float*>(p.residual) + (long)gm * p.ldr + gn;
+              const f32x4 q0 = *reinterpret_cast<const f32x4*>(r);
+              const f32x4 q1 = *reinterpret_cast<const f32x4*>(r + 4);
+#pragma unroll
+              for (int c = 0; c < 4; ++c) { v[c] += q0[c]; v[4 + c] += q1[c]; }
+            } else {
+              const u32x4 a = *reinterpret_cast<const u32x4*>(
+                  reinterpret_cast<const unsigned short*>(p.residual) + (long)gm * p.ldr + gn);
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                v[2 * c] += bf16_to_f32((unsigned short)(a[c] & 0xffffu));
+                v[2 * c + 1] += bf16_to_f32((unsigned short)(a[c] >> 16));
+              }
+            }
+          }
+          if (p.c_f32) {
+            float* c = reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn;
+            *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(c + 4) = f32x4{v[4], v[5], v[6], v[7]};
+          } else {
+            u32x4 o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
+            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.C) + (long)gm * p.ldc + gn) = o;
+          }
+        }
+      }
+    }
+  }
+}
+
+static inline EpiArgs epi_args_from(const clipk_gemm_args* a) {
+  EpiArgs e;
+  e.C = a->C; e.ldc = a->ldc; e.c_f32 = (a->c_dtype == CLIPK_F32);
+  e.M = a->M; e.N = a->N;
+  e.bias = a->bias; e.act = a->act;
+  e.out_preact = (unsigned short*)a->out_preact; e.ldp = a->ldp;
+  e.dact_aux = (const unsigned short*)a->dact_aux; e.ldd = a->ldd; e.dact = a->dact;
+  e.residual = a->residual; e.ldr = a->ldr; e.r_f32 = (a->r_dtype == CLIPK_F32);
+  e.alpha = a->alpha;
+  return e;
+}

@@ -225,7 +225,7 @@ extern "C" int clipk_gemm_nt(const clipk_gemm_args* a, void* stream) {
   // fast path: LDS-DMA staged, 4 workgroups per CU (gemm_nt_v2.hip); needs whole 32-deep K steps
   const bool force_v1 = getenv("CLIPK_GEMM_V1") != nullptr;     // A/B switch for tools/bench_kernels.py
   const char* v3 = getenv("CLIPK_GEMM_V3");                      // 256x256-tile kernel: A/B switch
-  if (!force_v1 && (a->K & 31) == 0 && v3 && atoi(v3) == 1 && a->M >= 2048) return clipk_gemm_nt_v3_launch(a, stream);
+  if (!force_v1 && (a->K & 31) == 0 && v3 && atoi(v3) == 1 && a->M >= 2048 && a->K >= 128) return clipk_gemm_nt_v3_launch(a, stream);
   if (!force_v1 && (a->K & 31) == 0) return clipk_gemm_nt_v2_launch(a, stream);
   Params p;
   p.A = (const unsigned short*)a->A; p.lda = a->lda;

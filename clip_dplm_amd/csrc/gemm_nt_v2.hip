@@ -12,46 +12,31 @@
 //     consecutive output columns of one row, so the accumulator -> LDS staging of the epilogue is 16
 //     ds_write_b128 per lane instead of 64 ds_write_b32.
 #include "common.h"
+#include "gemm_epilogue.h"
 #include <stdlib.h>
 
 namespace {
 
 constexpr int BN = 128, BK = 64;
 constexpr int B_TILE_BYTES = BN * BK * 2;               // weights      [128 n][64 k]
-constexpr int EPI_LD = 68;                              // f32 per staged row (16 rows x 64 cols per wave + pad)
 // BM = 128: 4 waves (2x2), 32 KiB LDS, 4 workgroups / CU.   BM = 256: 8 waves (4x2), 48 KiB LDS, 2 workgroups / CU
 // — a third fewer bytes per FLOP through the CU's L2->LDS path, which is what bounds this kernel.
 
 struct Params {
   const unsigned short* A; long lda;
   const unsigned short* B; long ldb;
-  void* C; long ldc; int c_f32;
   int M, N, K;
-  const float* bias;
-  int act;
-  unsigned short* out_preact; long ldp;
-  const unsigned short* dact_aux; long ldd; int dact;
-  const void* residual; long ldr; int r_f32;
-  float alpha;
+  EpiArgs e;
   int ntn;
-  int nt;           // 1: non-temporal output stores
   int stagger;      // s_sleep(127) units (~3.4 us each) per quarter-phase, 0 = off
 };
-
-// output stores: optionally non-temporal (streamed once, keep the XCD's L2 for the operand panels)
-template <typename V>
-__device__ __forceinline__ void st_out(V* ptr, V v, int nt) {
-  if (nt) __builtin_nontemporal_store(v, ptr);
-  else *ptr = v;
-}
 
 __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(gptr, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// ACT_T / DACT_T: compile-time activation of the epilogue (-1 = take p.act / p.dact at run time).  The GELU
-// epilogues are VALU-bound (one erf per output element), so the hot combinations get branch-free specialisations.
-template <int BM, int STAGES, int ACT_T = -1, int DACT_T = -1>
+// MODE: compile-time epilogue variant (gemm_epilogue.h); EPI_GENERIC decides everything at run time
+template <int BM, int STAGES, int MODE = EPI_GENERIC>
 __global__ __launch_bounds__(BM * 2, (STAGES == 1 ? 4 : 2)) void gemm_nt_v2_kernel(const Params p) {
   constexpr int A_TILE_BYTES = BM * BK * 2;             // activations  [BM m][64 k]
   constexpr int STAGE_BYTES = A_TILE_BYTES + B_TILE_BYTES;
@@ -167,88 +152,9 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 ? 4 : 2)) void gemm_nt_v2_kern
     }
   }
 
-  // ---- epilogue, one 16-row m-tile at a time through a wave-private LDS slab [16 m][64 n (+4)] f32
+  // ---- epilogue (gemm_epilogue.h): wave-private LDS slab, 16 rows at a time
   float* eb = reinterpret_cast<float*>(smem) + wid * 16 * EPI_LD;
-  const float alpha = p.alpha;
-  const int g = lane >> 4, li = lane & 15;
-  const int ecol = (lane & 7) * 8;
-  const int gn = n0 + wn * 64 + ecol;
-  float bv[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) bv[c] = 0.f;
-  if (p.bias && gn < N) {
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + gn);
-    const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + gn + 4);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { bv[c] = b0[c]; bv[4 + c] = b1[c]; }
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<f32x4*>(eb + li * EPI_LD + i * 16 + 4 * g) = acc[i][j] * alpha;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int row = half * 8 + (lane >> 3);
-      const int gm = m0 + wm * 64 + j * 16 + row;
-      float v[8];
-      {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(eb + row * EPI_LD + ecol);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(eb + row * EPI_LD + ecol + 4);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { v[c] = v0[c] + bv[c]; v[4 + c] = v1[c] + bv[4 + c]; }
-      }
-      if (gm < M && gn < N) {
-        if (p.out_preact) {
-          u32x4 o;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) o[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
-          st_out(reinterpret_cast<u32x4*>(p.out_preact + (long)gm * p.ldp + gn), o, p.nt);
-        }
-        const int act = (ACT_T >= 0) ? ACT_T : p.act;
-        const int dact = (DACT_T >= 0) ? DACT_T : p.dact;
-        if (act != CLIPK_ACT_NONE) {
-#pragma unroll
-          for (int c = 0; c < 8; ++c) v[c] = act_apply(v[c], act);
-        }
-        if ((DACT_T < 0 || DACT_T != CLIPK_ACT_NONE) && p.dact_aux) {
-          const u32x4 a = *reinterpret_cast<const u32x4*>(p.dact_aux + (long)gm * p.ldd + gn);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            v[2 * c] *= act_grad(bf16_to_f32((unsigned short)(a[c] & 0xffffu)), dact);
-            v[2 * c + 1] *= act_grad(bf16_to_f32((unsigned short)(a[c] >> 16)), dact);
-          }
-        }
-        if (p.residual) {
-          if (p.r_f32) {
-            const float* r = reinterpret_cast<const float*>(p.residual) + (long)gm * p.ldr + gn;
-            const f32x4 r0 = *reinterpret_cast<const f32x4*>(r);
-            const f32x4 r1 = *reinterpret_cast<const f32x4*>(r + 4);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { v[c] += r0[c]; v[4 + c] += r1[c]; }
-          } else {
-            const u32x4 a = *reinterpret_cast<const u32x4*>(
-                reinterpret_cast<const unsigned short*>(p.residual) + (long)gm * p.ldr + gn);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              v[2 * c] += bf16_to_f32((unsigned short)(a[c] & 0xffffu));
-              v[2 * c + 1] += bf16_to_f32((unsigned short)(a[c] >> 16));
-            }
-          }
-        }
-        if (p.c_f32) {
-          float* c = reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn;
-          st_out(reinterpret_cast<f32x4*>(c), f32x4{v[0], v[1], v[2], v[3]}, p.nt);
-          st_out(reinterpret_cast<f32x4*>(c + 4), f32x4{v[4], v[5], v[6], v[7]}, p.nt);
-        } else {
-          u32x4 o;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) o[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
-          st_out(reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.C) + (long)gm * p.ldc + gn), o, p.nt);
-        }
-      }
-    }
-  }
+  gemm_epilogue<MODE, 4>(p.e, acc, eb, lane, m0 + wm * 64, n0 + wn * 64 + (lane & 7) * 8);
 }
 
 }  // namespace
@@ -258,21 +164,17 @@ extern "C" int clipk_gemm_nt_v2_launch(const clipk_gemm_args* a, void* stream) {
   Params p;
   p.A = (const unsigned short*)a->A; p.lda = a->lda;
   p.B = (const unsigned short*)a->B; p.ldb = a->ldb;
-  p.C = a->C; p.ldc = a->ldc; p.c_f32 = (a->c_dtype == CLIPK_F32);
   p.M = a->M; p.N = a->N; p.K = a->K;
-  p.bias = a->bias; p.act = a->act;
-  p.out_preact = (unsigned short*)a->out_preact; p.ldp = a->ldp;
-  p.dact_aux = (const unsigned short*)a->dact_aux; p.ldd = a->ldd; p.dact = a->dact;
-  p.residual = a->residual; p.ldr = a->ldr; p.r_f32 = (a->r_dtype == CLIPK_F32);
-  p.alpha = a->alpha;
+  p.e = epi_args_from(a);
   const int ntn = (a->N + BN - 1) / BN;
   p.ntn = ntn;
   { const char* sg = getenv("CLIPK_GEMM_STAGGER"); p.stagger = sg ? atoi(sg) : 0; }
-  { const char* e = getenv("CLIPK_GEMM_NT"); p.nt = e ? atoi(e) : 0; }
   const char* force = getenv("CLIPK_GEMM_BM");             // A/B switch for tools/bench_kernels.py
   const bool big = force ? (atoi(force) == 256) : false;
   const char* fs = getenv("CLIPK_GEMM_STAGES");
   const int stages = fs ? atoi(fs) : 1;
+  const char* ge = getenv("CLIPK_GEMM_EPI_GENERIC");       // A/B switch: force the run-time epilogue
+  const int mode = (ge && atoi(ge) == 1) ? EPI_GENERIC : epi_mode_for(a);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_v2_kernel<256, 2>),
@@ -289,14 +191,11 @@ extern "C" int clipk_gemm_nt_v2_launch(const clipk_gemm_args* a, void* stream) {
     const int ntm = (a->M + 127) / 128;
     const int lds = 128 * BK * 2 + B_TILE_BYTES;
     const dim3 grid(ntm * ntn), blk(256);
-    const bool has_dact = a->dact_aux != nullptr;
     if (stages == 2) hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 2>), grid, blk, 2 * lds, st, p);
-    else if (a->act == CLIPK_ACT_GELU && !has_dact)
-      hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, CLIPK_ACT_GELU, CLIPK_ACT_NONE>), grid, blk, lds, st, p);
-    else if (a->act == CLIPK_ACT_NONE && has_dact && a->dact == CLIPK_ACT_GELU)
-      hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, CLIPK_ACT_NONE, CLIPK_ACT_GELU>), grid, blk, lds, st, p);
-    else if (a->act == CLIPK_ACT_NONE && !has_dact)
-      hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, CLIPK_ACT_NONE, CLIPK_ACT_NONE>), grid, blk, lds, st, p);
+    else if (mode == EPI_PLAIN) hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, EPI_PLAIN>), grid, blk, lds, st, p);
+    else if (mode == EPI_RES32) hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, EPI_RES32>), grid, blk, lds, st, p);
+    else if (mode == EPI_GELU_PRE) hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, EPI_GELU_PRE>), grid, blk, lds, st, p);
+    else if (mode == EPI_DGELU) hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, EPI_DGELU>), grid, blk, lds, st, p);
     else hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1>), grid, blk, lds, st, p);
   }
   return clipk_check_launch();

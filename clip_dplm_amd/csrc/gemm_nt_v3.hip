@@ -1,39 +1,43 @@
-// gemm_nt_v3.hip — 256 x 256 tile variant of clipk_gemm_nt for the large-M Linear layers (K % 32 == 0).
+// gemm_nt_v3.hip — 256 x 256 tile, 8 waves, phase-interleaved schedule for clipk_gemm_nt (K % 32 == 0, K >= 128).
+// Same contract and epilogue as gemm_nt_v2.hip; selected by CLIPK_GEMM_V3 (gemm_nt.hip).
 //
-// Why a bigger tile: profiles/r01 + tools/exp_gemm.py show the 128 x 128 kernel's main loop running at the
-// L2 -> LDS bandwidth of the chip (15.3 TB/s of operand tiles at K = N = 1920, ~90 % of what the fabric delivers),
-// i.e. bound by bytes per FLOP (32 KiB of staged operands per 2.1 MFLOP step), not by MFMA issue.  A 256 x 256 tile
-// stages 64 KiB per 8.4 MFLOP step: half the L2 traffic per FLOP.
-//
-// Structure: 8 waves (2 along M x 4 along N, each wave 128 x 64 = 8 x 4 MFMA 16x16x32 tiles, 128 accumulator
-// registers), BK = 64, two 64 KiB LDS stages filled by LDS-DMA (global_load_lds_dwordx4, swizzle on the source
-// address as in v2).  The DMA of step k+1 stays in flight across the barrier while step k's MFMAs run: counted
-// `s_waitcnt vmcnt(8)` + raw s_barrier (a __syncthreads() would drain it).  One workgroup per CU, so the overlap
-// of loads and MFMAs is inside the workgroup.  Epilogue identical to v2 (swapped operand roles, LDS slab per wave,
-// 16-byte row-contiguous global accesses, fused bias / GELU / GELU' / residual / cast).
+// Why a second structure: the 128 x 128 kernel tops out where the CU's L2 -> LDS path saturates.
+// A 256 x 256 tile halves the operand bytes per FLOP, but only pays with ~1 workgroup per CU if the loads stay in
+// flight across barriers and the two waves of each SIMD alternate between "fetch fragments" and "issue MFMAs"
+// (cdna_hip_programming.md §5, 8-phase template).  Structure:
+//   * 8 waves = 2 (m) x 4 (n), wave tile 128 m x 64 n, 128 accumulator VGPRs; one K-tile (BK = 64) = 4 phases of
+//     16 MFMAs, each phase one quadrant (64 m x 32 n) of the wave tile: (m0,n0) (m0,n1) (m1,n1) (m1,n0);
+//   * LDS = 2 buffers x 4 half-tiles of 16 KiB.  A half-tile is defined by CONSUMPTION order, not by position:
+//     "X mh" holds the mh-th 64 rows of BOTH m-waves, "W nh" the nh-th 32 rows of all four n-waves, so a half-tile
+//     is dead after the phase that read it and can be refilled while the rest of the buffer is still in use;
+//   * every phase refills one half-tile (2 x global_load_lds_dwordx4 per lane) two K-tiles ahead; the only vmcnt
+//     waits are a counted vmcnt(6) once per K-tile (three half-tiles stay in flight) — never 0 in the main loop;
+//   * raw s_barrier twice per phase; the m = 1 waves run one barrier behind the m = 0 waves, so on every SIMD one
+//     wave is in its MFMA block (s_setprio 1) while the other fetches fragments and issues the refill.
+// Hazard bookkeeping (phases numbered 4T + ph for K-tile T):
+//   RAW  tile T+1 is complete at the vmcnt(6) of phase 4T+3, both wave groups have executed that wait before the
+//        barrier that opens phase 4T+4, where it is first read;
+//   WAR  W nh0: read first in phase 4T (retired by lgkmcnt(8) before that phase's barrier), refilled in 4T+1;
+//        X mh0: read 4T, refilled 4T+2;  W nh1: read 4T+1, refilled 4T+3;  X mh1: read 4T+2, refilled 4T+4.
 #include "common.h"
+#include "gemm_epilogue.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = 64, NTHREADS = 512;
-constexpr int A_TILE_BYTES = BM * BK * 2;               // 32 KiB
-constexpr int B_TILE_BYTES = BN * BK * 2;               // 32 KiB
-constexpr int STAGE_BYTES = A_TILE_BYTES + B_TILE_BYTES;
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;              // 128 KiB
-constexpr int EPI_LD = 68;
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int HALF_BYTES = 128 * BK * 2;        // 16 KiB
+constexpr int BUF_BYTES = 4 * HALF_BYTES;       // X mh0 | X mh1 | W nh0 | W nh1
+constexpr int LDS_BYTES = 2 * BUF_BYTES;        // 128 KiB
+
+__device__ __attribute__((aligned(16))) const unsigned int kZeroChunk[4] = {0u, 0u, 0u, 0u};
 
 struct Params {
   const unsigned short* A; long lda;
   const unsigned short* B; long ldb;
-  void* C; long ldc; int c_f32;
   int M, N, K;
-  const float* bias;
-  int act;
-  unsigned short* out_preact; long ldp;
-  const unsigned short* dact_aux; long ldd; int dact;
-  const void* residual; long ldr; int r_f32;
-  float alpha;
+  EpiArgs e;
   int ntn;
 };
 
@@ -41,8 +45,24 @@ __device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(gptr, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int ACT_T, int DACT_T>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_v3_kernel(const Params p) {
+// one quadrant: 2 n-tiles x 4 m-tiles x 2 k-halves = 16 MFMAs (k outer so dependent accumulations sit 8 apart)
+template <int NH, int MH>
+__device__ __forceinline__ void quad(f32x4 (&acc)[4][8], const bf16x8 (&wf)[2][2][2], const bf16x8 (&xf)[4][2]) {
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[NH * 2 + t][MH * 4 + j] =
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[NH][t][kk], xf[j][kk], acc[NH * 2 + t][MH * 4 + j], 0, 0, 0);
+}
+
+#define CLIPK_BAR() __builtin_amdgcn_s_barrier()
+#define CLIPK_SB() __builtin_amdgcn_sched_barrier(0)
+
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void gemm_nt_v3_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -52,20 +72,37 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_v3_kernel(const Params p)
   const int m0 = tm * BM, n0 = tn * BN;
   const int M = p.M, N = p.N, K = p.K;
 
-  // ---- LDS-DMA assignment: wave w, piece i (0..3) fills rows 8*(4w+i) .. +7 of each 256-row operand tile
+  // ---- LDS-DMA assignment: wave w fills pieces 2w, 2w+1 (8 rows x 128 B each) of every half-tile.
+  // lane -> (row in piece = lane>>3, physical 16-B slot = lane&7); source chunk = slot ^ ((row>>1)&7)
   const int prow = lane >> 3, pslot = lane & 7;
-  const unsigned short* asrc[4];
-  const unsigned short* bsrc[4];
-  int kchunk[4];
+  const unsigned short* xs0[2]; const unsigned short* xs1[2];
+  const unsigned short* ws0[2]; const unsigned short* ws1[2];
+  int kch[2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = 8 * (4 * wid + i) + prow;
-    kchunk[i] = (pslot ^ ((row >> 1) & 7)) * 8;
-    int ra = m0 + row; ra = ra < M ? ra : M - 1;
-    int rb = n0 + row; rb = rb < N ? rb : N - 1;
-    asrc[i] = p.A + (long)ra * p.lda;
-    bsrc[i] = p.B + (long)rb * p.ldb;
+  for (int i = 0; i < 2; ++i) {
+    const int r = 8 * (2 * wid + i) + prow;                     // row of the half-tile image
+    kch[i] = (pslot ^ ((r >> 1) & 7)) * 8;
+    const int mb = m0 + (r >> 6) * 128 + (r & 63);              // X half mh: rows of m-wave r>>6
+    const int nb = n0 + (r >> 5) * 64 + (r & 31);               // W half nh: rows of n-wave r>>5
+    int ma = mb, mc = mb + 64, na = nb, nc = nb + 32;
+    ma = ma < M ? ma : M - 1; mc = mc < M ? mc : M - 1;
+    na = na < N ? na : N - 1; nc = nc < N ? nc : N - 1;
+    xs0[i] = p.A + (long)ma * p.lda + kch[i];
+    xs1[i] = p.A + (long)mc * p.lda + kch[i];
+    ws0[i] = p.B + (long)na * p.ldb + kch[i];
+    ws1[i] = p.B + (long)nc * p.ldb + kch[i];
   }
+  const unsigned short* zsrc = reinterpret_cast<const unsigned short*>(kZeroChunk);
+  auto stage = [&](const unsigned short* const (&src)[2], int T, int region) {
+    const int k0 = T * BK;
+    char* dst = smem + (T & 1) * BUF_BYTES + region + wid * 2048;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned short* g = (k0 + kch[i] < K) ? src[i] + k0 : zsrc;   // K tail (K % 64 == 32): zero x zero
+      glds16(g, dst + i * 1024);
+    }
+  };
+  constexpr int XH0 = 0, XH1 = HALF_BYTES, WH0 = 2 * HALF_BYTES, WH1 = 3 * HALF_BYTES;
 
   f32x4 acc[4][8];          // [n-tile i][m-tile j]: rows n = 4g+r, col m = lane&15
 #pragma unroll
@@ -73,171 +110,129 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_v3_kernel(const Params p)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int lane_sw = (lane >> 1) & 7;
-  const int frow = lane & 15, fch = lane >> 4;
-  const int x_frag_off = (wm * 128 + frow) * 128;                  // activation rows (B operand)
-  const int w_frag_off = A_TILE_BYTES + (wn * 64 + frow) * 128;    // weight rows (A operand)
-
-  const int nk = (K + BK - 1) / BK;
-  auto issue = [&](int kt, char* stage) {
-    const int k0 = kt * BK;
+  const int frow = lane & 15, fch = lane >> 4, lane_sw = (frow >> 1) & 7;
+  int xo[2], wo[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int k = k0 + kchunk[i];
-      k = k < K ? k : 0;                                 // K tail: slot is never read, keep the address valid
-      glds16(asrc[i] + k, stage + (4 * wid + i) * 1024);
-      glds16(bsrc[i] + k, stage + A_TILE_BYTES + (4 * wid + i) * 1024);
-    }
-  };
+  for (int kk = 0; kk < 2; ++kk) {
+    const int choff = ((kk * 4 + fch) ^ lane_sw) << 4;
+    xo[kk] = (wm * 64 + frow) * 128 + choff;
+    wo[kk] = WH0 + (wn * 32 + frow) * 128 + choff;
+  }
 
-  issue(0, smem);
-  for (int kt = 0; kt < nk; ++kt) {
-    const char* cur = smem + (kt & 1) * STAGE_BYTES;
-    if (kt + 1 < nk) {
-      issue(kt + 1, smem + ((kt + 1) & 1) * STAGE_BYTES);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // everything but the 8 youngest DMA (= next stage) has landed
-    } else {
+  bf16x8 xf[4][2], wf[2][2][2];
+  const int nk = (K + BK - 1) / BK;
+
+  // TM 0: steady state; 1: K-tile nk-2 (only the last half-tile of tile nk-1 left to fetch); 2: last K-tile
+  auto tile_body = [&](auto mode_c, int T) {
+    constexpr int TM = decltype(mode_c)::value;
+    const char* buf = smem + (T & 1) * BUF_BYTES;
+    // ---- phase 0: quadrant (n0, m0); fetch W nh0 (4 reads, first) + X mh0 (8 reads); refill X mh1 of tile T+1
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) wf[0][t][kk] = *reinterpret_cast<const bf16x8*>(buf + wo[kk] + t * 2048);
+    CLIPK_SB();
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) xf[j][kk] = *reinterpret_cast<const bf16x8*>(buf + xo[kk] + XH0 + j * 2048);
+    if (TM <= 1) stage(xs1, T + 1, XH1);
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");          // W nh0 reads retired: refilled next phase
+    CLIPK_SB(); CLIPK_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    CLIPK_SB();
+    __builtin_amdgcn_s_setprio(1);
+    quad<0, 0>(acc, wf, xf);
+    __builtin_amdgcn_s_setprio(0);
+    CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
+    // ---- phase 1: quadrant (n1, m0); fetch W nh1; refill W nh0 of tile T+2
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        wf[1][t][kk] = *reinterpret_cast<const bf16x8*>(buf + wo[kk] + HALF_BYTES + t * 2048);
+    if (TM == 0) stage(ws0, T + 2, WH0);
+    CLIPK_SB(); CLIPK_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    CLIPK_SB();
+    __builtin_amdgcn_s_setprio(1);
+    quad<1, 0>(acc, wf, xf);
+    __builtin_amdgcn_s_setprio(0);
+    CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
+    // ---- phase 2: quadrant (n1, m1); fetch X mh1; refill X mh0 of tile T+2
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) xf[j][kk] = *reinterpret_cast<const bf16x8*>(buf + xo[kk] + XH1 + j * 2048);
+    if (TM == 0) stage(xs0, T + 2, XH0);
+    CLIPK_SB(); CLIPK_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    CLIPK_SB();
+    __builtin_amdgcn_s_setprio(1);
+    quad<1, 1>(acc, wf, xf);
+    __builtin_amdgcn_s_setprio(0);
+    CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
+    // ---- phase 3: quadrant (n0, m1); nothing to fetch; refill W nh1 of tile T+2; tile T+1 must be complete
+    if (TM == 0) {
+      stage(ws1, T + 2, WH1);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else if (TM == 1) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();
-    const int ksub = (kt * BK + 32 < K) ? 2 : 1;
-    for (int kk = 0; kk < ksub; ++kk) {
-      const int choff = (((kk * 4 + fch) ^ lane_sw) << 4);
-      bf16x8 wf[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(cur + w_frag_off + t * 2048 + choff);
-#pragma unroll
-      for (int jh = 0; jh < 2; ++jh) {                   // two halves of the wave's 8 m-tiles: 16 fragment registers live
-        bf16x8 xf[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          xf[t] = *reinterpret_cast<const bf16x8*>(cur + x_frag_off + (jh * 4 + t) * 2048 + choff);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            acc[i][jh * 4 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[t], acc[i][jh * 4 + t], 0, 0, 0);
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                        // stage (kt&1) fully read before step kt+2's DMA refills it
-  }
+    CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
+    __builtin_amdgcn_s_setprio(1);
+    quad<0, 1>(acc, wf, xf);
+    __builtin_amdgcn_s_setprio(0);
+    CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
+  };
 
-  // ---- epilogue, one 16-row m-tile at a time through a wave-private LDS slab [16 m][64 n (+4)] f32
+  // ---- prologue: tile 0 complete, three half-tiles of tile 1 in flight (nk >= 2 guaranteed by the launcher)
+  stage(ws0, 0, WH0); stage(xs0, 0, XH0); stage(ws1, 0, WH1); stage(xs1, 0, XH1);
+  stage(ws0, 1, WH0); stage(xs0, 1, XH0); stage(ws1, 1, WH1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
+  if (wm == 1) CLIPK_BAR();                                     // m = 1 waves run one barrier behind
+  for (int T = 0; T < nk - 2; ++T) tile_body(std::integral_constant<int, 0>{}, T);
+  tile_body(std::integral_constant<int, 1>{}, nk - 2);
+  tile_body(std::integral_constant<int, 2>{}, nk - 1);
+  if (wm == 0) CLIPK_BAR();                                     // re-align the two groups
+  __syncthreads();   // compiler-visible drain: without it hipcc waits vmcnt(0) before every epilogue LDS read
+
+  // ---- epilogue (gemm_epilogue.h): wave-private LDS slab, 16 rows at a time
   float* eb = reinterpret_cast<float*>(smem) + wid * 16 * EPI_LD;
-  const float alpha = p.alpha;
-  const int g = lane >> 4, li = lane & 15;
-  const int ecol = (lane & 7) * 8;
-  const int gn = n0 + wn * 64 + ecol;
-  float bv[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) bv[c] = 0.f;
-  if (p.bias && gn < N) {
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + gn);
-    const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + gn + 4);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { bv[c] = b0[c]; bv[4 + c] = b1[c]; }
-  }
-  const int act = (ACT_T >= 0) ? ACT_T : p.act;
-  const int dact = (DACT_T >= 0) ? DACT_T : p.dact;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<f32x4*>(eb + li * EPI_LD + i * 16 + 4 * g) = acc[i][j] * alpha;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int row = half * 8 + (lane >> 3);
-      const int gm = m0 + wm * 128 + j * 16 + row;
-      float v[8];
-      {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(eb + row * EPI_LD + ecol);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(eb + row * EPI_LD + ecol + 4);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { v[c] = v0[c] + bv[c]; v[4 + c] = v1[c] + bv[4 + c]; }
-      }
-      if (gm < M && gn < N) {
-        if (p.out_preact) {
-          u32x4 o;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) o[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
-          *reinterpret_cast<u32x4*>(p.out_preact + (long)gm * p.ldp + gn) = o;
-        }
-        if (act != CLIPK_ACT_NONE) {
-#pragma unroll
-          for (int c = 0; c < 8; ++c) v[c] = act_apply(v[c], act);
-        }
-        if ((DACT_T < 0 || DACT_T != CLIPK_ACT_NONE) && p.dact_aux) {
-          const u32x4 a = *reinterpret_cast<const u32x4*>(p.dact_aux + (long)gm * p.ldd + gn);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            v[2 * c] *= act_grad(bf16_to_f32((unsigned short)(a[c] & 0xffffu)), dact);
-            v[2 * c + 1] *= act_grad(bf16_to_f32((unsigned short)(a[c] >> 16)), dact);
-          }
-        }
-        if (p.residual) {
-          if (p.r_f32) {
-            const float* r = reinterpret_cast<const float*>(p.residual) + (long)gm * p.ldr + gn;
-            const f32x4 r0 = *reinterpret_cast<const f32x4*>(r);
-            const f32x4 r1 = *reinterpret_cast<const f32x4*>(r + 4);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { v[c] += r0[c]; v[4 + c] += r1[c]; }
-          } else {
-            const u32x4 a = *reinterpret_cast<const u32x4*>(
-                reinterpret_cast<const unsigned short*>(p.residual) + (long)gm * p.ldr + gn);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              v[2 * c] += bf16_to_f32((unsigned short)(a[c] & 0xffffu));
-              v[2 * c + 1] += bf16_to_f32((unsigned short)(a[c] >> 16));
-            }
-          }
-        }
-        if (p.c_f32) {
-          float* c = reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn;
-          *reinterpret_cast<f32x4*>(c) = f32x4{v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<f32x4*>(c + 4) = f32x4{v[4], v[5], v[6], v[7]};
-        } else {
-          u32x4 o;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) o[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
-          *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.C) + (long)gm * p.ldc + gn) = o;
-        }
-      }
-    }
-  }
+  gemm_epilogue<MODE, 8>(p.e, acc, eb, lane, m0 + wm * 128, n0 + wn * 64 + (lane & 7) * 8);
 }
 
-template <int ACT_T, int DACT_T>
-void launch(const Params& p, int grid, hipStream_t st) {
+template <int MODE>
+void launch_v3(const Params& p, dim3 grid, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_v3_kernel<ACT_T, DACT_T>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_v3_kernel<MODE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_v3_kernel<ACT_T, DACT_T>), dim3(grid), dim3(NTHREADS), LDS_BYTES, st, p);
+  hipLaunchKernelGGL((gemm_nt_v3_kernel<MODE>), grid, dim3(512), LDS_BYTES, st, p);
 }
 
 }  // namespace
 
+// called by clipk_gemm_nt (gemm_nt.hip) after it validated the arguments (K % 32 == 0, K >= 128)
 extern "C" int clipk_gemm_nt_v3_launch(const clipk_gemm_args* a, void* stream) {
   Params p;
   p.A = (const unsigned short*)a->A; p.lda = a->lda;
   p.B = (const unsigned short*)a->B; p.ldb = a->ldb;
-  p.C = a->C; p.ldc = a->ldc; p.c_f32 = (a->c_dtype == CLIPK_F32);
   p.M = a->M; p.N = a->N; p.K = a->K;
-  p.bias = a->bias; p.act = a->act;
-  p.out_preact = (unsigned short*)a->out_preact; p.ldp = a->ldp;
-  p.dact_aux = (const unsigned short*)a->dact_aux; p.ldd = a->ldd; p.dact = a->dact;
-  p.residual = a->residual; p.ldr = a->ldr; p.r_f32 = (a->r_dtype == CLIPK_F32);
-  p.alpha = a->alpha;
+  p.e = epi_args_from(a);
   const int ntm = (a->M + BM - 1) / BM, ntn = (a->N + BN - 1) / BN;
   p.ntn = ntn;
+  const dim3 grid(ntm * ntn);
   hipStream_t st = (hipStream_t)stream;
-  const bool has_dact = a->dact_aux != nullptr;
-  if (a->act == CLIPK_ACT_GELU && !has_dact) launch<CLIPK_ACT_GELU, CLIPK_ACT_NONE>(p, ntm * ntn, st);
-  else if (a->act == CLIPK_ACT_NONE && has_dact && a->dact == CLIPK_ACT_GELU) launch<CLIPK_ACT_NONE, CLIPK_ACT_GELU>(p, ntm * ntn, st);
-  else if (a->act == CLIPK_ACT_NONE && !has_dact) launch<CLIPK_ACT_NONE, CLIPK_ACT_NONE>(p, ntm * ntn, st);
-  else launch<-1, -1>(p, ntm * ntn, st);
+  const char* ge = getenv("CLIPK_GEMM_EPI_GENERIC");
+  const int mode = (ge && atoi(ge) == 1) ? EPI_GENERIC : epi_mode_for(a);
+  if (mode == EPI_PLAIN) launch_v3<EPI_PLAIN>(p, grid, st);
+  else if (mode == EPI_RES32) launch_v3<EPI_RES32>(p, grid, st);
+  else if (mode == EPI_GELU_PRE) launch_v3<EPI_GELU_PRE>(p, grid, st);
+  else if (mode == EPI_DGELU) launch_v3<EPI_DGELU>(p, grid, st);
+  else launch_v3<EPI_GENERIC>(p, grid, st);
   return clipk_check_launch();
 }

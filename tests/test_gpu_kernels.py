@@ -82,6 +82,46 @@ def test_gemm_nt_epilogue(dev, act):
     assert torch.allclose(outd, (a.float() @ b.float().t()) * gref, rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("kernel", ["v2", "v3", "generic"])
+@pytest.mark.parametrize("M,N,K", [(2048, 256, 128), (2500, 360, 160), (4096, 1440, 480), (2304, 480, 1920),
+                                   (3000, 776, 192)])
+def test_gemm_nt_specialised_epilogues(dev, monkeypatch, kernel, M, N, K):
+    """The four compile-time epilogue modes (gemm_epilogue.h) of the 128x128 kernel and of the 256x256 phase-
+    interleaved kernel (CLIPK_GEMM_V3), ragged M / N edges and the K % 64 == 32 tail, against torch f32."""
+    ops = _ops()
+    if kernel == "v3":
+        monkeypatch.setenv("CLIPK_GEMM_V3", "1")
+    if kernel == "generic":
+        monkeypatch.setenv("CLIPK_GEMM_EPI_GENERIC", "1")
+    a = _rand((M, K), dev, 11, dtype=torch.bfloat16)
+    b = _rand((N, K), dev, 12, 0.05, dtype=torch.bfloat16)
+    bias = _rand((N,), dev, 13)
+    res = _rand((M, N), dev, 14)
+    aux = _rand((M, N), dev, 15, dtype=torch.bfloat16)
+    ref = a.float() @ b.float().t()
+    tol = dict(rtol=1e-2, atol=1e-2)
+    # PLAIN (with and without bias)
+    assert torch.allclose(ops.gemm_nt(a, b).float(), ref, **tol)
+    assert torch.allclose(ops.gemm_nt(a, b, bias=bias).float(), ref + bias, **tol)
+    # RES32
+    out = ops.gemm_nt(a, b, bias=bias, residual=res, out_dtype=torch.float32)
+    assert torch.allclose(out, ref + bias + res, rtol=1e-4, atol=1e-4 * math.sqrt(K)), (out - ref - bias - res).abs().max()
+    # GELU_PRE
+    g, u = ops.gemm_nt(a, b, bias=bias, act="gelu", out_preact=True)
+    assert torch.allclose(u.float(), ref + bias, **tol)
+    assert torch.allclose(g.float(), F.gelu(ref + bias), **tol)
+    # DGELU
+    auxf = aux.float().requires_grad_(True)
+    gref, = torch.autograd.grad(F.gelu(auxf), auxf, torch.ones_like(auxf))
+    d = ops.gemm_nt(a, b, dact_aux=aux, dact="gelu")
+    assert torch.allclose(d.float(), ref * gref, **tol)
+    # nothing may be written outside [M, N]: run into a padded buffer and check the guard band
+    big = torch.full((M + 8, N + 8), 7.0, dtype=torch.bfloat16, device=dev)
+    ops.gemm_nt(a, b, bias=bias, out=big[:M, :N])
+    assert (big[M:] == 7.0).all() and (big[:, N:] == 7.0).all()
+    assert torch.allclose(big[:M, :N].float(), ref + bias, **tol)
+
+
 @pytest.mark.parametrize("M,N,K", [(512, 128, 128), (4096, 1440, 480), (1000, 360, 120), (8192, 480, 1920),
                                    (300, 8, 16), (16384, 768, 768)])
 def test_gemm_wgrad(dev, M, N, K):

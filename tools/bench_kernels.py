@@ -45,13 +45,17 @@ GEMM_SHAPES = [  # (name, M, N, K, epilogue)
     ("esm qkv", T, 1440, 480, "bias"), ("esm out", T, 480, 480, "res32"), ("esm fc1", T, 1920, 480, "gelu+pre"),
     ("esm fc2", T, 480, 1920, "res32"), ("rna qkv", T, 2304, 768, "bias"), ("rna out", T, 768, 768, "res32"),
     ("rna fc1", T, 2048, 768, "gelu+pre"), ("rna fc2", T, 768, 2048, "res32"),
-    ("esm d_fc2", T, 1920, 480, "dact"), ("rna d_qkv", T, 768, 2304, "res32"),
+    ("esm d_fc2", T, 1920, 480, "dact"), ("rna d_qkv", T, 768, 2304, "res32"), ("esm d_qkv", T, 480, 1440, "bias"),
 ]
 
 
 def bench_gemm():
-    print(f"{'shape':12s} {'M':>7s} {'N':>5s} {'K':>5s} {'epi':9s} | v2 128^2 us TF/s | v3 256^2 us TF/s | ratio")
-    tot = {"v1": 0.0, "v2": 0.0}
+    """three arms, interleaved in one process: 128^2 kernel with the run-time epilogue (round-1 baseline), 128^2 with
+    the specialised straight-line epilogue, 256^2 phase-interleaved kernel (CLIPK_GEMM_V3)"""
+    arms = (("v2gen", {"CLIPK_GEMM_EPI_GENERIC": "1"}), ("v2", {}), ("v3", {"CLIPK_GEMM_V3": "1"}))
+    print(f"{'shape':12s} {'M':>7s} {'N':>5s} {'K':>5s} {'epi':9s} | " + " | ".join(f"{n:>5s} us  TF/s" for n, _ in arms)
+          + " | v2/v2gen v3/v2")
+    tot = {n: 0.0 for n, _ in arms}
     for name, M, N, K, epi in GEMM_SHAPES:
         a, b = rnd((M, K)), rnd((N, K), scale=0.05)
         bias = torch.randn(N, device=DEV)
@@ -63,17 +67,21 @@ def bench_gemm():
         elif epi == "dact":
             kw = {"dact_aux": rnd((M, N)), "dact": "gelu"}
         out = {}
-        for ver in ("v1", "v2"):
-            os.environ["CLIPK_GEMM_V3"] = "0" if ver == "v1" else "1"
+        for n, env in arms:
+            for k in ("CLIPK_GEMM_EPI_GENERIC", "CLIPK_GEMM_V3"):
+                os.environ.pop(k, None)
+            os.environ.update(env)
             med, mn = timeit(lambda: ops.gemm_nt(a, b, **kw))
-            out[ver] = med
-            tot[ver] += med
+            out[n] = med
+            tot[n] += med
         fl = 2.0 * M * N * K
-        print(f"{name:12s} {M:7d} {N:5d} {K:5d} {epi:9s} | {out['v1'] * 1e3:7.1f} {fl / out['v1'] / 1e9:6.0f} | "
-              f"{out['v2'] * 1e3:7.1f} {fl / out['v2'] / 1e9:6.0f} | {out['v1'] / out['v2']:.2f}x")
+        print(f"{name:12s} {M:7d} {N:5d} {K:5d} {epi:9s} | "
+              + " | ".join(f"{out[n] * 1e3:7.1f} {fl / out[n] / 1e9:5.0f}" for n, _ in arms)
+              + f" | {out['v2gen'] / out['v2']:.2f}x {out['v2'] / out['v3']:.2f}x", flush=True)
         del a, b, kw
-    os.environ.pop("CLIPK_GEMM_V3", None)
-    print(f"sum: bm128 {tot['v1']:.2f} ms, bm256 {tot['v2']:.2f} ms")
+    for k in ("CLIPK_GEMM_EPI_GENERIC", "CLIPK_GEMM_V3"):
+        os.environ.pop(k, None)
+    print("sum: " + ", ".join(f"{n} {tot[n]:.2f} ms" for n, _ in arms))
 
 
 def bench_wgrad():
