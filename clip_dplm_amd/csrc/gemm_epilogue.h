@@ -33,6 +33,12 @@ enum {
   EPI_DGELU = 3,      // bf16 out = acc * GELU'(aux)
 };
 
+// VMEM stores one wave issues in gemm_epilogue<MODE, NJ> (its loads are consumed inside): callers that keep LDS-DMA
+// in flight across the epilogue count them in their s_waitcnt vmcnt(N)
+constexpr int epi_stores(int mode, int nj) {
+  return (mode == EPI_PLAIN || mode == EPI_DGELU) ? 2 * nj : (mode == EPI_RES32 || mode == EPI_GELU_PRE) ? 4 * nj : -1;
+}
+
 // which specialised mode (if any) matches a request
 static inline int epi_mode_for(const clipk_gemm_args* a) {
   const bool c_f32 = a->c_dtype == CLIPK_F32, has_res = a->residual != nullptr, has_aux = a->dact_aux != nullptr;
@@ -49,28 +55,49 @@ static inline int epi_mode_for(const clipk_gemm_args* a) {
 
 constexpr int EPI_LD = 68;                              // f32 per staged row (16 rows x 64 cols per wave + pad)
 
-// eb: wave-private slab (16 * EPI_LD floats); mbase: first output row of this wave; gn: this lane's first column
-template <int MODE, int NJ>
+// float offset of the 16-B chunk `chunk` (0..15) of slab row `row` (0..15).  SWZ = false: rows padded to EPI_LD
+// floats (4352 B per wave).  SWZ = true: 64-float rows, chunk index XOR row (4096 B per wave, conflict-free for the
+// column-wise accumulator writes and the row-wise reads alike) — for kernels that have no LDS to spare for the pad.
+template <bool SWZ>
+__device__ __forceinline__ int slab_off(int row, int chunk) {
+  return SWZ ? row * 64 + ((chunk ^ row) << 2) : row * EPI_LD + (chunk << 2);
+}
+
+// this lane's 8 bias values (columns gn .. gn+7), zeros without a bias.  Separate from gemm_epilogue so that a kernel
+// with LDS-DMA prefetches in flight can issue these loads BEFORE the prefetch (vmcnt is in-order: a load issued
+// after the prefetch cannot be waited for without waiting for the prefetch as well).
+// Two steps so that the loads can be issued well ahead (epi_issue_bias) of the point where they must have landed
+// (epi_retire_bias).
+__device__ __forceinline__ void epi_issue_bias(const EpiArgs& p, int gn, f32x4& b0, f32x4& b1) {
+  b0 = f32x4{0.f, 0.f, 0.f, 0.f}; b1 = b0;
+  if (p.bias && gn < p.N) {
+    b0 = *reinterpret_cast<const f32x4*>(p.bias + gn);
+    b1 = *reinterpret_cast<const f32x4*>(p.bias + gn + 4);
+  }
+}
+__device__ __forceinline__ void epi_retire_bias(const f32x4& b0, const f32x4& b1, float (&bv)[8]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { bv[c] = b0[c]; bv[4 + c] = b1[c]; }
+  // retire the loads here, so that none is pending on any path into the slice loop
+#pragma unroll
+  for (int c = 0; c < 8; ++c) asm volatile("" ::"v"(bv[c]));
+}
+__device__ __forceinline__ void epi_load_bias(const EpiArgs& p, int gn, float (&bv)[8]) {
+  f32x4 b0, b1;
+  epi_issue_bias(p, gn, b0, b1);
+  epi_retire_bias(b0, b1, bv);
+}
+
+// eb: wave-private slab; mbase: first output row of this wave; gn: this lane's first column; bv: epi_load_bias
+template <int MODE, int NJ, bool SWZ = false>
 __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][NJ], float* eb, int lane, int mbase,
-                                              int gn) {
+                                              int gn, const float (&bv)[8]) {
   const int M = p.M, N = p.N;
   const float alpha = p.alpha;
   const int g = lane >> 4, li = lane & 15;
   const int ecol = (lane & 7) * 8;
-  float bv[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) bv[c] = 0.f;
-  if (p.bias && gn < N) {
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + gn);
-    const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + gn + 4);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { bv[c] = b0[c]; bv[4 + c] = b1[c]; }
-  }
 
   if constexpr (MODE != EPI_GENERIC) {
-    // retire the bias loads here, outside the slice loop, so no load is pending on any path into it
-#pragma unroll
-    for (int c = 0; c < 8; ++c) asm volatile("" ::"v"(bv[c]));
     const bool col_ok = gn < N;
     const long gnc = col_ok ? gn : 0;
     // stores go through buffer descriptors: an out-of-range lane gets an offset past num_records and the hardware
@@ -101,7 +128,7 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
       const int j = s >> 1;
       if ((s & 1) == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(eb + li * EPI_LD + i * 16 + 4 * g) = acc[i][j] * alpha;
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(eb + slab_off<SWZ>(li, i * 4 + g)) = acc[i][j] * alpha;
       }
       f32x4 n0 = r0, n1 = r1;
       u32x4 nx = ax;
@@ -110,8 +137,8 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
       const int gm = row_of(s);
       float v[8];
       {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(eb + row * EPI_LD + ecol);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(eb + row * EPI_LD + ecol + 4);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(eb + slab_off<SWZ>(row, ecol >> 2));
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(eb + slab_off<SWZ>(row, (ecol >> 2) + 1));
 #pragma unroll
         for (int c = 0; c < 4; ++c) { v[c] = v0[c] + bv[c]; v[4 + c] = v1[c] + bv[4 + c]; }
       }
@@ -159,15 +186,15 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(eb + li * EPI_LD + i * 16 + 4 * g) = acc[i][j] * alpha;
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(eb + slab_off<SWZ>(li, i * 4 + g)) = acc[i][j] * alpha;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int row = half * 8 + (lane >> 3);
         const int gm = mbase + j * 16 + row;
         float v[8];
         {
-          const f32x4 v0 = *reinterpret_cast<const f32x4*>(eb + row * EPI_LD + ecol);
-          const f32x4 v1 = *reinterpret_cast<const f32x4*>(eb + row * EPI_LD + ecol + 4);
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(eb + slab_off<SWZ>(row, ecol >> 2));
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(eb + slab_off<SWZ>(row, (ecol >> 2) + 1));
 #pragma unroll
           for (int c = 0; c < 4; ++c) { v[c] = v0[c] + bv[c]; v[4 + c] = v1[c] + bv[4 + c]; }
         }

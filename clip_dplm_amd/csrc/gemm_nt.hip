@@ -222,10 +222,18 @@ extern "C" int clipk_gemm_nt(const clipk_gemm_args* a, void* stream) {
   if (a->out_preact && (!aligned16(a->out_preact) || (a->ldp & 7))) return CLIPK_ERR_BAD_ARG;
   if (a->dact_aux && (!aligned16(a->dact_aux) || (a->ldd & 7))) return CLIPK_ERR_BAD_ARG;
   if (a->residual && (!aligned16(a->residual) || (a->ldr & 7))) return CLIPK_ERR_BAD_ARG;
-  // fast path: LDS-DMA staged, 4 workgroups per CU (gemm_nt_v2.hip); needs whole 32-deep K steps
-  const bool force_v1 = getenv("CLIPK_GEMM_V1") != nullptr;     // A/B switch for tools/bench_kernels.py
-  const char* v3 = getenv("CLIPK_GEMM_V3");                      // 256x256-tile kernel: A/B switch
-  if (!force_v1 && (a->K & 31) == 0 && v3 && atoi(v3) == 1 && a->M >= 2048 && a->K >= 128) return clipk_gemm_nt_v3_launch(a, stream);
+  // fast paths, both LDS-DMA staged and needing whole 32-deep K steps:
+  //   gemm_nt_v3.hip  persistent 256 x 256 tiles, phase-interleaved: problems with at least ~3/4 of a tile per CU
+  //   gemm_nt_v2.hip  128 x 128 tiles, 4 workgroups per CU: everything else
+  // CLIPK_GEMM_V3 = 0 / 1 forces the choice (tools/bench_kernels.py, tests), CLIPK_GEMM_V1 the generic kernel.
+  const bool force_v1 = getenv("CLIPK_GEMM_V1") != nullptr;
+  const char* v3 = getenv("CLIPK_GEMM_V3");
+  const int v3mode = v3 ? atoi(v3) : -1;
+  const long tiles256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
+  const bool v3_ok = (a->K & 31) == 0 && a->K >= 160 && (long)a->M * a->lda * 2 < (1L << 32) &&
+                     (long)a->N * a->ldb * 2 < (1L << 32);     // 32-bit buffer offsets
+  if (!force_v1 && v3_ok && ((v3mode == 1 && a->M >= 2048) || (v3mode < 0 && tiles256 >= 192)))
+    return clipk_gemm_nt_v3_launch(a, stream);
   if (!force_v1 && (a->K & 31) == 0) return clipk_gemm_nt_v2_launch(a, stream);
   Params p;
   p.A = (const unsigned short*)a->A; p.lda = a->lda;

@@ -154,7 +154,9 @@ __global__ __launch_bounds__(BM * 2, (STAGES == 1 ? 4 : 2)) void gemm_nt_v2_kern
 
   // ---- epilogue (gemm_epilogue.h): wave-private LDS slab, 16 rows at a time
   float* eb = reinterpret_cast<float*>(smem) + wid * 16 * EPI_LD;
-  gemm_epilogue<MODE, 4>(p.e, acc, eb, lane, m0 + wm * 64, n0 + wn * 64 + (lane & 7) * 8);
+  float bv[8];
+  epi_load_bias(p.e, n0 + wn * 64 + (lane & 7) * 8, bv);
+  gemm_epilogue<MODE, 4>(p.e, acc, eb, lane, m0 + wm * 64, n0 + wn * 64 + (lane & 7) * 8, bv);
 }
 
 }  // namespace

@@ -84,10 +84,12 @@ def test_gemm_nt_epilogue(dev, act):
 
 @pytest.mark.parametrize("kernel", ["v2", "v3", "generic"])
 @pytest.mark.parametrize("M,N,K", [(2048, 256, 128), (2500, 360, 160), (4096, 1440, 480), (2304, 480, 1920),
-                                   (3000, 776, 192)])
+                                   (3000, 776, 192), (66000, 520, 480), (40000, 1000, 224)])
 def test_gemm_nt_specialised_epilogues(dev, monkeypatch, kernel, M, N, K):
-    """The four compile-time epilogue modes (gemm_epilogue.h) of the 128x128 kernel and of the 256x256 phase-
-    interleaved kernel (CLIPK_GEMM_V3), ragged M / N edges and the K % 64 == 32 tail, against torch f32."""
+    """The four compile-time epilogue modes (gemm_epilogue.h) of the 128x128 kernel and of the persistent 256x256
+    phase-interleaved kernel (CLIPK_GEMM_V3), ragged M / N edges and the K % 64 == 32 tail, against torch f32.  The
+    two largest shapes have 774 / 628 output tiles, i.e. every persistent workgroup walks 2-4 tiles: that covers the
+    next-tile prefetch under the epilogue and the store-tolerant vmcnt bookkeeping."""
     ops = _ops()
     if kernel == "v3":
         monkeypatch.setenv("CLIPK_GEMM_V3", "1")

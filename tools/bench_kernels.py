@@ -52,7 +52,14 @@ GEMM_SHAPES = [  # (name, M, N, K, epilogue)
 def bench_gemm():
     """three arms, interleaved in one process: 128^2 kernel with the run-time epilogue (round-1 baseline), 128^2 with
     the specialised straight-line epilogue, 256^2 phase-interleaved kernel (CLIPK_GEMM_V3)"""
-    arms = (("v2gen", {"CLIPK_GEMM_EPI_GENERIC": "1"}), ("v2", {}), ("v3", {"CLIPK_GEMM_V3": "1"}))
+    arms = [("v2gen", {"CLIPK_GEMM_EPI_GENERIC": "1"}), ("v2", {}), ("v3", {"CLIPK_GEMM_V3": "1"})]
+    for ab in os.environ.get("BENCH_ABL", "").split():
+        arms.append(("v3a" + ab, {"CLIPK_GEMM_V3": "1", "CLIPK_GEMM_ABL": ab}))
+    for nw in os.environ.get("BENCH_NWG", "").split():
+        arms.append(("v3w" + nw, {"CLIPK_GEMM_V3": "1", "CLIPK_GEMM_NWG": nw}))
+        arms.append(("w%sa1" % nw, {"CLIPK_GEMM_V3": "1", "CLIPK_GEMM_NWG": nw, "CLIPK_GEMM_ABL": "1"}))
+    for st in os.environ.get("BENCH_STAGGER", "").split():
+        arms.append(("v3s" + st, {"CLIPK_GEMM_V3": "1", "CLIPK_GEMM_STAGGER": st}))
     print(f"{'shape':12s} {'M':>7s} {'N':>5s} {'K':>5s} {'epi':9s} | " + " | ".join(f"{n:>5s} us  TF/s" for n, _ in arms)
           + " | v2/v2gen v3/v2")
     tot = {n: 0.0 for n, _ in arms}
@@ -68,7 +75,7 @@ def bench_gemm():
             kw = {"dact_aux": rnd((M, N)), "dact": "gelu"}
         out = {}
         for n, env in arms:
-            for k in ("CLIPK_GEMM_EPI_GENERIC", "CLIPK_GEMM_V3"):
+            for k in ("CLIPK_GEMM_EPI_GENERIC", "CLIPK_GEMM_V3", "CLIPK_GEMM_STAGGER", "CLIPK_GEMM_ABL", "CLIPK_GEMM_NWG"):
                 os.environ.pop(k, None)
             os.environ.update(env)
             med, mn = timeit(lambda: ops.gemm_nt(a, b, **kw))
@@ -79,7 +86,7 @@ def bench_gemm():
               + " | ".join(f"{out[n] * 1e3:7.1f} {fl / out[n] / 1e9:5.0f}" for n, _ in arms)
               + f" | {out['v2gen'] / out['v2']:.2f}x {out['v2'] / out['v3']:.2f}x", flush=True)
         del a, b, kw
-    for k in ("CLIPK_GEMM_EPI_GENERIC", "CLIPK_GEMM_V3"):
+    for k in ("CLIPK_GEMM_EPI_GENERIC", "CLIPK_GEMM_V3", "CLIPK_GEMM_STAGGER", "CLIPK_GEMM_ABL", "CLIPK_GEMM_NWG"):
         os.environ.pop(k, None)
     print("sum: " + ", ".join(f"{n} {tot[n]:.2f} ms" for n, _ in arms))
 
