@@ -52,7 +52,8 @@ GEMM_SHAPES = [  # (name, M, N, K, epilogue)
 def bench_gemm():
     """three arms, interleaved in one process: 128^2 kernel with the run-time epilogue (round-1 baseline), 128^2 with
     the specialised straight-line epilogue, 256^2 phase-interleaved kernel (CLIPK_GEMM_V3)"""
-    arms = [("v2gen", {"CLIPK_GEMM_EPI_GENERIC": "1"}), ("v2", {}), ("v3", {"CLIPK_GEMM_V3": "1"})]
+    arms = [("v2gen", {"CLIPK_GEMM_EPI_GENERIC": "1", "CLIPK_GEMM_V3": "0"}), ("v2", {"CLIPK_GEMM_V3": "0"}),
+            ("v3", {"CLIPK_GEMM_V3": "1"})]
     for ab in os.environ.get("BENCH_ABL", "").split():
         arms.append(("v3a" + ab, {"CLIPK_GEMM_V3": "1", "CLIPK_GEMM_ABL": ab}))
     for nw in os.environ.get("BENCH_NWG", "").split():
