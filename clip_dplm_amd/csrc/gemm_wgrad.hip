@@ -18,6 +18,18 @@
 //   * the bias gradient rides along as one extra MFMA per n-tile against an all-ones B fragment in the
 //     k-tile-0 workgroups (no second pass over dY).
 #include "common.h"
+#include <stdlib.h>
+
+// gemm_wgrad_v3.hip: 256 x 256 output tiles, 8 waves, phase-interleaved (large problems)
+struct clipk_wgrad_v3_args {
+  const unsigned short* dY; long lddy;
+  const unsigned short* X; long ldx;
+  float* slab; float* bslab;
+  int M, N, K;
+  int ntn, ntk, splits, m_per_split;
+};
+extern "C" void clipk_wgrad_v3_plan(int M, int N, int K, int* ntn, int* ntk, int* splits, int* mps);
+extern "C" int clipk_wgrad_v3_launch(const clipk_wgrad_v3_args* a, void* stream);
 
 namespace {
 
@@ -215,12 +227,24 @@ Plan make_plan(int M, int N, int K) {
   return pl;
 }
 
+// large problems go to the 256 x 256 phase-interleaved kernel; CLIPK_WGRAD_V3 = 0 / 1 forces the choice
+bool use_v3(int M, int N, int K) {
+  const char* e = getenv("CLIPK_WGRAD_V3");
+  const int mode = e ? atoi(e) : -1;
+  if (mode == 0) return false;
+  if (mode == 1) return M >= 1024;
+  return M >= 16384 && N >= 128 && K >= 128;
+}
+
 }  // namespace
 
 extern "C" size_t clipk_gemm_wgrad_workspace(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const Plan pl = make_plan(M, N, K);
-  return (size_t)pl.splits * ((size_t)N * K + N) * sizeof(float);
+  int ntn, ntk, splits, mps;
+  clipk_wgrad_v3_plan(M, N, K, &ntn, &ntk, &splits, &mps);
+  const int smax = pl.splits > splits ? pl.splits : splits;    // either kernel may be chosen at launch time
+  return (size_t)smax * ((size_t)N * K + N) * sizeof(float);
 }
 
 extern "C" int clipk_gemm_wgrad(const void* dY, int64_t lddy, const void* X, int64_t ldx,
@@ -229,6 +253,24 @@ extern "C" int clipk_gemm_wgrad(const void* dY, int64_t lddy, const void* X, int
   if (!dY || !X || !dW || !workspace || M <= 0 || N <= 0 || K <= 0) return CLIPK_ERR_BAD_ARG;
   if ((N & 7) || (K & 7) || (lddy & 7) || (ldx & 7) || (lddw & 3)) return CLIPK_ERR_UNSUPPORTED;
   if (!aligned16(dY) || !aligned16(X) || !aligned16(dW) || !aligned16(workspace)) return CLIPK_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (use_v3(M, N, K)) {
+    clipk_wgrad_v3_args a;
+    clipk_wgrad_v3_plan(M, N, K, &a.ntn, &a.ntk, &a.splits, &a.m_per_split);
+    if (workspace_bytes < (size_t)a.splits * ((size_t)N * K + N) * sizeof(float)) return CLIPK_ERR_BAD_ARG;
+    a.dY = (const unsigned short*)dY; a.lddy = lddy;
+    a.X = (const unsigned short*)X; a.ldx = ldx;
+    a.slab = (float*)workspace;
+    a.bslab = dbias ? (float*)workspace + (size_t)a.splits * N * K : nullptr;
+    a.M = M; a.N = N; a.K = K;
+    int rc = clipk_wgrad_v3_launch(&a, stream);
+    if (rc) return rc;
+    long total4 = (long)N * K / 4;
+    int blocks = (int)((total4 + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)a.slab, (const float*)a.bslab,
+                       a.splits, N, K, dW, (long)lddw, dbias, accumulate);
+    return clipk_check_launch();
+  }
   const Plan pl = make_plan(M, N, K);
   const size_t need = (size_t)pl.splits * ((size_t)N * K + N) * sizeof(float);
   if (workspace_bytes < need) return CLIPK_ERR_BAD_ARG;
@@ -239,7 +281,6 @@ extern "C" int clipk_gemm_wgrad(const void* dY, int64_t lddy, const void* X, int
   p.bslab = dbias ? (float*)workspace + (size_t)pl.splits * N * K : nullptr;
   p.M = M; p.N = N; p.K = K;
   p.ntn = pl.ntn; p.ntk = pl.ntk; p.splits = pl.splits; p.m_per_split = pl.mps;
-  hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(wgrad_kernel, dim3(pl.ntn * pl.ntk * pl.splits), dim3(NTHREADS), LDS_BYTES, st, p);
   int rc = clipk_check_launch();
   if (rc) return rc;

@@ -1,0 +1,313 @@
+// gemm_wgrad_v3.hip — 256(n) x 256(k) output tile, 8 waves, phase-interleaved schedule for the weight gradient
+// dW[N,K] (+)= dY[M,N]^T · X[M,K], db[N] (+)= colsum(dY).  Same contract, slab layout and reduce kernel as
+// gemm_wgrad.hip, which selects this kernel for large problems (CLIPK_WGRAD_V3 forces the choice).
+//
+// The schedule is the one of gemm_nt_v3.hip (read its header first) with the roles
+//     activation half-tile "X mh"  ->  dY half "nh": the nh-th 64 columns of BOTH n-waves,   [64 m][128 cols]
+//     weight half-tile     "W nh"  ->  X  half "kh": the kh-th 32 columns of all four k-waves, [64 m][128 cols]
+// and one "K-tile" = 64 token rows m.  Differences that matter:
+//   * the contraction index m is the ROW index of both operands in memory, so both MFMA fragments come from
+//     ds_read_b64_tr_b16 (transposed LDS read) on the row-major half-tiles; the LDS image is the 256-byte-row,
+//     32-byte-segment XOR-swizzled one of gemm_wgrad.hip (conflict-free for those reads, tools/lds_conflicts.py);
+//   * a fragment is two 8-byte reads, so phase 0 issues 24 LDS reads; lgkmcnt saturates at 15, and
+//     lgkmcnt(15) retires at least the 8 reads of X kh0 issued first (the half-tile refilled one phase later);
+//   * LDS-DMA sources are buffer descriptors re-based per 64-row step (scalar work): rows past M fail the range
+//     check and load zeros, which is exactly what the contraction needs at the ragged end;
+//   * M is split over workgroups so that one launch puts ~one workgroup on every CU; each workgroup runs ONE long
+//     main loop (M / splits / 64 = 30..100 steps), so unlike the forward GEMM nothing needs to be persistent;
+//   * the bias gradient is 4 extra MFMAs per step and wave against an all-ones fragment: the four k-waves of an
+//     n-wave hold identical dY fragments, so each of them sums two of the eight n-tiles (8 VGPRs, not 32).
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+struct clipk_wgrad_v3_args {
+  const unsigned short* dY; long lddy;
+  const unsigned short* X; long ldx;
+  float* slab;        // [splits][N][K]
+  float* bslab;       // [splits][N] or null
+  int M, N, K;
+  int ntn, ntk, splits, m_per_split;
+};
+
+namespace {
+
+constexpr int BN = 256, BKO = 256, BMS = 64;
+constexpr int ROWB = 256;                               // LDS row bytes of a half-tile (128 bf16)
+constexpr int HALF_BYTES = BMS * ROWB;                  // 16 KiB
+constexpr int BUF_BYTES = 4 * HALF_BYTES;               // dY nh0 | dY nh1 | X kh0 | X kh1
+constexpr int LDS_BYTES = 2 * BUF_BYTES;                // 128 KiB
+constexpr int YH0 = 0, YH1 = HALF_BYTES, XH0 = 2 * HALF_BYTES, XH1 = 3 * HALF_BYTES;
+
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// Transposed reads are inline asm on purpose: for the ds_read_tr builtin hipcc (ROCm 7.2) cannot tell that the read
+// does not alias an LDS-DMA still in flight and puts s_waitcnt vmcnt(0) in front of every batch, which drains the
+// three half-tiles this schedule keeps in flight.  The counters are therefore managed by hand below: every batch is
+// followed (after the phase barrier) by s_waitcnt lgkmcnt(0) + sched_barrier before its first use.
+template <int OFF>
+__device__ __forceinline__ u32x2 ds_tr16(unsigned lds_addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF));
+  return v;
+}
+// 8 m-values of one column: rows r and r + 16 of the transposed-read block (address already swizzled for this lane)
+template <int OFF>
+__device__ __forceinline__ bf16x8 tr_pair(unsigned lds_addr) {
+  const u32x2 lo = ds_tr16<OFF>(lds_addr);
+  const u32x2 hi = ds_tr16<OFF + 16 * ROWB>(lds_addr);
+  const u32x4 f = {lo[0], lo[1], hi[0], hi[1]};
+  return __builtin_bit_cast(bf16x8, f);
+}
+
+// one quadrant: 4 n-tiles x 2 k-tiles x 2 m-halves = 16 MFMAs (m-half outer: dependent accumulations sit 8 apart)
+template <int KH, int NH>
+__device__ __forceinline__ void quad(f32x4 (&acc)[8][4], const bf16x8 (&yf)[4][2], const bf16x8 (&xf)[2][2][2]) {
+#pragma unroll
+  for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        acc[NH * 4 + t][KH * 2 + u] =
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[t][ms], xf[KH][u][ms], acc[NH * 4 + t][KH * 2 + u], 0, 0, 0);
+}
+
+#define CLIPK_BAR() __builtin_amdgcn_s_barrier()
+#define CLIPK_SB() __builtin_amdgcn_sched_barrier(0)
+
+__global__ __launch_bounds__(512, 1) void wgrad_v3_kernel(const clipk_wgrad_v3_args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wid >> 2, wk = wid & 3;
+  const int ntiles = p.ntn * p.ntk;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = bid / ntiles;
+  const int tile = bid - split * ntiles;
+  const int tn = tile / p.ntk, tk = tile - tn * p.ntk;
+  const int n0 = tn * BN, k0 = tk * BKO;
+  const int M = p.M, N = p.N, K = p.K;
+  const int m_beg = split * p.m_per_split;
+  int m_end = m_beg + p.m_per_split; m_end = m_end < M ? m_end : M;
+  const int nkt = (m_end - m_beg + BMS - 1) / BMS;             // >= 1
+  const bool do_bias = (p.bslab != nullptr) && (tk == 0);
+
+  // ---- LDS-DMA assignment: wave w fills pieces 2w, 2w+1 (4 rows x 256 B each) of every half-tile.
+  // lane -> (row in piece = lane>>4, physical 16-B slot = lane&15); the slot's 32-B segment (slot>>1) holds the
+  // logical segment (slot>>1) ^ (row&7).  Offsets are relative to (row m_t, first column of the half).
+  unsigned yv[2], xv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 4 * (2 * wid + i) + (lane >> 4);
+    const int slot = lane & 15;
+    const int col = (((slot >> 1) ^ (row & 7)) << 4) + (slot & 1) * 8;      // logical column of this 16-B chunk
+    yv[i] = (unsigned)(((long)row * p.lddy + (col >> 6) * 128 + (col & 63)) * 2);   // n-wave col>>6
+    xv[i] = (unsigned)(((long)row * p.ldx + (col >> 5) * 64 + (col & 31)) * 2);     // k-wave col>>5
+  }
+  const unsigned short* y_end = p.dY + ((long)(M - 1) * p.lddy + N);       // one past the last valid element
+  const unsigned short* x_end = p.X + ((long)(M - 1) * p.ldx + K);
+  // half-tile `half` of step T: descriptor based at (row m_beg + 64 T, first column of the half); everything from
+  // there to the end of the operand is in range, i.e. rows >= M (and only those) read as zero
+  auto stage = [&](bool is_y, int half, int T, int region) {
+    const long mt = (long)m_beg + (long)T * BMS;
+    const unsigned short* base = is_y ? p.dY + mt * p.lddy + (n0 + half * 64) : p.X + mt * p.ldx + (k0 + half * 32);
+    const long left = ((is_y ? y_end : x_end) - base) * 2;
+    const int bytes = left > 0 ? (int)(left < 0x7fffffffL ? left : 0x7fffffffL) : 0;
+    const auto d = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+    char* dst = smem + (T & 1) * BUF_BYTES + region + wid * 2048;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(d, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16,
+                                               (int)(is_y ? yv[i] : xv[i]), 0, 0, 0);
+  };
+
+  f32x4 acc[8][4];          // [n-tile i][k-tile j]: rows n = 4g+r, col k = lane&15
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 accb[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (short)0x3F80;          // bf16 1.0
+
+  // ---- transposed-read addressing.  Lane group g = lane>>4, in-group li = lane&15: the lane supplies row
+  // 4g + (li>>2) (+16, +32, +48) at byte 8 (li&3) of a 16-column segment.  Segment s of the wave sits at physical
+  // segment s ^ (row & 7), row & 7 = 4 (g&1) + (li>>2): an XOR of the segment's low bits with a lane constant, so
+  // one address register per segment of the quadrant and immediates for everything else.
+  const int g = lane >> 4, li = lane & 15;
+  const int trow = 4 * g + (li >> 2);
+  const int sw = trow & 7;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte address of smem
+  unsigned ya[4], xa[2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) ya[t] = lds0 + trow * ROWB + (((wn * 4 + t) ^ sw) << 5) + 8 * (li & 3);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) xa[u] = lds0 + trow * ROWB + (((wk * 2 + u) ^ sw) << 5) + 8 * (li & 3);
+
+  bf16x8 yf[4][2], xf[2][2][2];
+
+  // TM 0: steady state; 1: step nkt-2 (only the last half-tile of step nkt-1 left to fetch); 2: last step
+  auto step_body = [&](auto mode_c, int T) {
+    constexpr int TM = decltype(mode_c)::value;
+    const unsigned bo = (T & 1) * BUF_BYTES;
+    // ---- phase 0: quadrant (k0, n0); fetch X kh0 (8 reads, first) + dY nh0 (16 reads); refill dY nh1 of step T+1
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms)
+        xf[0][u][ms] = ms ? tr_pair<XH0 + 32 * ROWB>(xa[u] + bo) : tr_pair<XH0>(xa[u] + bo);
+    CLIPK_SB();
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms)
+        yf[t][ms] = ms ? tr_pair<YH0 + 32 * ROWB>(ya[t] + bo) : tr_pair<YH0>(ya[t] + bo);
+    if (TM <= 1) stage(true, 1, T + 1, YH1);
+    asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");         // >= 9 of 24 reads retired: all of X kh0
+    CLIPK_SB(); CLIPK_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    CLIPK_SB();
+    __builtin_amdgcn_s_setprio(1);
+    quad<0, 0>(acc, yf, xf);
+    __builtin_amdgcn_s_setprio(0);
+    CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
+    // ---- phase 1: quadrant (k1, n0); fetch X kh1; refill X kh0 of step T+2
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms)
+        xf[1][u][ms] = ms ? tr_pair<XH1 + 32 * ROWB>(xa[u] + bo) : tr_pair<XH1>(xa[u] + bo);
+    if (TM == 0) stage(false, 0, T + 2, XH0);
+    CLIPK_SB(); CLIPK_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    CLIPK_SB();
+    __builtin_amdgcn_s_setprio(1);
+    quad<1, 0>(acc, yf, xf);
+    if (do_bias && wk < 2) {                                    // n-tiles 0..3 are live: k-waves 0, 1 sum two each
+      if (wk == 0) {
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) {
+          accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[0][ms], ones, accb[0], 0, 0, 0);
+          accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[1][ms], ones, accb[1], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) {
+          accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[2][ms], ones, accb[0], 0, 0, 0);
+          accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[3][ms], ones, accb[1], 0, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
+    // ---- phase 2: quadrant (k1, n1); fetch dY nh1; refill dY nh0 of step T+2
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms)
+        yf[t][ms] = ms ? tr_pair<YH1 + 32 * ROWB>(ya[t] + bo) : tr_pair<YH1>(ya[t] + bo);
+    if (TM == 0) stage(true, 0, T + 2, YH0);
+    CLIPK_SB(); CLIPK_BAR();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    CLIPK_SB();
+    __builtin_amdgcn_s_setprio(1);
+    quad<1, 1>(acc, yf, xf);
+    __builtin_amdgcn_s_setprio(0);
+    CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
+    // ---- phase 3: quadrant (k0, n1); nothing to fetch; refill X kh1 of step T+2; step T+1 must be complete
+    if (TM == 0) {
+      stage(false, 1, T + 2, XH1);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else if (TM == 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
+    __builtin_amdgcn_s_setprio(1);
+    quad<0, 1>(acc, yf, xf);
+    if (do_bias && wk >= 2) {                                   // n-tiles 4..7 are live: k-waves 2, 3
+      if (wk == 2) {
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) {
+          accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[0][ms], ones, accb[0], 0, 0, 0);
+          accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[1][ms], ones, accb[1], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) {
+          accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[2][ms], ones, accb[0], 0, 0, 0);
+          accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[3][ms], ones, accb[1], 0, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
+  };
+
+  // ---- prologue: step 0 complete, three half-tiles of step 1 in flight
+  stage(false, 0, 0, XH0); stage(true, 0, 0, YH0); stage(false, 1, 0, XH1); stage(true, 1, 0, YH1);
+  if (nkt > 1) {
+    stage(false, 0, 1, XH0); stage(true, 0, 1, YH0); stage(false, 1, 1, XH1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
+  if (wn == 1) CLIPK_BAR();                                     // n = 1 waves run one barrier behind
+  for (int T = 0; T < nkt - 2; ++T) step_body(std::integral_constant<int, 0>{}, T);
+  if (nkt > 1) step_body(std::integral_constant<int, 1>{}, nkt - 2);
+  step_body(std::integral_constant<int, 2>{}, nkt - 1);
+  if (wn == 0) CLIPK_BAR();                                     // re-align
+
+  // ---- store the f32 partial tile: rows n (4 per lane), cols k (lane&15)
+  float* slab = p.slab + (long)split * N * K;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wn * 128 + i * 16 + 4 * g + r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = k0 + wk * 64 + j * 16 + li;
+        if (n < N && k < K) slab[(long)n * K + k] = acc[i][j][r];
+      }
+    }
+  if (do_bias && li == 0) {
+    // this k-wave summed n-tiles (wk & 1) * 2 + {0, 1} of half wk >> 1
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 128 + (wk >> 1) * 64 + ((wk & 1) * 2 + u) * 16 + 4 * g + r;
+        if (n < N) p.bslab[(long)split * N + n] = accb[u][r];
+      }
+  }
+}
+
+}  // namespace
+
+// plan: one workgroup per (tile, split), about one per CU; splits are multiples of 64 rows
+extern "C" void clipk_wgrad_v3_plan(int M, int N, int K, int* ntn, int* ntk, int* splits, int* mps) {
+  *ntn = (N + BN - 1) / BN; *ntk = (K + BKO - 1) / BKO;
+  const int ntiles = *ntn * *ntk;
+  int s = 256 / ntiles;
+  if (s < 1) s = 1;
+  const int max_splits = (M + 8 * BMS - 1) / (8 * BMS);         // at least 512 rows per split
+  if (s > max_splits) s = max_splits;
+  int m = (M + s - 1) / s;
+  m = (m + BMS - 1) / BMS * BMS;
+  *mps = m;
+  *splits = (M + m - 1) / m;
+}
+
+extern "C" int clipk_wgrad_v3_launch(const clipk_wgrad_v3_args* a, void* stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_v3_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wgrad_v3_kernel, dim3(a->ntn * a->ntk * a->splits), dim3(512), LDS_BYTES, (hipStream_t)stream, *a);
+  return clipk_check_launch();
+}

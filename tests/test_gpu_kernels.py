@@ -123,9 +123,13 @@ def test_gemm_nt_specialised_epilogues(dev, monkeypatch, kernel, M, N, K):
     assert torch.allclose(big[:M, :N].float(), ref + bias, **tol)
 
 
+@pytest.mark.parametrize("kernel", ["v2", "v3"])
 @pytest.mark.parametrize("M,N,K", [(512, 128, 128), (4096, 1440, 480), (1000, 360, 120), (8192, 480, 1920),
-                                   (300, 8, 16), (16384, 768, 768)])
-def test_gemm_wgrad(dev, M, N, K):
+                                   (300, 8, 16), (16384, 768, 768), (20000, 1440, 480), (1100, 264, 520)])
+def test_gemm_wgrad(dev, monkeypatch, kernel, M, N, K):
+    """128x128 kernel and the 256x256 phase-interleaved kernel (CLIPK_WGRAD_V3 = 1 takes every M >= 1024): ragged
+    N / K edges, a ragged last 64-row step (M = 20000, 1100), one- and two-step splits."""
+    monkeypatch.setenv("CLIPK_WGRAD_V3", "1" if kernel == "v3" else "0")
     ops = _ops()
     dy = _rand((M, N), dev, 8, 0.1, dtype=torch.bfloat16)
     x = _rand((M, K), dev, 9, dtype=torch.bfloat16)

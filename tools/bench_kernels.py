@@ -93,11 +93,21 @@ def bench_gemm():
 
 
 def bench_wgrad():
-    print(f"{'shape':12s} {'M':>7s} {'N':>5s} {'K':>5s} | us     TF/s")
+    print(f"{'shape':12s} {'M':>7s} {'N':>5s} {'K':>5s} |   v2 us  TF/s |   v3 us  TF/s | v3/v2")
+    tot = {"0": 0.0, "1": 0.0}
     for name, M, N, K, _ in GEMM_SHAPES[:8]:
         dy, x = rnd((M, N), scale=0.1), rnd((M, K))
-        med, mn = timeit(lambda: ops.gemm_wgrad(dy, x, want_bias=True))
-        print(f"{name:12s} {M:7d} {N:5d} {K:5d} | {med * 1e3:7.1f} {2.0 * M * N * K / med / 1e9:6.0f}")
+        out = {}
+        for ver in ("0", "1"):
+            os.environ["CLIPK_WGRAD_V3"] = ver
+            med, mn = timeit(lambda: ops.gemm_wgrad(dy, x, want_bias=True))
+            out[ver] = med
+            tot[ver] += med
+        fl = 2.0 * M * N * K
+        print(f"{name:12s} {M:7d} {N:5d} {K:5d} | {out['0'] * 1e3:7.1f} {fl / out['0'] / 1e9:5.0f} | "
+              f"{out['1'] * 1e3:7.1f} {fl / out['1'] / 1e9:5.0f} | {out['0'] / out['1']:.2f}x", flush=True)
+    os.environ.pop("CLIPK_WGRAD_V3", None)
+    print(f"sum: v2 {tot['0']:.2f} ms, v3 {tot['1']:.2f} ms")
 
 
 def bench_attn():
