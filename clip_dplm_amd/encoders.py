@@ -35,20 +35,34 @@ WGRAD_SIDE_STREAM = False
 _SIDE = {}
 
 
-def _wgrad(dy, x):
+DIRECT_PARAM_GRADS = True      # weight-gradient kernels accumulate straight into existing .grad buffers
+
+
+def _direct_ok(t):
+    g = t.grad if (t is not None and t.is_leaf) else None      # e.g. ESM's fused qkv weight is a cat(), not a leaf
+    return g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.device == t.device
+
+
+def _wgrad(dy, x, lin=None):
     """dW, db = wgrad(dy, x), optionally enqueued on the calling stream's side stream."""
+    # With pre-allocated .grad buffers (FusedAdamW keeps them as views of one flat buffer) the reduce kernel adds
+    # into them directly and autograd gets None: saves one torch `add` launch per parameter and step (289 of them
+    # in the config-2 model) and the temporary.  Same semantics as AccumulateGrad: grad += dW.
+    direct = DIRECT_PARAM_GRADS and lin is not None and _direct_ok(lin.w) and _direct_ok(lin.b)
+    kw = dict(dw=lin.w.grad, dbias=lin.b.grad, accumulate=True) if direct else dict(want_bias=True)
     if not (WGRAD_SIDE_STREAM and dy.is_cuda):
-        return ops.gemm_wgrad(dy, x, want_bias=True)
+        r = ops.gemm_wgrad(dy, x, **kw)
+        return (None, None) if direct else r
     cur = torch.cuda.current_stream()
     side = _SIDE.get(cur.cuda_stream)
     if side is None:
         side = _SIDE[cur.cuda_stream] = torch.cuda.Stream()
     side.wait_event(cur.record_event())            # dy / x are ready at this point of the calling stream
     with torch.cuda.stream(side):
-        dw, db = ops.gemm_wgrad(dy, x, want_bias=True)
+        dw, db = ops.gemm_wgrad(dy, x, **kw)
     dy.record_stream(side)
     x.record_stream(side)
-    return dw, db
+    return (None, None) if direct else (dw, db)
 
 
 def _join_side(*tensors):
@@ -96,16 +110,16 @@ def _esm_layer_bwd(dy, dyb, p, saved, meta, need_dx_bf16):
         dyb = ops.to_bf16(dy)
     gr = {}
     du = ops.gemm_nt(dyb, p["fc2"].wtb, dact_aux=u, dact="gelu")               # dgrad fused with GELU'
-    gr["fc2_w"], gr["fc2_b"] = _wgrad(dyb, g)
+    gr["fc2_w"], gr["fc2_b"] = _wgrad(dyb, g, p["fc2"])
     dh2 = ops.gemm_nt(du, p["fc1"].wtb)
-    gr["fc1_w"], gr["fc1_b"] = _wgrad(du, h2)
+    gr["fc1_w"], gr["fc1_b"] = _wgrad(du, h2, p["fc1"])
     dx2, dx2b, gr["ln2_w"], gr["ln2_b"] = ops.layernorm_bwd(dh2, x2, p["ln2_w"], None, m2, r2, dx_add=dy,
                                                             want_f32=True, want_bf16=True)
     dctx = ops.gemm_nt(dx2b, p["out"].wtb)
-    gr["out_w"], gr["out_b"] = _wgrad(dx2b, ctx)
+    gr["out_w"], gr["out_b"] = _wgrad(dx2b, ctx, p["out"])
     dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, H, D, key_mask=mask, rope=rope, q_scale=D ** -0.5)
     dh1 = ops.gemm_nt(dqkv, p["qkv"].wtb)
-    gr["qkv_w"], gr["qkv_b"] = _wgrad(dqkv, h1)
+    gr["qkv_w"], gr["qkv_b"] = _wgrad(dqkv, h1, p["qkv"])
     dx, dxb, gr["ln1_w"], gr["ln1_b"] = ops.layernorm_bwd(dh1, x, p["ln1_w"], None, m1, r1, dx_add=dx2,
                                                           want_f32=True, want_bf16=need_dx_bf16)
     return dx, dxb, gr
@@ -318,15 +332,15 @@ def _post_layer_bwd(dy, p, saved, meta):
     gr = {}
     ds2, ds2b, gr["n2_w"], gr["n2_b"] = ops.layernorm_bwd(dy, s2, p["n2_w"], None, m2, r2, want_f32=True, want_bf16=True)
     du = ops.gemm_nt(ds2b, p["fc2"].wtb, dact_aux=u, dact=act)
-    gr["fc2_w"], gr["fc2_b"] = _wgrad(ds2b, g)
+    gr["fc2_w"], gr["fc2_b"] = _wgrad(ds2b, g, p["fc2"])
     dx1 = ops.gemm_nt(du, p["fc1"].wtb, residual=ds2, out_dtype=torch.float32)      # + residual-path gradient
-    gr["fc1_w"], gr["fc1_b"] = _wgrad(du, x1b)
+    gr["fc1_w"], gr["fc1_b"] = _wgrad(du, x1b, p["fc1"])
     ds1, ds1b, gr["n1_w"], gr["n1_b"] = ops.layernorm_bwd(dx1, s1, p["n1_w"], None, m1, r1, want_f32=True, want_bf16=True)
     dctx = ops.gemm_nt(ds1b, p["out"].wtb)
-    gr["out_w"], gr["out_b"] = _wgrad(ds1b, ctx)
+    gr["out_w"], gr["out_b"] = _wgrad(ds1b, ctx, p["out"])
     dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, H, D, key_mask=mask, rope=None, q_scale=qs)
     dx = ops.gemm_nt(dqkv, p["in"].wtb, residual=ds1, out_dtype=torch.float32)
-    gr["in_w"], gr["in_b"] = _wgrad(dqkv, xb)
+    gr["in_w"], gr["in_b"] = _wgrad(dqkv, xb, p["in"])
     return dx, gr
 
 

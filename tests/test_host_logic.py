@@ -23,7 +23,10 @@ def relerr(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
 
 
-def test_protein_rna_clip_wiring_vs_oracle(monkeypatch):
+@pytest.mark.parametrize("direct_grads", [False, True])
+def test_protein_rna_clip_wiring_vs_oracle(monkeypatch, direct_grads):
+    """direct_grads: .grad buffers pre-allocated by FusedAdamW (views of the flat buffer), so the weight-gradient
+    kernels accumulate into them and autograd receives None for those parameters (encoders._wgrad)."""
     ops_emulator.install(monkeypatch)
     import clip_dplm_amd as K
     from clip_dplm_amd.encoders import ESM2_SHAPES
@@ -39,6 +42,10 @@ def test_protein_rna_clip_wiring_vs_oracle(monkeypatch):
     lens = torch.randint(6, L + 1, (B,), generator=g)
     pmask = (torch.arange(L)[None] < lens[:, None]).long()
     rmask = (torch.arange(L)[None] < lens.flip(0)[:, None]).long()
+    if direct_grads:
+        opt = K.FusedAdamW(m, lr=1e-3)
+        opt.zero_grad()
+        assert all(p.grad is not None for p in m.parameters())
     loss = m.loss(rna, ids, rna_mask=rmask, protein_mask=pmask)
     ref, _, _ = model_ref.protein_rna_clip_loss(sd, rna, ids, rmask, pmask, esm_layers=2, esm_heads=4, rna_layers=2,
                                                 rna_heads=8)
