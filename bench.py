@@ -184,7 +184,7 @@ def main():
         g = summ.get("gemm_nt")
         if g:
             achieved = g["work"] / (g["total_ms"] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 16x16x32 MFMA Linear fwd/dgrad)",
+            out["roofline"] = {"bound": "mfma", "kernel": "clipk_gemm_nt = gemm_nt_v3_kernel / gemm_nt_v2_kernel (bf16 16x16x32 MFMA Linear fwd/dgrad)",
                                "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
                                "avg_launch_us": round(g["avg_us"], 2), "launches": g["launches"],
