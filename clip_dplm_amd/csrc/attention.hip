@@ -63,6 +63,11 @@ template <int DP> struct Geo {
   static constexpr int DT = DP / 16;         // 16-wide d tiles
   static constexpr int NCH = DP / 8;         // 16-byte chunks per (padded) row
   static constexpr int KVB = (DP <= 96) ? 128 : 64;   // keys (or queries) per staged block
+  // minimum resident workgroups per CU asked of the register allocator.  Left alone hipcc spends 296 / 308 VGPRs on
+  // the D = 96 backward kernels (one wave per SIMD, every LDS / HBM latency exposed); capped at 256 they spill 32 /
+  // 72 registers and still run 1.3x faster (1330 -> 1010 us), D = 24: 915 -> 815 us backward, 380 -> 330 us forward
+  static constexpr int WG_FWD = (DP <= 32) ? 4 : (DP <= 96 ? 2 : 1);
+  static constexpr int WG_BWD = (DP <= 32) ? 3 : (DP <= 96 ? 2 : 1);
 };
 
 template <int NCH> struct RowRegs { u32x4 c[NCH]; };
@@ -168,7 +173,7 @@ struct PairStager {
 // forward: one workgroup = 128 queries of one (batch, head); 4 waves x 32 queries; KVB-key staged blocks
 // =================================================================================================
 template <int DP, int DR>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AP p) {
+__global__ __launch_bounds__(256, Geo<DP>::WG_FWD) void attn_fwd_kernel(const AP p) {
   constexpr int RS = Geo<DP>::RS, KS = Geo<DP>::KS, DT = Geo<DP>::DT, NCH = Geo<DP>::NCH, KVB = Geo<DP>::KVB;
   constexpr int NSUB = KVB / 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -360,7 +365,7 @@ __device__ __forceinline__ void store_grad_rows(const float* img, int ILD, unsig
 // backward dQ (+ delta): one workgroup = 128 queries, sweeps KVB-key blocks
 // =================================================================================================
 template <int DP, int DR>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AP p) {
+__global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dq_kernel(const AP p) {
   constexpr int RS = Geo<DP>::RS, KS = Geo<DP>::KS, DT = Geo<DP>::DT, NCH = Geo<DP>::NCH, KVB = Geo<DP>::KVB;
   constexpr int NSUB = KVB / 64, ILD = DP + 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -517,7 +522,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AP p) {
 // backward dK/dV: one workgroup = KVB keys (4 waves x KVB/4), sweeps KVB-query blocks
 // =================================================================================================
 template <int DP, int DR>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AP p) {
+__global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dkv_kernel(const AP p) {
   constexpr int RS = Geo<DP>::RS, KS = Geo<DP>::KS, DT = Geo<DP>::DT, KVB = Geo<DP>::KVB, ILD = DP + 4;
   constexpr int KTW = KVB / 64;                           // 16-key tiles per wave
   constexpr int KPW = 16 * KTW, QB = KVB, NS2 = QB / 32;
