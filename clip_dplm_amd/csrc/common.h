@@ -53,6 +53,36 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {     // Phi(x) + x phi(
   const float cdf = fmaf(copysignf(0.5f, x), erf_abs, 0.5f);
   return fmaf(x * 0.39894228040143267794f, e, cdf);
 }
+// Two elements at a time on the packed-f32 pipe (v_pk_fma_f32 / v_pk_mul_f32: 2 results per issue slot): 9 VALU + 2
+// transcendentals per element instead of 15 + 2.  Same arithmetic as gelu_parts, element for element.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float c) { return f32x2{c, c}; }
+__device__ __forceinline__ void gelu_parts2(f32x2 x, f32x2 ax, f32x2& erf_abs, f32x2& e) {
+  const f32x2 d = __builtin_elementwise_fma(splat2(0.3275911f * 0.70710678118654752440f), ax, splat2(1.0f));
+  const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  const f32x2 xx = (x * splat2(-0.72134752044448170368f)) * x;
+  e = f32x2{__builtin_amdgcn_exp2f(xx[0]), __builtin_amdgcn_exp2f(xx[1])};
+  f32x2 poly = __builtin_elementwise_fma(splat2(1.061405429f), t, splat2(-1.453152027f));
+  poly = __builtin_elementwise_fma(poly, t, splat2(1.421413741f));
+  poly = __builtin_elementwise_fma(poly, t, splat2(-0.284496736f));
+  poly = __builtin_elementwise_fma(poly, t, splat2(0.254829592f));
+  erf_abs = __builtin_elementwise_fma(-(poly * t), e, splat2(1.0f));
+}
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+  const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+  f32x2 erf_abs, e;
+  gelu_parts2(x, ax, erf_abs, e);
+  return __builtin_elementwise_fma(ax * splat2(0.5f), erf_abs, x * splat2(0.5f));
+}
+__device__ __forceinline__ f32x2 gelu_erf_grad2(f32x2 x) {
+  const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+  f32x2 erf_abs, e;
+  gelu_parts2(x, ax, erf_abs, e);
+  const f32x2 half_sgn = {copysignf(0.5f, x[0]), copysignf(0.5f, x[1])};
+  const f32x2 cdf = __builtin_elementwise_fma(half_sgn, erf_abs, splat2(0.5f));
+  return __builtin_elementwise_fma(x * splat2(0.39894228040143267794f), e, cdf);
+}
+
 __device__ __forceinline__ float act_apply(float x, int act) {
   if (act == CLIPK_ACT_RELU) return x > 0.f ? x : 0.f;
   if (act == CLIPK_ACT_GELU) return gelu_erf(x);

@@ -162,9 +162,10 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
 #pragma unroll
         for (int c = 0; c < 4; ++c) u[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = gelu_erf(v[c]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) o[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
+        for (int c = 0; c < 4; ++c) {
+          const f32x2 y = gelu_erf2(f32x2{v[2 * c], v[2 * c + 1]});           // packed-f32 pipe
+          o[c] = pack_bf16x2(y[0], y[1]);
+        }
         const unsigned offu = ok ? (unsigned)(((long)gm * p.ldp + gn) * 2) : OOB;
         const unsigned off = ok ? (unsigned)(((long)gm * p.ldc + gn) * 2) : OOB;
         __builtin_amdgcn_raw_buffer_store_b128(u, u_rsrc, offu, 0, 0);

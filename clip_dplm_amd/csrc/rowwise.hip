@@ -118,8 +118,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
   const float inv_n = 1.0f / (float)p.cols;
   for (int row = wave; row < p.rows; row += nwaves) {
     const float mean = p.mean[row], rstd = p.rstd[row];
-    f32x4 xh[VPL], gy[VPL];
+    f32x4 xh[VPL], gy[VPL], addv[VPL];
     float s1 = 0.f, s2 = 0.f;
+    // the residual-path gradient is only needed after the row reductions: issue its load with the others, so the
+    // row costs one memory round trip instead of two
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int c = lane + 64 * v;
+      addv[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.dx_add && c < nch) addv[v] = *reinterpret_cast<const f32x4*>(p.dx_add + (long)row * p.lddx + 4 * c);
+    }
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
       const int c = lane + 64 * v;
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
         f32x4 dx;
 #pragma unroll
         for (int e = 0; e < 4; ++e) dx[e] = rstd * (gy[v][e] - c1 - xh[v][e] * c2);
-        if (p.dx_add) dx += *reinterpret_cast<const f32x4*>(p.dx_add + (long)row * p.lddx + 4 * c);
+        dx += addv[v];
         if (p.dx_f32) *reinterpret_cast<f32x4*>(p.dx_f32 + (long)row * p.lddx + 4 * c) = dx;
         if (p.dx_bf16) store4_bf16(p.dx_bf16, (long)row * p.lddx + 4 * c, dx);
       }
@@ -257,12 +265,18 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* dy, const 
   }
 }
 
-int ln_blocks(int rows) {
+// one wave per row, 4 waves per block.  These kernels are pure HBM streams: they need ~72 KiB in flight per CU
+// (MI355X_MICROARCH.md) and a 480-wide f32 row is 1.9 KiB, i.e. >= 32 resident waves per CU.  The backward also
+// writes one [2][cols] partial row per block for dgamma / dbeta, hence its smaller cap.
+int ln_blocks_cap(int rows, int cap) {
   int b = (rows + 3) / 4;
-  if (b > 512) b = 512;
+  if (b > cap) b = cap;
   if (b < 1) b = 1;
   return b;
 }
+// backward: as many blocks as are resident at once (~80 VGPRs at VPL 2, ~140 at VPL 4), never a second round
+int ln_blocks(int rows, int cols) { return ln_blocks_cap(rows, cols <= 512 ? 1024 : (cols <= 1024 ? 768 : 512)); }
+int ln_blocks_fwd(int rows) { return ln_blocks_cap(rows, 2048); }
 
 template <int VPL, bool DYBF16, bool XBF16>
 void launch_ln_bwd(const LnBwd& p, int blocks, size_t lds, hipStream_t st) {
@@ -291,7 +305,7 @@ extern "C" int clipk_layernorm_fwd(const void* x, int x_dtype, int64_t ldx, cons
   if ((cols & 3) || (ldx & 3) || (ldy & 3)) return CLIPK_ERR_UNSUPPORTED;
   if (!aligned16(gamma) || !aligned16(beta)) return CLIPK_ERR_BAD_ARG;
   LnFwd p{x, (long)ldx, gamma, beta, eps, act, y_f32, y_bf16, (long)ldy, mean, rstd, rows, cols};
-  const int blocks = ln_blocks(rows);
+  const int blocks = ln_blocks_fwd(rows);
   hipStream_t st = (hipStream_t)stream;
 #define CALL(V)                                                                                   \
   if (x_dtype == CLIPK_BF16) hipLaunchKernelGGL((ln_fwd_kernel<V, true>), dim3(blocks), dim3(256), 0, st, p); \
@@ -302,7 +316,7 @@ extern "C" int clipk_layernorm_fwd(const void* x, int x_dtype, int64_t ldx, cons
 }
 
 extern "C" size_t clipk_layernorm_bwd_workspace(int rows, int cols) {
-  return (size_t)ln_blocks(rows) * 2 * cols * sizeof(float);
+  return (size_t)ln_blocks(rows, cols) * 2 * cols * sizeof(float);
 }
 
 extern "C" int clipk_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, const void* x, int x_dtype, int64_t ldx,
@@ -313,7 +327,7 @@ extern "C" int clipk_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, c
   if (!dy || !x || !gamma || !mean || !rstd || rows <= 0 || cols <= 0 || !workspace) return CLIPK_ERR_BAD_ARG;
   if (act != CLIPK_ACT_NONE && !beta) return CLIPK_ERR_BAD_ARG;
   if ((cols & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3)) return CLIPK_ERR_UNSUPPORTED;
-  const int blocks = ln_blocks(rows);
+  const int blocks = ln_blocks(rows, cols);
   if (workspace_bytes < (size_t)blocks * 2 * cols * sizeof(float)) return CLIPK_ERR_BAD_ARG;
   LnBwd p{dy, (long)lddy, x, (long)ldx, gamma, beta, mean, rstd, act, dx_add, dx_f32, dx_bf16, (long)lddx,
           (float*)workspace, rows, cols};

@@ -43,6 +43,15 @@ def _direct_ok(t):
     return g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.device == t.device
 
 
+def _ln_bwd(dy, x, w, b, mean, rstd, **kw):
+    """ops.layernorm_bwd whose dgamma / dbeta go straight into w.grad / b.grad when those buffers exist (then the
+    returned parameter grads are None, as in _wgrad)."""
+    if DIRECT_PARAM_GRADS and _direct_ok(w) and _direct_ok(b):
+        dx, dxb, _, _ = ops.layernorm_bwd(dy, x, w, None, mean, rstd, dgamma=w.grad, dbeta=b.grad, accumulate=True, **kw)
+        return dx, dxb, None, None
+    return ops.layernorm_bwd(dy, x, w, None, mean, rstd, **kw)
+
+
 def _wgrad(dy, x, lin=None):
     """dW, db = wgrad(dy, x), optionally enqueued on the calling stream's side stream."""
     # With pre-allocated .grad buffers (FusedAdamW keeps them as views of one flat buffer) the reduce kernel adds
@@ -113,15 +122,15 @@ def _esm_layer_bwd(dy, dyb, p, saved, meta, need_dx_bf16):
     gr["fc2_w"], gr["fc2_b"] = _wgrad(dyb, g, p["fc2"])
     dh2 = ops.gemm_nt(du, p["fc1"].wtb)
     gr["fc1_w"], gr["fc1_b"] = _wgrad(du, h2, p["fc1"])
-    dx2, dx2b, gr["ln2_w"], gr["ln2_b"] = ops.layernorm_bwd(dh2, x2, p["ln2_w"], None, m2, r2, dx_add=dy,
-                                                            want_f32=True, want_bf16=True)
+    dx2, dx2b, gr["ln2_w"], gr["ln2_b"] = _ln_bwd(dh2, x2, p["ln2_w"], p["ln2_b"], m2, r2, dx_add=dy,
+                                                  want_f32=True, want_bf16=True)
     dctx = ops.gemm_nt(dx2b, p["out"].wtb)
     gr["out_w"], gr["out_b"] = _wgrad(dx2b, ctx, p["out"])
     dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, H, D, key_mask=mask, rope=rope, q_scale=D ** -0.5)
     dh1 = ops.gemm_nt(dqkv, p["qkv"].wtb)
     gr["qkv_w"], gr["qkv_b"] = _wgrad(dqkv, h1, p["qkv"])
-    dx, dxb, gr["ln1_w"], gr["ln1_b"] = ops.layernorm_bwd(dh1, x, p["ln1_w"], None, m1, r1, dx_add=dx2,
-                                                          want_f32=True, want_bf16=need_dx_bf16)
+    dx, dxb, gr["ln1_w"], gr["ln1_b"] = _ln_bwd(dh1, x, p["ln1_w"], p["ln1_b"], m1, r1, dx_add=dx2,
+                                                want_f32=True, want_bf16=need_dx_bf16)
     return dx, dxb, gr
 
 
@@ -330,12 +339,12 @@ def _post_layer_bwd(dy, p, saved, meta):
     B, L, H, D, mask, act, eps, qs = meta
     xb, qkv, ctx, lse, s1, x1b, m1, r1, g, u, s2, m2, r2 = saved
     gr = {}
-    ds2, ds2b, gr["n2_w"], gr["n2_b"] = ops.layernorm_bwd(dy, s2, p["n2_w"], None, m2, r2, want_f32=True, want_bf16=True)
+    ds2, ds2b, gr["n2_w"], gr["n2_b"] = _ln_bwd(dy, s2, p["n2_w"], p["n2_b"], m2, r2, want_f32=True, want_bf16=True)
     du = ops.gemm_nt(ds2b, p["fc2"].wtb, dact_aux=u, dact=act)
     gr["fc2_w"], gr["fc2_b"] = _wgrad(ds2b, g, p["fc2"])
     dx1 = ops.gemm_nt(du, p["fc1"].wtb, residual=ds2, out_dtype=torch.float32)      # + residual-path gradient
     gr["fc1_w"], gr["fc1_b"] = _wgrad(du, x1b, p["fc1"])
-    ds1, ds1b, gr["n1_w"], gr["n1_b"] = ops.layernorm_bwd(dx1, s1, p["n1_w"], None, m1, r1, want_f32=True, want_bf16=True)
+    ds1, ds1b, gr["n1_w"], gr["n1_b"] = _ln_bwd(dx1, s1, p["n1_w"], p["n1_b"], m1, r1, want_f32=True, want_bf16=True)
     dctx = ops.gemm_nt(ds1b, p["out"].wtb)
     gr["out_w"], gr["out_b"] = _wgrad(ds1b, ctx, p["out"])
     dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, H, D, key_mask=mask, rope=None, q_scale=qs)
