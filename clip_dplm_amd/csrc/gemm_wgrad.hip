@@ -197,7 +197,15 @@ __global__ void wgrad_reduce_kernel(const float* slab, const float* bslab, int s
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += stride) {
     f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < splits; ++s) a += reinterpret_cast<const f32x4*>(slab + (long)s * N * K)[i];
+    const long sstride = (long)N * K / 4;
+    const f32x4* src = reinterpret_cast<const f32x4*>(slab) + i;
+    int s = 0;
+    for (; s + 4 <= splits; s += 4) {                        // four loads in flight; fixed summation order
+      const f32x4 v0 = src[(long)s * sstride], v1 = src[(long)(s + 1) * sstride];
+      const f32x4 v2 = src[(long)(s + 2) * sstride], v3 = src[(long)(s + 3) * sstride];
+      a += (v0 + v1) + (v2 + v3);
+    }
+    for (; s < splits; ++s) a += src[(long)s * sstride];
     const long n = i / k4; const int c = (int)(i - n * k4);
     f32x4* o = reinterpret_cast<f32x4*>(dW + n * lddw + 4 * c);
     *o = accumulate ? (*o + a) : a;
