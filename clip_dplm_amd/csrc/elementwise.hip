@@ -302,14 +302,17 @@ extern "C" int clipk_embed_fwd(const int64_t* ids, const float* table, const flo
 extern "C" int clipk_embed_bwd(const int64_t* ids, const float* dx, const float* row_scale, const uint8_t* mask,
                                int mask_token_id, float* dtable, int B, int L, int d, int V, void* stream) {
   if (!ids || !dx || !dtable || B <= 0 || L <= 0 || d <= 0 || V <= 0) return CLIPK_ERR_BAD_ARG;
-  int dc = (48 * 1024) / (V * (int)sizeof(float));           // columns per block so the private table is <= 48 KiB
+  // columns per block so that the private table is <= 16 KiB: the kernel streams B*L*d floats and needs many
+  // resident blocks (it ran one 48-KiB block per CU before: 0.3 TB/s); small vocabularies keep >= 64 columns
+  int dc = (16 * 1024) / (V * (int)sizeof(float));
+  if (dc < 64) dc = (48 * 1024) / (V * (int)sizeof(float));
   dc &= ~3;
   if (dc < 4) return CLIPK_ERR_UNSUPPORTED;                  // vocabulary too large for the LDS-table scheme
   if (dc > d) dc = d;
   const size_t lds = (size_t)V * dc * sizeof(float);
   const int nchunks = (d + dc - 1) / dc;
   long waves = (long)B * L;
-  int blocks = (int)((waves + 3) / 4); if (blocks > 256 / nchunks + 1) blocks = 256 / nchunks + 1; if (blocks < 1) blocks = 1;
+  int blocks = (int)((waves + 3) / 4); if (blocks > 1024 / nchunks + 1) blocks = 1024 / nchunks + 1; if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks, nchunks), dim3(256), lds, (hipStream_t)stream, ids, dx, row_scale, mask,
                      mask_token_id, dtable, B, L, d, V, dc);
   return clipk_check_launch();
