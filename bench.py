@@ -160,7 +160,7 @@ def main():
     if rank == 0:
         print(f"[bench] {args.steps} timed steps: {dt:.3f} s", file=sys.stderr, flush=True)
     if rank != 0:
-        if world > 1:
+        if dist.is_initialized():
             dist.destroy_process_group()
         return
 
@@ -198,7 +198,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(sd_cpu, {"rna_dim": 768, "esm_layers": nl, "esm_heads": h, "rna_layers": 6,
                                                     "rna_heads": 8}, L)
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -61,6 +61,7 @@ SIGNATURES = {
     "clipk_cast_f32_to_bf16": (_i, [_vp, _vp, _i64, _vp]),
     "clipk_cast_bf16_to_f32": (_i, [_vp, _vp, _i64, _vp]),
     "clipk_cast_transpose": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "clipk_cast_transpose_batched": (_i, [_vp, _i, _vp]),
     "clipk_act_fwd": (_i, [_vp, _vp, _i, _i64, _vp]),
     "clipk_act_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _vp]),
     "clipk_dact": (_i, [_vp, _i, _vp, _i, _vp, _i64, _vp]),

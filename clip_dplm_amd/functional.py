@@ -7,6 +7,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import weakref
+
 import torch
 
 from . import ops
@@ -21,13 +23,15 @@ def mark_weights_dirty() -> None:
 
 
 class WeightCache:
-    """bf16 W [N,K] and W^T [K,N] of an f32 master weight, refreshed lazily."""
+    """bf16 W [N,K] and W^T [K,N] of an f32 master weight, refreshed lazily (or all at once, refresh_weight_caches)."""
 
-    __slots__ = ("wb", "wtb", "key")
+    __slots__ = ("wb", "wtb", "key", "src", "__weakref__")
 
     def __init__(self):
         self.wb = self.wtb = None
         self.key = None
+        self.src = None                      # the master weight this cache was last built from
+        _CACHES.add(self)
 
     def get(self, w: torch.Tensor):
         key = (w.data_ptr(), w._version, _WEIGHT_EPOCH, tuple(w.shape))
@@ -38,7 +42,45 @@ class WeightCache:
             self.wb, self.wtb = ops.cast_transpose(src, w_out=self.wb if self.wb is not None and self.wb.shape == w.shape else None,
                                                    wt_out=self.wtb if self.wtb is not None and self.wtb.shape == (w.shape[1], w.shape[0]) else None)
             self.key = key
+            self.src = w
         return self.wb, self.wtb
+
+
+_CACHES = weakref.WeakSet()
+_BATCH_DESC = {}                             # (device, pointer tuple) -> int64 [n, 5] device descriptor table
+
+
+def refresh_weight_caches() -> int:
+    """Rebuild every stale bf16 copy in ONE kernel launch on the current stream.  Called by FusedAdamW.step() right
+    after the update: the lazy path costs one launch per weight (76 in the config-2 model) at the next forward.
+    Covers caches that already have their buffers and a contiguous leaf master weight; the rest stay lazy."""
+    todo = []
+    for c in list(_CACHES):
+        w = c.src
+        if w is None or c.wb is None or c.wtb is None or not w.is_cuda or not w.is_leaf or not w.is_contiguous():
+            continue
+        if w.dim() != 2 or c.wb.shape != w.shape:
+            continue
+        key = (w.data_ptr(), w._version, _WEIGHT_EPOCH, tuple(w.shape))
+        if key != c.key:
+            todo.append((c, w, key))
+    if not todo:
+        return 0
+    by_dev = {}
+    for item in todo:
+        by_dev.setdefault(item[1].device, []).append(item)
+    for dev, items in by_dev.items():
+        rows = tuple((w.data_ptr(), c.wb.data_ptr(), c.wtb.data_ptr(), w.shape[0], w.shape[1]) for c, w, _ in items)
+        desc = _BATCH_DESC.get((dev, rows))
+        if desc is None:
+            _BATCH_DESC.clear()              # pointers changed (new model / reallocated flat buffer)
+            desc = torch.tensor(rows, dtype=torch.int64).to(dev)
+            _BATCH_DESC[(dev, rows)] = desc
+        with torch.cuda.device(dev):
+            ops.cast_transpose_batched(desc)
+        for c, w, key in items:
+            c.key = key
+    return len(todo)
 
 
 def _bf16(x: torch.Tensor) -> torch.Tensor:

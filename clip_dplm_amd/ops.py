@@ -282,6 +282,13 @@ def cast_transpose(w: torch.Tensor, want_w=True, want_wt=True, w_out=None, wt_ou
     return wb, wt
 
 
+def cast_transpose_batched(desc: torch.Tensor):
+    """desc: int64 [n, 5] device tensor of (w_ptr, wb_ptr, wt_ptr, rows, cols): all n weights in one launch."""
+    _need_cuda(desc)
+    assert desc.dtype == torch.int64 and desc.dim() == 2 and desc.shape[1] == 5 and desc.is_contiguous()
+    check(_lib().clipk_cast_transpose_batched(desc.data_ptr(), desc.shape[0], _stream()), "clipk_cast_transpose_batched")
+
+
 def act_fwd(x, act):
     y = torch.empty_like(x)
     check(_lib().clipk_act_fwd(x.data_ptr(), y.data_ptr(), ACT[act], x.numel(), _stream()), "clipk_act_fwd")

@@ -17,6 +17,8 @@ from __future__ import annotations
 import math
 from typing import Iterable, List, Optional
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -108,7 +110,9 @@ class FusedAdamW:
         if self.group is not None:
             dist.all_gather_into_tensor(self.flat.data, w.clone() if dist.get_backend(self.group) == "gloo" else w,
                                         group=self.group)
-        KF.mark_weights_dirty()              # bf16 W / W^T copies are refreshed lazily at the next forward
+        KF.mark_weights_dirty()              # bf16 W / W^T copies of the Linear weights are stale now ...
+        if self.flat.data.is_cuda and os.environ.get("CLIPK_BATCH_REFRESH", "1") != "0":
+            KF.refresh_weight_caches()       # ... rebuild them in one launch (what is left is refreshed lazily)
         return self.norm_sq
 
     def state_dict(self):

@@ -155,6 +155,10 @@ int clipk_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 int clipk_cast_bf16_to_f32(const void* x, float* y, int64_t n, void* stream);
 /* W f32 [rows,cols] -> bf16 copy and bf16 transposed copy [cols,rows] (either may be NULL). */
 int clipk_cast_transpose(const float* w, void* w_bf16, void* wt_bf16, int rows, int cols, void* stream);
+/* The same for n weights in one launch (what `optimizer.step()` leaves to do before the next forward: the reference
+ * re-reads its f32 nn.Linear weights under autocast every step, old/clip.py:11).  desc_dev: device array of n
+ * records {w, w_bf16, wt_bf16, rows, cols}, five int64 each (pointers as integers, either output may be 0). */
+int clipk_cast_transpose_batched(const void* desc_dev, int n, void* stream);
 /* y = act(x) / dx = dy * act'(x) on f32. */
 int clipk_act_fwd(const float* x, float* y, int act, int64_t n, void* stream);
 int clipk_act_bwd(const float* dy, const float* x, float* dx, int act, int64_t n, void* stream);

@@ -147,6 +147,42 @@ def test_gemm_wgrad(dev, monkeypatch, kernel, M, N, K):
     assert torch.equal(dw3, dw)
 
 
+def test_cast_transpose_batched(dev):
+    """one launch over several weights == the per-weight kernel (ragged 64x64 tile edges included)"""
+    ops = _ops()
+    shapes = [(480, 480), (1440, 480), (100, 72), (8, 1920), (513, 65)]
+    ws = [_rand(sh, dev, 40 + i) for i, sh in enumerate(shapes)]
+    ref = [ops.cast_transpose(w) for w in ws]
+    outs = [(torch.zeros_like(a), torch.zeros_like(b)) for a, b in ref]
+    desc = torch.tensor([(w.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), w.shape[0], w.shape[1])
+                         for w, o in zip(ws, outs)], dtype=torch.int64).to(dev)
+    ops.cast_transpose_batched(desc)
+    for (a, b), (oa, ob) in zip(ref, outs):
+        assert torch.equal(a, oa) and torch.equal(b, ob)
+
+
+def test_weight_cache_batched_refresh(dev):
+    """FusedAdamW.step() refreshes all bf16 weight copies in one launch; the next forward must see the new weights"""
+    import clip_dplm_amd as K
+    from clip_dplm_amd import functional as KF
+    from types import SimpleNamespace as NS
+    torch.manual_seed(0)
+    sub = lambda h: NS(hidden_size=h, num_hidden_layers=2, layer_norm_eps=1e-12)
+    cfg = NS(rna_config=sub(64), protein_config=sub(64), diffmap_config=sub(64), projection_dim=32,
+             logit_scale_init_value=2.6592)
+    m = K.RNAProteinCLIPModule(cfg).to(dev).eval()
+    opt = K.FusedAdamW(m, lr=1e-2)
+    a, b = _rand((64, 64), dev, 50), _rand((64, 64), dev, 51)
+    opt.zero_grad(); m.loss(a, b, symmetric=True).backward(); opt.step()
+    stale = [c for c in KF._CACHES if c.src is not None and c.key != (c.src.data_ptr(), c.src._version, KF._WEIGHT_EPOCH,
+                                                                    tuple(c.src.shape))]
+    assert not stale                                     # everything was rebuilt by the step itself
+    for c in KF._CACHES:
+        if c.src is not None and c.wb is not None:
+            assert torch.equal(c.wb, c.src.detach().to(torch.bfloat16))
+            assert torch.equal(c.wtb, c.src.detach().t().contiguous().to(torch.bfloat16))
+
+
 # ------------------------------------------------------------------------------------------------ simce
 def _unit(shape, dev, seed):
     return F.normalize(_rand(shape, dev, seed), dim=-1).contiguous()
