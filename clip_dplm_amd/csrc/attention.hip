@@ -66,6 +66,11 @@ template <int DP> struct Geo {
   // minimum resident workgroups per CU asked of the register allocator.  Left alone hipcc spends 296 / 308 VGPRs on
   // the D = 96 backward kernels (one wave per SIMD, every LDS / HBM latency exposed); capped at 256 they spill 32 /
   // 72 registers and still run 1.3x faster (1330 -> 1010 us), D = 24: 915 -> 815 us backward, 380 -> 330 us forward
+  // Backward kernels: element-wise part two scores at a time on the packed-f32 pipe (v_pk_fma/add/mul) with the key
+  // mask folded into the exponent.  Measured and left OFF: D = 24 backward 820 -> 850 us (the pairs cost registers
+  // and moves), D = 96 dK/dV 72 -> 147 spilled VGPRs.  The forward kernel's packed softmax is unconditional
+  // (329 -> 315 us at D = 24, 323 -> 307 us at D = 96).
+  static constexpr bool PACKED_SOFTMAX = false;
   static constexpr int WG_FWD = (DP <= 32) ? 4 : (DP <= 96 ? 2 : 1);
   static constexpr int WG_BWD = (DP <= 32) ? 3 : (DP <= 96 ? 2 : 1);
 };
@@ -269,15 +274,22 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_FWD) void attn_fwd_kernel(const AP
         const float m_new = fmaxf(m_run[qt], mx);
         const bool dead = (m_new == -INFINITY);
         const float alpha = dead ? 1.f : fast_exp2((m_run[qt] - m_new) * c2);
-        float ls = 0.f;
+        // p = 2^(s c2 - m c2) as ONE fma per element; a dead row (everything masked so far) gets -inf as the
+        // addend, and a masked score is -inf itself: -inf + -inf = -inf, 2^-inf = 0, no select per element.
+        // Two elements per instruction on the packed-f32 pipe for the fma and the row sum.
+        const f32x2 mc = splat2(dead ? -INFINITY : -m_new * c2);
+        const f32x2 cc = splat2(c2);
+        f32x2 ls2 = {0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float pv = dead ? 0.f : fast_exp2((s[kt][qt][r] - m_new) * c2);
-            s[kt][qt][r] = pv;
-            ls += pv;
+          for (int r = 0; r < 4; r += 2) {
+            const f32x2 a = __builtin_elementwise_fma(f32x2{s[kt][qt][r], s[kt][qt][r + 1]}, cc, mc);
+            const f32x2 pv = {fast_exp2(a[0]), fast_exp2(a[1])};
+            s[kt][qt][r] = pv[0]; s[kt][qt][r + 1] = pv[1];
+            ls2 += pv;
           }
+        const float ls = ls2[0] + ls2[1];
         l_run[qt] = l_run[qt] * alpha + ls;
         m_run[qt] = m_new;
 #pragma unroll
@@ -464,16 +476,35 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dq_kernel(const
           dp[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[0][ks], dp[kt][0], 0, 0, 0);
           dp[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[1][ks], dp[kt][1], 0, 0, 0);
         }
+      // dS^T = P (dP - delta), P = 2^(s c2 - lse + kb), kb = 0 / -inf for a valid / masked key (one select per key
+      // row instead of one per element).  The two query tiles of a lane share the packed-f32 pipe: 4 packed
+      // instructions + 2 v_exp per element pair.
+      if constexpr (Geo<DP>::PACKED_SOFTMAX) {
+        const f32x2 cc = splat2(c2), nl = {-lse2[0], -lse2[1]}, dl2 = {dl[0], dl[1]};
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        const unsigned int mk = *reinterpret_cast<const unsigned int*>(mask_l + sub * 64 + kt * 16 + 4 * g);
+        for (int kt = 0; kt < 4; ++kt) {
+          const unsigned int mk = *reinterpret_cast<const unsigned int*>(mask_l + sub * 64 + kt * 16 + 4 * g);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool ok = ((mk >> (8 * r)) & 0xffu) != 0;
+          for (int r = 0; r < 4; ++r) {
+            const f32x2 kb = splat2(((mk >> (8 * r)) & 0xffu) ? 0.f : -INFINITY);
+            const f32x2 a = __builtin_elementwise_fma(f32x2{s[kt][0][r], s[kt][1][r]}, cc, nl) + kb;
+            const f32x2 pv = {fast_exp2(a[0]), fast_exp2(a[1])};
+            const f32x2 ds = pv * (f32x2{dp[kt][0][r], dp[kt][1][r]} - dl2);    // dS^T (w.r.t. the scaled score)
+            s[kt][0][r] = ds[0]; s[kt][1][r] = ds[1];
+          }
+        }
+      } else {
 #pragma unroll
-          for (int qt = 0; qt < 2; ++qt) {
-            const float pv = ok ? fast_exp2(s[kt][qt][r] * c2 - lse2[qt]) : 0.f;
-            s[kt][qt][r] = pv * (dp[kt][qt][r] - dl[qt]);          // dS^T (w.r.t. the scaled score)
+        for (int kt = 0; kt < 4; ++kt) {
+          const unsigned int mk = *reinterpret_cast<const unsigned int*>(mask_l + sub * 64 + kt * 16 + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = ((mk >> (8 * r)) & 0xffu) != 0;
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+              const float pv = ok ? fast_exp2(s[kt][qt][r] * c2 - lse2[qt]) : 0.f;
+              s[kt][qt][r] = pv * (dp[kt][qt][r] - dl[qt]);
+            }
           }
         }
       }
@@ -567,6 +598,9 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dkv_kernel(cons
     const int key = k0 + wid * KPW + kt * 16 + li;
     kvalid[kt] = key < L && (!p.key_mask || p.key_mask[(long)b * L + key]);
   }
+  float kbias[KTW];
+#pragma unroll
+  for (int kt = 0; kt < KTW; ++kt) kbias[kt] = kvalid[kt] ? 0.f : -INFINITY;
   __syncthreads();
 
   f32x4 dk[DT][KTW], dv[DT][KTW];
@@ -611,18 +645,40 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dkv_kernel(cons
           }
         }
       // rows of the accumulators are queries (4g+r), columns are this lane's key
+      if constexpr (Geo<DP>::PACKED_SOFTMAX) {
+        // P = 2^(s c2 - lse + kb[kt]) with kb = 0 / -inf for this lane's key; the two query tiles share the packed-
+        // f32 pipe (4 packed instructions + 2 v_exp per element pair, no select)
+        const f32x4 ls0 = *reinterpret_cast<const f32x4*>(lse_l + (2 * s2 + 0) * 16 + 4 * g);
+        const f32x4 ls1 = *reinterpret_cast<const f32x4*>(lse_l + (2 * s2 + 1) * 16 + 4 * g);
+        const f32x4 dd0 = *reinterpret_cast<const f32x4*>(dl_l + (2 * s2 + 0) * 16 + 4 * g);
+        const f32x4 dd1 = *reinterpret_cast<const f32x4*>(dl_l + (2 * s2 + 1) * 16 + 4 * g);
+        const f32x2 cc = splat2(c2);
 #pragma unroll
-      for (int qq = 0; qq < 2; ++qq) {
-        const f32x4 ls = *reinterpret_cast<const f32x4*>(lse_l + (2 * s2 + qq) * 16 + 4 * g);
-        const f32x4 dd = *reinterpret_cast<const f32x4*>(dl_l + (2 * s2 + qq) * 16 + 4 * g);
+        for (int r = 0; r < 4; ++r) {
+          const f32x2 nl = {-ls0[r], -ls1[r]}, dd = {dd0[r], dd1[r]};
 #pragma unroll
-        for (int kt = 0; kt < KTW; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float pv = kvalid[kt] ? fast_exp2(s[qq][kt][r] * c2 - ls[r]) : 0.f;
-            s[qq][kt][r] = pv;                                  // P
-            dp[qq][kt][r] = pv * (dp[qq][kt][r] - dd[r]);       // dS
+          for (int kt = 0; kt < KTW; ++kt) {
+            const f32x2 a = __builtin_elementwise_fma(f32x2{s[0][kt][r], s[1][kt][r]}, cc, nl) + splat2(kbias[kt]);
+            const f32x2 pv = {fast_exp2(a[0]), fast_exp2(a[1])};
+            const f32x2 ds = pv * (f32x2{dp[0][kt][r], dp[1][kt][r]} - dd);
+            s[0][kt][r] = pv[0]; s[1][kt][r] = pv[1];             // P
+            dp[0][kt][r] = ds[0]; dp[1][kt][r] = ds[1];           // dS
           }
+        }
+      } else {
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+          const f32x4 ls = *reinterpret_cast<const f32x4*>(lse_l + (2 * s2 + qq) * 16 + 4 * g);
+          const f32x4 dd = *reinterpret_cast<const f32x4*>(dl_l + (2 * s2 + qq) * 16 + 4 * g);
+#pragma unroll
+          for (int kt = 0; kt < KTW; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float pv = kvalid[kt] ? fast_exp2(s[qq][kt][r] * c2 - ls[r]) : 0.f;
+              s[qq][kt][r] = pv;                                  // P
+              dp[qq][kt][r] = pv * (dp[qq][kt][r] - dd[r]);       // dS
+            }
+        }
       }
 #pragma unroll
       for (int kt = 0; kt < KTW; ++kt) {
