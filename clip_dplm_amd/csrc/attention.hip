@@ -67,8 +67,8 @@ template <int DP> struct Geo {
   // the D = 96 backward kernels (one wave per SIMD, every LDS / HBM latency exposed); capped at 256 they spill 32 /
   // 72 registers and still run 1.3x faster (1330 -> 1010 us), D = 24: 915 -> 815 us backward, 380 -> 330 us forward
   // Backward kernels: element-wise part two scores at a time on the packed-f32 pipe (v_pk_fma/add/mul) with the key
-  // mask folded into the exponent.  Measured and left OFF: D = 24 backward 820 -> 850 us (the pairs cost registers
-  // and moves), D = 96 dK/dV 72 -> 147 spilled VGPRs.  The forward kernel's packed softmax is unconditional
+  // mask folded into the accumulator start value.  Measured and left OFF: D = 24 backward 816 -> 837 us (the pairs
+  // cost registers and moves), D = 96 dK/dV 72 -> 147 spilled VGPRs.  The forward kernel's packed softmax is unconditional
   // (329 -> 315 us at D = 24, 323 -> 307 us at D = 96).
   static constexpr bool PACKED_SOFTMAX = false;
   static constexpr int WG_FWD = (DP <= 32) ? 4 : (DP <= 96 ? 2 : 1);
@@ -464,7 +464,15 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dq_kernel(const
       const char* vt_ = vtile + sub * 64 * RS;
       f32x4 s[4][2], dp[4][2];
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) { s[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[kt][1] = s[kt][0]; dp[kt][0] = s[kt][0]; dp[kt][1] = s[kt][0]; }
+      for (int kt = 0; kt < 4; ++kt) {
+        // the S accumulators start at 0 / -inf for a valid / masked key (their rows are keys): the mask then costs
+        // nothing per score, 2^(-inf) = 0 falls out of the exponential
+        const unsigned int mk = *reinterpret_cast<const unsigned int*>(mask_l + sub * 64 + kt * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[kt][0][r] = ((mk >> (8 * r)) & 0xffu) ? 0.f : -INFINITY;
+        s[kt][1] = s[kt][0];
+        dp[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[kt][1] = dp[kt][0];
+      }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -483,11 +491,9 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dq_kernel(const
         const f32x2 cc = splat2(c2), nl = {-lse2[0], -lse2[1]}, dl2 = {dl[0], dl[1]};
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-          const unsigned int mk = *reinterpret_cast<const unsigned int*>(mask_l + sub * 64 + kt * 16 + 4 * g);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const f32x2 kb = splat2(((mk >> (8 * r)) & 0xffu) ? 0.f : -INFINITY);
-            const f32x2 a = __builtin_elementwise_fma(f32x2{s[kt][0][r], s[kt][1][r]}, cc, nl) + kb;
+            const f32x2 a = __builtin_elementwise_fma(f32x2{s[kt][0][r], s[kt][1][r]}, cc, nl);
             const f32x2 pv = {fast_exp2(a[0]), fast_exp2(a[1])};
             const f32x2 ds = pv * (f32x2{dp[kt][0][r], dp[kt][1][r]} - dl2);    // dS^T (w.r.t. the scaled score)
             s[kt][0][r] = ds[0]; s[kt][1][r] = ds[1];
@@ -495,18 +501,14 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dq_kernel(const
         }
       } else {
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-          const unsigned int mk = *reinterpret_cast<const unsigned int*>(mask_l + sub * 64 + kt * 16 + 4 * g);
+        for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const bool ok = ((mk >> (8 * r)) & 0xffu) != 0;
+          for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
-              const float pv = ok ? fast_exp2(s[kt][qt][r] * c2 - lse2[qt]) : 0.f;
-              s[kt][qt][r] = pv * (dp[kt][qt][r] - dl[qt]);
+              const float pv = fast_exp2(s[kt][qt][r] * c2 - lse2[qt]);
+              s[kt][qt][r] = pv * (dp[kt][qt][r] - dl[qt]);          // dS^T (w.r.t. the scaled score)
             }
-          }
-        }
       }
       bf16x8 db[2][2];
 #pragma unroll
@@ -630,7 +632,11 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dkv_kernel(cons
 #pragma unroll
       for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
-        for (int kt = 0; kt < KTW; ++kt) { s[qq][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qq][kt] = s[qq][kt]; }
+        for (int kt = 0; kt < KTW; ++kt) {
+          // columns of S are this lane's keys: start the accumulator at 0 / -inf for a valid / masked key
+          s[qq][kt] = f32x4{kbias[kt], kbias[kt], kbias[kt], kbias[kt]};
+          dp[qq][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -658,7 +664,7 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dkv_kernel(cons
           const f32x2 nl = {-ls0[r], -ls1[r]}, dd = {dd0[r], dd1[r]};
 #pragma unroll
           for (int kt = 0; kt < KTW; ++kt) {
-            const f32x2 a = __builtin_elementwise_fma(f32x2{s[0][kt][r], s[1][kt][r]}, cc, nl) + splat2(kbias[kt]);
+            const f32x2 a = __builtin_elementwise_fma(f32x2{s[0][kt][r], s[1][kt][r]}, cc, nl);
             const f32x2 pv = {fast_exp2(a[0]), fast_exp2(a[1])};
             const f32x2 ds = pv * (f32x2{dp[0][kt][r], dp[1][kt][r]} - dd);
             s[0][kt][r] = pv[0]; s[1][kt][r] = pv[1];             // P
@@ -674,7 +680,7 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dkv_kernel(cons
           for (int kt = 0; kt < KTW; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float pv = kvalid[kt] ? fast_exp2(s[qq][kt][r] * c2 - ls[r]) : 0.f;
+              const float pv = fast_exp2(s[qq][kt][r] * c2 - ls[r]);
               s[qq][kt][r] = pv;                                  // P
               dp[qq][kt][r] = pv * (dp[qq][kt][r] - dd[r]);       // dS
             }

@@ -27,6 +27,17 @@ elif which == "attn_esm":
     fr = torch.arange(L, dtype=torch.float32)[:, None] * inv[None]
     r = (fr.cos().contiguous().to(dev), fr.sin().contiguous().to(dev))
     f = lambda: ops.attn_fwd(qkv, B, L, H, D, rope=r, q_scale=D ** -0.5)
+if which in ("attn_esm_bwd", "attn_rna_bwd"):
+    B, L, H, D = (512, 256, 20, 24) if which == "attn_esm_bwd" else (512, 256, 8, 96)
+    qkv = rnd((B * L, 3 * H * D))
+    r = None
+    if which == "attn_esm_bwd":
+        inv = 1.0 / (10000 ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
+        fr = torch.arange(L, dtype=torch.float32)[:, None] * inv[None]
+        r = (fr.cos().contiguous().to(dev), fr.sin().contiguous().to(dev))
+    out, lse = ops.attn_fwd(qkv, B, L, H, D, rope=r, q_scale=D ** -0.5)
+    dout = rnd((B * L, H * D))
+    f = lambda: ops.attn_bwd(qkv, out, dout, lse, B, L, H, D, rope=r, q_scale=D ** -0.5)
 for _ in range(5):
     f()
 torch.cuda.synchronize()
