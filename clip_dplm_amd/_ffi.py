@@ -69,7 +69,8 @@ SIGNATURES = {
     "clipk_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "clipk_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "clipk_embed_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
-    "clipk_embed_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "clipk_embed_bwd_workspace": (_sz, [_i, _i, _i, _i]),
+    "clipk_embed_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "clipk_pool_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "clipk_pool_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "clipk_sumsq_workspace": (_sz, [_i64]),

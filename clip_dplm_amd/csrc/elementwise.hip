@@ -192,6 +192,115 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* ids, cons
   }
 }
 
+// ---- deterministic embedding gradient for small vocabularies (V <= 64: ESM-2 has 33 tokens) --------------------
+// dtable[V][d] += onehot(ids)^T [V x T] . (dx * sc) [T x d] on the exact-f32 matrix pipe (v_mfma_f32_32x32x2_f32):
+// the one-hot operand is built in registers from the ids, dx streams in as one float4 per lane and token (512 B per
+// token and wave), a wave owns 128 columns x a slice of tokens.  Slices are combined in a fixed order (4 waves
+// through LDS, then the slice partials by embed_bwd_reduce_kernel): no atomics, bitwise reproducible, and ~5x
+// faster than the LDS-atomic table below, which 33 hot rows serialise.
+constexpr int EB_COLS = 128;                             // columns per workgroup (4 interleaved strips of 32)
+__global__ __launch_bounds__(256, 3) void embed_bwd_mfma_kernel(const int64_t* ids, const float* dx, const float* row_scale,
+                                                             const uint8_t* mask, int mask_token_id, float* part,
+                                                             int B, int L, int d, int V, int tok_per_slice) {
+  __shared__ float red[3][64][33];                       // waves 1..3 hand their accumulators to wave 0, one at a time
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int cg = blockIdx.y, slice = blockIdx.x;
+  const long T = (long)B * L;
+  const long t_beg = (long)slice * tok_per_slice;
+  long t_end = t_beg + tok_per_slice; t_end = t_end < T ? t_end : T;
+  const int c0 = cg * EB_COLS + 4 * (lane & 31);         // this lane's 4 columns: strip j owns column c0 + j
+  const bool col_ok = c0 < d;                            // d % 4 == 0
+  const int kk = lane >> 5;                              // which token of the pair this lane feeds (MFMA k index)
+  const int vrow = lane & 31;
+  typedef __attribute__((ext_vector_type(16))) float f32x16;
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int vt = 0; vt < 2; ++vt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[vt][j][r] = 0.f;
+  // wave w takes token pairs w, w+4, ... of the slice, four pairs per iteration so that their loads are in flight
+  // together (the MFMAs of a pair depend on its load)
+  constexpr int U = 4;
+  for (long t0 = t_beg + 2 * wid; t0 < t_end; t0 += 8 * U) {
+    f32x4 v[U];
+    float a0[U], a1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long t = t0 + 8 * u + kk;
+      const bool tok_ok = t < t_end;
+      const unsigned tc = (unsigned)(tok_ok ? t : t_beg);      // B * L < 2^31 (launcher)
+      const int id = (int)ids[tc];
+      float sc = row_scale ? row_scale[tc / (unsigned)L] : 1.0f;
+      if (mask && !mask[tc]) sc = 0.f;
+      if (id == mask_token_id || !tok_ok) sc = 0.f;
+      v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (col_ok) v[u] = *reinterpret_cast<const f32x4*>(dx + (long)tc * d + c0);
+      a0[u] = (id == vrow) ? sc : 0.f;
+      a1[u] = (id == vrow + 32) ? sc : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], v[u][j], acc[0][j], 0, 0, 0);
+        if (V > 32) acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], v[u][j], acc[1][j], 0, 0, 0);
+      }
+  }
+  // C layout: lane holds column (lane & 31), rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5), r = 0..15
+  float* out = part + ((long)slice * V) * d;
+  const int nvt = V > 32 ? 2 : 1;
+#pragma unroll
+  for (int vt = 0; vt < 2; ++vt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (vt >= nvt) break;                              // block-uniform
+      // fixed-order sum over the 4 waves: waves 1..3 write, wave 0 adds in order 1, 2, 3
+      __syncthreads();
+      if (wid > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wid - 1][lane][r] = acc[vt][j][r];
+      }
+      __syncthreads();
+      if (wid == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float sum = ((acc[vt][j][r] + red[0][lane][r]) + red[1][lane][r]) + red[2][lane][r];
+          const int row = vt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int col = cg * EB_COLS + 4 * (lane & 31) + j;
+          if (row < V && col < d) out[(long)row * d + col] = sum;
+        }
+      }
+    }
+}
+// dtable[i] += sum over slices of part[s][i], fixed order.  Block = 16 elements x 16 slice groups, 8 loads in flight
+// per thread (a thread per element with a serial loop over 256 slices is a 100-us latency chain).
+__global__ __launch_bounds__(256) void embed_bwd_reduce_kernel(const float* part, int nslices, long n, float* dtable) {
+  __shared__ float sm[16][17];
+  const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const long i = (long)blockIdx.x * 16 + c;
+  float a = 0.f;
+  if (i < n) {
+    int s = rg;
+    for (; s + 7 * 16 < nslices; s += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(long)(s + 16 * u) * n + i];
+      a += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; s < nslices; s += 16) a += part[(long)s * n + i];
+  }
+  sm[rg][c] = a;
+  __syncthreads();
+  if (rg == 0 && i < n) {
+    a = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a += sm[r][c];
+    dtable[i] += a;
+  }
+}
+
 // ---- pooling ------------------------------------------------------------------------------------
 __global__ void pool_fwd_kernel(const float* x, const uint8_t* mask, float* y, int B, int L, int d, int mode) {
   const int b = blockIdx.y;
@@ -339,11 +448,38 @@ extern "C" int clipk_embed_fwd(const int64_t* ids, const float* table, const flo
                      ids, table, row_scale, mask, mask_token_id, x, B, L, d);
   return clipk_check_launch();
 }
+static int embed_bwd_slices(int B, int L) {
+  long T = (long)B * L;
+  int s = (int)((T + 511) / 512);                            // >= 512 tokens per slice, ~4 workgroups per CU at d = 480
+  if (s > 256) s = 256;
+  if (s < 1) s = 1;
+  return s;
+}
+extern "C" size_t clipk_embed_bwd_workspace(int B, int L, int d, int V) {
+  if (B <= 0 || L <= 0 || d <= 0 || V <= 0 || V > 64) return 0;   // larger vocabularies use the LDS-table kernel
+  return (size_t)embed_bwd_slices(B, L) * V * d * sizeof(float);
+}
 extern "C" int clipk_embed_bwd(const int64_t* ids, const float* dx, const float* row_scale, const uint8_t* mask,
-                               int mask_token_id, float* dtable, int B, int L, int d, int V, void* stream) {
+                               int mask_token_id, float* dtable, int B, int L, int d, int V, void* workspace,
+                               size_t workspace_bytes, void* stream) {
   if (!ids || !dx || !dtable || B <= 0 || L <= 0 || d <= 0 || V <= 0) return CLIPK_ERR_BAD_ARG;
+  if (V <= 64 && (d & 3) == 0 && workspace && aligned16(dx)) {
+    const int slices = embed_bwd_slices(B, L);
+    if (workspace_bytes < (size_t)slices * V * d * sizeof(float)) return CLIPK_ERR_BAD_ARG;
+    const long T = (long)B * L;
+    int tps = (int)((T + slices - 1) / slices);
+    tps = (tps + 31) & ~31;                                  // whole iterations of 4 waves x 4 pairs
+    if ((long)B * L >= (1L << 31)) return CLIPK_ERR_UNSUPPORTED;
+    const int ncg = (d + EB_COLS - 1) / EB_COLS;
+    hipLaunchKernelGGL(embed_bwd_mfma_kernel, dim3(slices, ncg), dim3(256), 0, (hipStream_t)stream, ids, dx, row_scale,
+                       mask, mask_token_id, (float*)workspace, B, L, d, V, tps);
+    const long n = (long)V * d;
+    hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3((int)((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, slices, n, dtable);
+    return clipk_check_launch();
+  }
   // columns per block so that the private table is <= 16 KiB: the kernel streams B*L*d floats and needs many
-  // resident blocks (it ran one 48-KiB block per CU before: 0.3 TB/s); small vocabularies keep >= 64 columns
+  // resident blocks; small vocabularies keep >= 64 columns
   int dc = (16 * 1024) / (V * (int)sizeof(float));
   if (dc < 64) dc = (48 * 1024) / (V * (int)sizeof(float));
   dc &= ~3;
@@ -357,7 +493,6 @@ extern "C" int clipk_embed_bwd(const int64_t* ids, const float* dx, const float*
                      mask_token_id, dtable, B, L, d, V, dc);
   return clipk_check_launch();
 }
-
 extern "C" int clipk_pool_fwd(const float* x, const uint8_t* mask, float* y, int B, int L, int d, int mode, void* stream) {
   if (!x || !y || B <= 0 || L <= 0 || d <= 0) return CLIPK_ERR_BAD_ARG;
   hipLaunchKernelGGL(pool_fwd_kernel, dim3((d + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, mask, y, B, L, d, mode);

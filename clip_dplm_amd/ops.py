@@ -355,8 +355,12 @@ def embed_fwd(ids, table, row_scale=None, mask=None, mask_token_id=-1):
 def embed_bwd(ids, dx, dtable, row_scale=None, mask=None, mask_token_id=-1):
     B, L = ids.shape
     V, d = dtable.shape
-    check(_lib().clipk_embed_bwd(ids.data_ptr(), dx.data_ptr(), ptr(row_scale), ptr(mask), mask_token_id,
-                                 dtable.data_ptr(), B, L, d, V, _stream()), "clipk_embed_bwd")
+    lib = _lib()
+    nbytes = lib.clipk_embed_bwd_workspace(B, L, d, V)
+    ws = workspace(nbytes, dx.device, "embed") if nbytes else None
+    check(lib.clipk_embed_bwd(ids.data_ptr(), dx.data_ptr(), ptr(row_scale), ptr(mask), mask_token_id,
+                              dtable.data_ptr(), B, L, d, V, ptr(ws), ws.numel() if ws is not None else 0, _stream()),
+          "clipk_embed_bwd")
     return dtable
 
 

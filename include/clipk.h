@@ -191,9 +191,13 @@ int clipk_attn_bwd(const void* qkv, const uint8_t* key_mask, const float* rope_c
 int clipk_embed_fwd(const int64_t* ids, const float* table, const float* row_scale /*[B] or NULL*/,
                     const uint8_t* mask /*[B*L] or NULL*/, int mask_token_id,
                     float* x, int B, int L, int d, void* stream);
+/* dtable[V,d] += sum over tokens (torch embedding backward).  V <= 64 (ESM-2: 33): one-hot product on the exact-f32
+ * matrix pipe with fixed-order reductions, bitwise reproducible, needs the workspace below; larger vocabularies (or
+ * workspace == NULL): per-block LDS tables + float atomics. */
+size_t clipk_embed_bwd_workspace(int B, int L, int d, int V);
 int clipk_embed_bwd(const int64_t* ids, const float* dx, const float* row_scale, const uint8_t* mask,
-                    int mask_token_id, float* dtable /* [V,d], accumulated */, int B, int L, int d, int V,
-                    void* stream);
+                    int mask_token_id, float* dtable, int B, int L, int d, int V,
+                    void* workspace, size_t workspace_bytes, void* stream);
 
 /* Pooling over the sequence: mode 0 = position 0 (rna_clip_codes.ipynb:1948), 1 = masked mean
  * (configuration_hybrid_clip.py:109 use_mean_pooling).  x f32 [B,L,d] -> y f32 [B,d]. */

@@ -15,4 +15,5 @@ e.record(); torch.cuda.synchronize()
 print('embed_bwd us', s.elapsed_time(e)*100)
 ref=torch.zeros(V,d,device=dev); ref.index_add_(0, ids.view(-1), dx)
 tab.zero_(); run()
+t1=tab.clone(); tab.zero_(); run(); print('bitwise reproducible', torch.equal(t1, tab))
 print('maxerr', (tab-ref).abs().max().item(), ref.abs().max().item())
