@@ -257,6 +257,38 @@ def test_training_step_is_bitwise_reproducible(dev, dual_stream):
     assert out[0][1].abs().sum().item() > 0
 
 
+def test_large_tile_kernels_agree_with_small_tile_kernels_in_the_model(dev, monkeypatch):
+    """The persistent 256x256 Linear kernel and the 256x256 weight-gradient kernel (picked automatically at
+    benchmark scale) against the 128x128 kernels, which the golden-vector tests above pin to the reference: same
+    model, same inputs, loss within 2e-4 and every parameter gradient with cosine > 0.9999 (both accumulate exact
+    bf16 products in f32, only the summation order differs)."""
+    import clip_dplm_amd as K
+    from clip_dplm_amd.encoders import ESM2_SHAPES
+    ESM2_SHAPES["test_repro"] = (2, 480, 20, 1920)
+    torch.manual_seed(0)
+    m = K.ProteinRNACLIP(esm="test_repro", rna_dim=768, rna_layers=1, rna_heads=8, rna_ffn=2048, projection_dim=128).eval()
+    m = m.to(dev)
+    B, L = 64, 256
+    g = torch.Generator().manual_seed(7)
+    ids = torch.randint(4, 24, (B, L), generator=g).to(dev)
+    rna = torch.randn(B, L, 768, generator=g).to(dev)
+    res = {}
+    for tag, v in (("small", "0"), ("large", "1")):
+        monkeypatch.setenv("CLIPK_GEMM_V3", v)
+        monkeypatch.setenv("CLIPK_WGRAD_V3", v)
+        m.zero_grad(set_to_none=True)
+        loss = m.loss(rna, ids)
+        loss.backward()
+        res[tag] = (loss.item(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert abs(res["small"][0] - res["large"][0]) < 2e-4, (res["small"][0], res["large"][0])
+    for n, ga in res["small"][1].items():
+        gb = res["large"][1][n]
+        if ga.abs().max() < 1e-12:
+            continue
+        cos = torch.nn.functional.cosine_similarity(ga.flatten().double(), gb.flatten().double(), dim=0).item()
+        assert cos > 0.9999, (n, cos)
+
+
 def test_fused_adamw_training_reduces_loss(dev):
     """A few fused optimiser steps on config 1: loss goes down, flat grads are used, weights stay in sync."""
     import clip_dplm_amd as K
