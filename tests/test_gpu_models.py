@@ -281,6 +281,18 @@ def test_large_tile_kernels_agree_with_small_tile_kernels_in_the_model(dev, monk
         loss.backward()
         res[tag] = (loss.item(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
     assert abs(res["small"][0] - res["large"][0]) < 2e-4, (res["small"][0], res["large"][0])
+    # and the large-tile path against the CPU oracle directly (loss bar 1e-3, as everywhere)
+    from oracle import clip_ref, encoder_ref
+    sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    ones = torch.ones(B, L, dtype=torch.bool)
+    esd = {k[len("protein_model."):]: v for k, v in sd.items() if k.startswith("protein_model.")}
+    hp = encoder_ref.esm_encoder(ids.cpu(), ones.long(), esd, 2, 20, 1e-5)
+    rsd = {k[len("rna_model."):]: v for k, v in sd.items() if k.startswith("rna_model.")}
+    hr = encoder_ref.post_ln_encoder(rna.cpu(), {"e." + k: v for k, v in rsd.items()}, "e", 1, 8, ones, "gelu", 1e-12, 1e-12)
+    er = clip_ref.l2_normalize(clip_ref.projection_head(encoder_ref.pool(hr, ones, "mean"), sd, "rna_projection"))
+    ep = clip_ref.l2_normalize(clip_ref.projection_head(encoder_ref.pool(hp, ones, "mean"), sd, "protein_projection"))
+    ref = clip_ref.clip_loss_symmetric((er @ ep.t()) * sd["logit_scale"].exp()).item()
+    assert abs(res["large"][0] - ref) < 1e-3, (res["large"][0], ref)
     for n, ga in res["small"][1].items():
         gb = res["large"][1][n]
         if ga.abs().max() < 1e-12:
