@@ -1,4 +1,4 @@
-"""ICNN transport maps (BASELINE config 5) on the libclipk kernels — inference path.
+"""ICNN transport maps (BASELINE config 5) on the libclipk kernels.
 
 Mirror of triple_flow/2_icnn_core.py (ConvexLayer :42-127, SingleCellICNN :129-241) and
 triple_flow/4_transport_maps.py (TransportCost :46-87, SingleCellTransport :89-145, TripleTransportMaps :147-224,
@@ -14,11 +14,16 @@ act'(.) and the normalisation Jacobian in one pass):
     z_k = act(LN_k(a_k));  Psi = w z_K + b
     dz_K = w;  da_k = LNact_bwd(dz_k);  dx^ += da_k W_k;  dz_{k-1} = c_k * da_k softplus(V_k + eps);  T = LN_bwd(dx^)
 
-Scope: eval-mode forward (`model.eval()`), i.e. the map itself.  The reference's train-time
-extras — the data-dependent no_grad rescale of the z-contribution (2_icnn_core.py:113-117), the per-row norm clip of
-T (:203-209) and back-propagation THROUGH T (double backward) — are not built; calling a module in training mode
-raises instead of silently computing something else.  Only the working family of architectures is supported
-(hidden_dims[:-1] == input_dim).
+Two paths, selected by `module.training`:
+  * eval (the map itself): everything above on hand-written kernels, no autograd graph;
+  * train: the reference's training branch — data-dependent no_grad rescale of the z contribution
+    (2_icnn_core.py:113-117; the rescaled contribution is a constant for autograd there, reproduced here), per-row
+    norm clip of T (:203-209), cost on the normalised target (4_transport_maps.py:124-143) — with back-propagation
+    THROUGH T, i.e. second derivatives of Psi.  Every matrix product of that path (forward, first and second
+    order) runs on the exact-f32 MFMA kernel through `_MatmulNT`, an autograd Function whose backward is built from
+    itself and is therefore differentiable again; the element-wise glue on [B, hidden] tensors (LayerNorm, CELU /
+    softplus and their first / second derivatives) is ATen's, because torch.autograd has to differentiate it twice.
+Only the working family of architectures is supported (hidden_dims[:-1] == input_dim).
 """
 from __future__ import annotations
 
@@ -27,6 +32,7 @@ from typing import Dict, List, Optional, Union
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import ops
 
@@ -56,10 +62,42 @@ class TransportOutput:                 # 4_transport_maps.py:39-44
     metrics: Optional[Dict[str, float]] = None
 
 
-def _no_training(m: nn.Module):
-    if m.training:
-        raise NotImplementedError("clip_dplm_amd.icnn implements the eval-mode transport map; call .eval() "
-                                  "(training through T needs double backward — not built, see DESIGN.md)")
+class _MatmulNT(torch.autograd.Function):
+    """C = A @ B^T in exact f32 on clipk_gemm_f32_nt.  backward() is written with _MatmulNT itself (plus transposed
+    copies), so autograd can differentiate it again: that is what training through T(x) = dPsi/dx needs."""
+
+    KMAX = 512      # the kernel keeps one operand row block in LDS: contraction length <= 768 and a multiple of 4
+
+    @staticmethod
+    def _mm(a, b):
+        out = None
+        for k0 in range(0, a.shape[1], _MatmulNT.KMAX):       # long contractions (dW over a large batch): chunk + add
+            ak, bk = a[:, k0:k0 + _MatmulNT.KMAX], b[:, k0:k0 + _MatmulNT.KMAX]
+            if ak.shape[1] % 4:
+                pad = 4 - ak.shape[1] % 4
+                ak, bk = F.pad(ak, (0, pad)), F.pad(bk, (0, pad))
+            out = ops.gemm_f32_nt(ak.contiguous(), bk.contiguous(), addend=out)
+        return out
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return _MatmulNT._mm(a.float(), b.float())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = _MatmulNT.apply(g, b.t().contiguous())                       # g @ b
+        if ctx.needs_input_grad[1]:
+            db = _MatmulNT.apply(g.t().contiguous(), a.t().contiguous())      # g^T @ a
+        return da, db
+
+
+def _linear_f32(x, weight, bias=None):
+    y = _MatmulNT.apply(x, weight)
+    return y if bias is None else y + bias
 
 
 class ConvexLayer(nn.Module):
@@ -79,6 +117,21 @@ class ConvexLayer(nn.Module):
     def get_positive_weights(self) -> torch.Tensor:
         """softplus(W+ + eps) (:84-86); the eps shift is a [out,in] elementwise add (plumbing), softplus a kernel."""
         return ops.act_fwd((self.pos_weights.detach() + self.config.eps).contiguous(), "softplus")
+
+    def forward(self, x: torch.Tensor, z: Optional[torch.Tensor] = None, scale: Optional[float] = None) -> torch.Tensor:
+        """Differentiable (train-mode) layer, 2_icnn_core.py:88-127."""
+        y = _linear_f32(x, self.linear.weight, self.linear.bias)
+        if z is not None:
+            scale = scale if scale is not None else self.scale
+            zc = _linear_f32(z, F.softplus(self.pos_weights + self.config.eps)) * scale
+            if self.training:
+                with torch.no_grad():                     # as in the reference: the rescaled tensor is a constant
+                    zs = zc.abs().mean()
+                    if zs > self.config.gradient_clip:
+                        zc = zc * (self.config.gradient_clip / zs)
+            y = y + zc
+        y = self.norm(y)
+        return F.softplus(y) if self.config.activation == "softplus" else F.celu(y)
 
 
 class SingleCellICNN(nn.Module):
@@ -122,14 +175,33 @@ class SingleCellICNN(nn.Module):
         return psi, (x, xh, m0, r0, saved, act)
 
     def forward(self, x: torch.Tensor, return_intermediates: bool = False):
-        _no_training(self)
-        psi, _ = self._forward(x)
-        return psi, None
+        if not self.training:
+            psi, _ = self._forward(x)
+            return psi, None
+        x = self.input_norm(x.float())                    # differentiable path (:156-179)
+        inter = [] if return_intermediates else None
+        z = None
+        for layer in self.layers:
+            z = layer(x, z)
+            if return_intermediates:
+                inter.append(z)
+        return _linear_f32(z, self.final.weight, self.final.bias), inter
+
+    def gradient(self, x: torch.Tensor, create_graph: bool = True) -> torch.Tensor:
+        """T(x) = dPsi/dx.  Eval: hand-derived on kernels, no graph.  Train: autograd.grad with create_graph (:181-211),
+        then the per-row norm clip."""
+        if self.training:
+            with torch.enable_grad():
+                if not x.requires_grad:
+                    x = x.detach().requires_grad_(True)
+                y = self.forward(x)[0]
+                grad, = torch.autograd.grad(y.sum(), x, create_graph=create_graph, retain_graph=True)
+            gn = grad.norm(dim=-1, keepdim=True)
+            return torch.where(gn > self.config.gradient_clip, grad * self.config.gradient_clip / gn, grad)
+        return self._gradient_eval(x)
 
     @torch.no_grad()
-    def gradient(self, x: torch.Tensor, create_graph: bool = True) -> torch.Tensor:
-        """T(x) = dPsi/dx (eval mode: no norm clip)."""
-        _no_training(self)
+    def _gradient_eval(self, x: torch.Tensor) -> torch.Tensor:
         _, (x, xh, m0, r0, saved, act) = self._forward(x)
         B = x.shape[0]
         dz = self.final.weight.detach().expand(B, -1).contiguous()           # d Psi / d z_K = w
@@ -152,8 +224,15 @@ class TransportCost(nn.Module):
         super().__init__()
         self.regularization = regularization
 
-    @torch.no_grad()
     def forward(self, source: torch.Tensor, target: torch.Tensor):
+        if torch.is_grad_enabled() and (source.requires_grad or target.requires_grad):
+            w2 = torch.norm(source - target, dim=-1).mean()                   # training: autograd needs the graph
+            sparsity = self.regularization * (torch.norm(source, p=1, dim=-1).mean() + torch.norm(target, p=1, dim=-1).mean())
+            return w2 + sparsity, {"w2_cost": w2.item(), "sparsity_cost": sparsity.item()}
+        return self._forward_value(source, target)
+
+    @torch.no_grad()
+    def _forward_value(self, source: torch.Tensor, target: torch.Tensor):
         _, n = ops.l2norm_fwd((source - target).contiguous())                # row L2 norms from the normalise kernel
         w2 = n.mean()
         sparsity = self.regularization * (source.abs().sum(-1).mean() + target.abs().sum(-1).mean())
@@ -171,9 +250,17 @@ class SingleCellTransport(nn.Module):
         self.input_norm = nn.LayerNorm(input_dim)
         self.output_norm = nn.LayerNorm(output_dim)
 
-    @torch.no_grad()
     def forward(self, source: torch.Tensor, target: Optional[torch.Tensor] = None):
-        _no_training(self)
+        if self.training:                                 # 4_transport_maps.py:113-145, differentiable
+            transported = self.output_norm(self.transport_net.gradient(self.input_norm(source.float())))
+            if target is not None:
+                cost, metrics = self.cost_fn(transported, self.output_norm(target.float()))
+                return TransportOutput(transported=transported, cost=cost, metrics=metrics)
+            return transported
+        return self._forward_eval(source)
+
+    @torch.no_grad()
+    def _forward_eval(self, source: torch.Tensor):
         s, _, _, _ = ops.layernorm_fwd(source.contiguous().float(), self.input_norm.weight, self.input_norm.bias,
                                        self.input_norm.eps, want_stats=False)
         t = self.transport_net.gradient(s)
@@ -184,7 +271,7 @@ class SingleCellTransport(nn.Module):
     @torch.no_grad()
     def cost(self, source: torch.Tensor, target: torch.Tensor) -> TransportOutput:
         """The value the reference's training branch reports (:135-143), without the train-only ICNN tweaks."""
-        transported = self.forward(source)
+        transported = self._forward_eval(source)
         tgt, _, _, _ = ops.layernorm_fwd(target.contiguous().float(), self.output_norm.weight, self.output_norm.bias,
                                          self.output_norm.eps, want_stats=False)
         c, metrics = self.cost_fn(transported, tgt)
@@ -192,8 +279,8 @@ class SingleCellTransport(nn.Module):
 
 
 class TripleTransportMaps(nn.Module):
-    """4_transport_maps.py:147-224 (eval): the three maps; the reference's ConsistencyChecker calls a tensor
-    (App. A-12) and only runs in training, so it is not part of this path."""
+    """4_transport_maps.py:147-224: the three maps.  The reference's ConsistencyChecker calls a tensor (App. A-12), so
+    its training call with all three modalities raises; the same error is raised here."""
 
     def __init__(self, cell_dim: int, pert_dim: int, protein_dim: int, config: ICNNConfig):
         super().__init__()
@@ -202,7 +289,10 @@ class TripleTransportMaps(nn.Module):
         self.pert_to_protein = SingleCellTransport(pert_dim, protein_dim, config)
 
     def forward(self, cell_states, pert_states=None, protein_states=None) -> Dict[str, Union[torch.Tensor, TransportOutput]]:
-        _no_training(self)
+        if self.training and pert_states is not None and protein_states is not None:
+            # the reference's ConsistencyChecker calls a tensor (`pert_protein(cell_pert)`, :242) and raises TypeError
+            raise TypeError("'Tensor' object is not callable  (reference 4_transport_maps.py:242: training with all three "
+                            "modalities is broken upstream, SURVEY App. A-12; train two modalities per call)")
         out = {}
         if pert_states is not None:
             out["cell_to_pert"] = self.cell_to_pert(cell_states, pert_states)

@@ -348,8 +348,70 @@ def test_icnn_transport_golden(dev):
     cref, _, _ = icnn_ref.transport_cost(t(z, "out_cell_to_pert"), tgt)
     assert abs(c.cost.item() - cref.item()) < 1e-3
     model.train()
-    with pytest.raises(NotImplementedError):
-        model(t(z, "cell", dev), t(z, "pert", dev))
+    with pytest.raises(TypeError):                         # the reference's 3-modality training call is broken (A-12)
+        model(t(z, "cell", dev), t(z, "pert", dev), t(z, "protein", dev))
+
+
+@pytest.mark.parametrize("case", ["A", "B"])
+def test_icnn_training_through_transport_map_golden(dev, case):
+    """BASELINE config 5, training branch: cost and d cost / d parameters THROUGH T(x) = dPsi/dx (second derivatives
+    of Psi) vs the reference's double backward (golden, tools/make_golden.py gen_icnn_train).  Case A: no train-time
+    rescale, every parameter gets a gradient; case B: the rescale fires in the last layer, whose z contribution the
+    reference then treats as a constant.  In both some rows of T are norm-clipped.  Every matrix product (forward,
+    first and second order) runs on the exact-f32 MFMA kernel; tolerance 2e-4 relative to the largest entry."""
+    from clip_dplm_amd import icnn
+    zf = np.load(os.path.join(G, "icnn_train.npz"))
+    pre = case + ":"
+    sd = {k[len(pre) + 2:]: torch.from_numpy(zf[k]) for k in zf.files if k.startswith(pre + "w:")}
+    m = icnn.SingleCellTransport(64, 64, icnn.ICNNConfig(input_dim=64, hidden_dims=[64, 64, 32]))
+    m.load_state_dict(sd)
+    m = m.to(dev).train()
+    src, tgt = torch.from_numpy(zf[pre + "source"]).to(dev), torch.from_numpy(zf[pre + "target"]).to(dev)
+    out = m(src, tgt)
+    assert isinstance(out, icnn.TransportOutput)
+    assert (out.transported.detach().cpu() - torch.from_numpy(zf[pre + "transported"])).abs().max().item() < 2e-4
+    assert abs(out.cost.item() - float(zf[pre + "cost"])) < 2e-4
+    assert abs(out.metrics["w2_cost"] - float(zf[pre + "w2"])) < 2e-4
+    assert abs(out.metrics["sparsity_cost"] - float(zf[pre + "sparsity"])) < 2e-4
+    out.cost.backward()
+    n_with_grad = 0
+    for name, p in m.named_parameters():
+        ref = torch.from_numpy(zf[pre + "g:" + name])
+        got = torch.zeros_like(ref) if p.grad is None else p.grad.detach().cpu()
+        scale = max(ref.abs().max().item(), 1e-6)
+        assert (got - ref).abs().max().item() < 2e-4 * max(scale, 1.0), (name, (got - ref).abs().max().item(), scale)
+        n_with_grad += int(ref.abs().max().item() > 0)
+    assert n_with_grad == (23 if case == "A" else 11)
+    # eval mode of the same module is the kernel-only path and differs from train (no rescale / clip): still runs
+    m.eval()
+    assert m(src).shape == (24, 64)
+
+
+def test_icnn_training_large_ragged_batch_vs_oracle(dev):
+    """Batch 1030 (not a multiple of 4, longer than one contraction chunk of the f32 kernel): the weight-gradient
+    products of the double backward are chunked and zero-padded; cost and gradients vs the CPU oracle."""
+    from clip_dplm_amd import icnn
+    from oracle import icnn_ref
+    torch.manual_seed(5)
+    m = icnn.SingleCellTransport(64, 64, icnn.ICNNConfig(input_dim=64, hidden_dims=[64, 32]))
+    with torch.no_grad():
+        m.transport_net.layers[1].pos_weights.normal_(0, 0.5)
+        m.transport_net.layers[1].scale.fill_(0.05)
+        m.transport_net.final.weight.mul_(2.0)
+    g = torch.Generator().manual_seed(6)
+    src, tgt = torch.randn(1030, 64, generator=g), torch.randn(1030, 64, generator=g)
+    sd = {"t." + k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    _, cref, _, _ = icnn_ref.single_cell_transport_train(src, tgt, sd, "t", 2)
+    cref.backward()
+    m = m.to(dev).train()
+    out = m(src.to(dev), tgt.to(dev))
+    assert abs(out.cost.item() - cref.item()) < 2e-4
+    out.cost.backward()
+    for name, p in m.named_parameters():
+        ref = sd["t." + name].grad
+        ref = torch.zeros_like(p.detach().cpu()) if ref is None else ref
+        got = torch.zeros_like(ref) if p.grad is None else p.grad.detach().cpu()
+        assert (got - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item()), name
 
 
 def test_esm_projections_golden(dev):

@@ -18,6 +18,9 @@ CASES = [
     ("protein_rna", T.test_protein_rna_clip_vs_oracle, {}),
     ("adamw_train", T.test_fused_adamw_training_reduces_loss, {}),
     ("icnn", T.test_icnn_transport_golden, {}),
+    ("icnn_train_A", T.test_icnn_training_through_transport_map_golden, {"case": "A"}),
+    ("icnn_train_B", T.test_icnn_training_through_transport_map_golden, {"case": "B"}),
+    ("icnn_train_ragged", T.test_icnn_training_large_ragged_batch_vs_oracle, {}),
     ("esm_proj", T.test_esm_projections_golden, {}),
 ]
 

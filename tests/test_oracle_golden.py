@@ -121,6 +121,27 @@ def test_analytic_properties():
     assert abs(clip_ref.clip_loss_symmetric(s * 0).item() - np.log(64)) < 1e-6
 
 
+def test_icnn_training_branch():
+    """Oracle's train-mode restatement (rescale under no_grad = constant, row-norm clip, cost) incl. the gradients
+    through T vs the reference's double backward (golden), both fixture cases."""
+    from oracle import icnn_ref
+    zf = np.load(os.path.join(G, "icnn_train.npz"))
+    for case in ("A", "B"):
+        pre = case + ":"
+        sd = {"t." + k[len(pre) + 2:]: torch.from_numpy(zf[k]).clone().requires_grad_(True) for k in zf.files
+              if k.startswith(pre + "w:")}
+        tr, cost, w2, sp = icnn_ref.single_cell_transport_train(torch.from_numpy(zf[pre + "source"]),
+                                                                torch.from_numpy(zf[pre + "target"]), sd, "t", 3)
+        assert torch.allclose(tr.detach(), torch.from_numpy(zf[pre + "transported"]), atol=2e-5)
+        assert abs(cost.item() - float(zf[pre + "cost"])) < 2e-5
+        cost.backward()
+        for k in zf.files:
+            if k.startswith(pre + "g:"):
+                g = sd["t." + k[len(pre) + 2:]].grad
+                g = torch.zeros_like(torch.from_numpy(zf[k])) if g is None else g
+                assert torch.allclose(g, torch.from_numpy(zf[k]), atol=5e-5), k
+
+
 def test_icnn_transport_maps():
     """triple_flow ICNN transport maps (eval): oracle vs the reference's autograd-of-autograd outputs."""
     from oracle import icnn_ref

@@ -241,8 +241,56 @@ def gen_icnn():
         o = icnn_ref.single_cell_transport(src, sd, name, 3)
         check(f"icnn {name}", o, out[name].detach(), 2e-5)
     psi = model.cell_to_pert.transport_net(model.cell_to_pert.input_norm(cell))[0].detach()
+    gen_icnn_train(tm, icnn_ref)
     save("icnn_transport.npz", cell=cell.numpy(), pert=pert.numpy(), protein=prot.numpy(), psi_cell_to_pert=psi.numpy(),
          **{"out_" + k: v.detach().numpy() for k, v in out.items()}, **sd_np(model))
+
+
+def gen_icnn_train(tm, icnn_ref):
+    """Training branch of ONE transport map (the reference's 3-modality training call is broken):
+    cost, metrics and d cost / d parameters through T = dPsi/dx (double backward).  Two cases: A = no train-time
+    rescale (every parameter receives a gradient), B = the rescale fires in the last layer (the reference then treats
+    the rescaled z contribution as a constant, so only the last layer's x-path parameters get gradients).  Some, not
+    all, rows of T exceed the clip norm in both."""
+    cfg = tm.ICNNConfig(input_dim=64, hidden_dims=[64, 64, 32])
+    arrays = {}
+    for case, (s1, s2, fmul) in (("A", (0.05, 0.05, 2.0)), ("B", (0.05, 0.8, 2.2))):
+        torch.manual_seed(3)
+        m = tm.SingleCellTransport(64, 64, cfg).train()
+        with torch.no_grad():
+            for mod in m.modules():
+                if hasattr(mod, "pos_weights"):
+                    mod.pos_weights.normal_(0, 0.5)
+            m.transport_net.layers[1].scale.fill_(s1)
+            m.transport_net.layers[2].scale.fill_(s2)
+            m.transport_net.final.weight.mul_(fmul)
+        g = torch.Generator().manual_seed(22)
+        src, tgt = torch.randn(24, 64, generator=g), torch.randn(24, 64, generator=g)
+        out = m(src.clone(), tgt.clone())
+        out.cost.backward()
+        sd = {"t." + k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+        t, cost, w2, sp = icnn_ref.single_cell_transport_train(src, tgt, sd, "t", 3)
+        check(f"icnn train {case} transported", t.detach(), out.transported.detach(), 2e-5)
+        check(f"icnn train {case} cost", cost.detach(), out.cost.detach(), 2e-5)
+        cost.backward()
+        for k, v in m.named_parameters():
+            if v.grad is not None:
+                check(f"icnn train {case} grad " + k, sd["t." + k].grad, v.grad, 5e-5)
+        with torch.no_grad():
+            s = m.input_norm(src)
+        sreq = s.clone().requires_grad_(True)
+        raw = torch.autograd.grad(m.transport_net.forward(sreq)[0].sum(), sreq)[0]
+        n_clip = int((raw.norm(dim=-1) > cfg.gradient_clip).sum())
+        with_grad = sorted(k for k, v in m.named_parameters() if v.grad is not None and v.grad.abs().max() > 0)
+        print(f"  train fixture {case}: {n_clip}/24 rows of T norm-clipped; {len(with_grad)} parameters with gradients")
+        arrays.update({f"{case}:source": src.numpy(), f"{case}:target": tgt.numpy(),
+                       f"{case}:transported": out.transported.detach().numpy(), f"{case}:cost": out.cost.detach().numpy(),
+                       f"{case}:w2": np.float32(out.metrics["w2_cost"]),
+                       f"{case}:sparsity": np.float32(out.metrics["sparsity_cost"]), f"{case}:rows_clipped": np.int32(n_clip)})
+        arrays.update({f"{case}:g:" + k: (v.grad.detach().numpy() if v.grad is not None else np.zeros(tuple(v.shape), np.float32))
+                       for k, v in m.named_parameters()})
+        arrays.update({f"{case}:w:" + k: v.detach().numpy() for k, v in m.state_dict().items()})
+    save("icnn_train.npz", **arrays)
 
 
 def gen_esm_projections():
