@@ -153,6 +153,20 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     ops.set_kernel_timer(None)
+    # With two HIP streams a kernel's event time includes the other tower's kernels it shares (or waits for) the chip
+    # with.  For reference, two more steps OUTSIDE the timed region with both towers on one stream: the same kernels
+    # timed alone (reported next to the timed-region numbers, never instead of them).
+    timer_alone = None
+    if timer is not None and model.dual_stream and rank == 0 and world == 1:
+        model.dual_stream = False
+        step(); torch.cuda.synchronize()
+        timer_alone = ops.KernelTimer()
+        ops.set_kernel_timer(timer_alone)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        ops.set_kernel_timer(None)
+        model.dual_stream = True
     tmax = torch.tensor([dt], device=device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -189,6 +203,14 @@ def main():
                                "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
                                "avg_launch_us": round(g["avg_us"], 2), "launches": g["launches"],
                                "share_of_step": round(g["total_ms"] / (1e3 * dt), 4)}
+            if timer_alone is not None:
+                ga = timer_alone.summary().get("gemm_nt")
+                if ga:
+                    ach = ga["work"] / (ga["total_ms"] * 1e-3) / 1e12
+                    out["roofline"]["one_stream"] = {"achieved": round(ach, 2), "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                                                     "avg_launch_us": round(ga["avg_us"], 2), "launches": ga["launches"],
+                                                     "note": "same kernels, 2 extra steps outside the timed region "
+                                                             "with both towers on one HIP stream"}
         out["kernels"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),
                               "share_of_step": round(v["total_ms"] / (1e3 * dt), 4),
                               "rate": round(v["work"] / (v["total_ms"] * 1e-3) / 1e12, 3),
