@@ -43,6 +43,30 @@ def _direct_ok(t):
     return g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.device == t.device
 
 
+def _fused_views(parts):
+    """[p0, p1, p2] stored back to back (FusedAdamW's flat buffer honours flat_param_groups) with .grad views laid
+    out the same way -> (data view, grad view) of the concatenation along dim 0, zero-copy; else None."""
+    p0 = parts[0]
+    if not all(q.is_leaf and q.requires_grad and q.grad is not None and q.is_contiguous() and q.grad.is_contiguous()
+               and q.dtype == torch.float32 and q.grad.dtype == torch.float32 for q in parts):
+        return None
+    d_ptr, g_ptr = p0.data_ptr(), p0.grad.data_ptr()
+    for q in parts:
+        if q.data_ptr() != d_ptr or q.grad.data_ptr() != g_ptr or q.shape[1:] != p0.shape[1:]:
+            return None
+        d_ptr += q.numel() * 4
+        g_ptr += q.numel() * 4
+    rows = sum(q.shape[0] for q in parts)
+    shape = (rows,) + tuple(p0.shape[1:])
+    stride = p0.stride()
+    try:
+        data = torch.as_strided(p0.data, shape, stride)
+        grad = torch.as_strided(p0.grad, shape, stride)
+    except RuntimeError:                                       # views would leave the storage: not back to back
+        return None
+    return data, grad
+
+
 def _ln_bwd(dy, x, w, b, mean, rstd, **kw):
     """ops.layernorm_bwd whose dgamma / dbeta go straight into w.grad / b.grad when those buffers exist (then the
     returned parameter grads are None, as in _wgrad)."""
@@ -57,8 +81,11 @@ def _wgrad(dy, x, lin=None):
     # With pre-allocated .grad buffers (FusedAdamW keeps them as views of one flat buffer) the reduce kernel adds
     # into them directly and autograd gets None: saves one torch `add` launch per parameter and step (289 of them
     # in the config-2 model) and the temporary.  Same semantics as AccumulateGrad: grad += dW.
-    direct = DIRECT_PARAM_GRADS and lin is not None and _direct_ok(lin.w) and _direct_ok(lin.b)
-    kw = dict(dw=lin.w.grad, dbias=lin.b.grad, accumulate=True) if direct else dict(want_bias=True)
+    if DIRECT_PARAM_GRADS and lin is not None and lin.gw is not None and lin.gb is not None:
+        direct, kw = True, dict(dw=lin.gw, dbias=lin.gb, accumulate=True)
+    else:
+        direct = DIRECT_PARAM_GRADS and lin is not None and _direct_ok(lin.w) and _direct_ok(lin.b)
+        kw = dict(dw=lin.w.grad, dbias=lin.b.grad, accumulate=True) if direct else dict(want_bias=True)
     if not (WGRAD_SIDE_STREAM and dy.is_cuda):
         r = ops.gemm_wgrad(dy, x, **kw)
         return (None, None) if direct else r
@@ -88,10 +115,12 @@ def _join_side(*tensors):
 
 
 class _Lin:
-    """Kernel-side view of one Linear: f32 master params + cached bf16 W / W^T."""
+    """Kernel-side view of one Linear: f32 master params + cached bf16 W / W^T.  gw / gb: explicit gradient buffers
+    (fused views of several parameters' .grad), used instead of w.grad / b.grad by the direct-accumulation path."""
 
-    def __init__(self, w, b, cache: KF.WeightCache):
+    def __init__(self, w, b, cache: KF.WeightCache, gw=None, gb=None):
         self.w, self.b = w, b
+        self.gw, self.gb = gw, gb
         self.wb, self.wtb = cache.get(w)
 
 
@@ -156,7 +185,8 @@ class EsmStackFn(torch.autograd.Function):
         for i in range(nl):
             t = flat[3 + 12 * i: 3 + 12 * (i + 1)]
             caches = module.layer_caches[i]
-            p = {"ln1_w": t[0], "ln1_b": t[1], "qkv": _Lin(t[2], t[3], caches[0]), "out": _Lin(t[4], t[5], caches[1]),
+            gw, gb = module._qkv_grads[i] if len(getattr(module, "_qkv_grads", ())) == nl else (None, None)
+            p = {"ln1_w": t[0], "ln1_b": t[1], "qkv": _Lin(t[2], t[3], caches[0], gw, gb), "out": _Lin(t[4], t[5], caches[1]),
                  "ln2_w": t[6], "ln2_b": t[7], "fc1": _Lin(t[8], t[9], caches[2]), "fc2": _Lin(t[10], t[11], caches[3])}
             x, s = _esm_layer_fwd(x, p, meta)
             layers.append(p)
@@ -285,15 +315,35 @@ class ESM2Encoder(nn.Module):
             self._rope[key] = _rope_tables(L, self.hidden_size // self.num_heads, device)
         return self._rope[key]
 
-    def _flat_params(self):
-        """Per layer: ln1 w,b | fused qkv w,b | out w,b | ln2 w,b | fc1 w,b | fc2 w,b (autograd-visible views)."""
-        flat = [self.embeddings.word_embeddings.weight, self.encoder.emb_layer_norm_after.weight,
-                self.encoder.emb_layer_norm_after.bias]
+    def flat_param_groups(self):
+        """Parameters FusedAdamW's flat buffer should store back to back: q/k/v weights, q/k/v biases per layer."""
+        groups = []
         for lyr in self.encoder.layer:
             s = lyr.attention.self
+            groups.append([s.query.weight, s.key.weight, s.value.weight])
+            groups.append([s.query.bias, s.key.bias, s.value.bias])
+        return groups
+
+    def _flat_params(self):
+        """Per layer: ln1 w,b | fused qkv w,b | out w,b | ln2 w,b | fc1 w,b | fc2 w,b.  The fused qkv tensors are
+        zero-copy views (plus their gradient views in self._qkv_grads) when the three Linears are stored back to
+        back with .grad buffers in place (DIRECT_PARAM_GRADS), else torch.cat results that autograd splits again."""
+        flat = [self.embeddings.word_embeddings.weight, self.encoder.emb_layer_norm_after.weight,
+                self.encoder.emb_layer_norm_after.bias]
+        self._qkv_grads = []
+        for lyr in self.encoder.layer:
+            s = lyr.attention.self
+            fw = _fused_views([s.query.weight, s.key.weight, s.value.weight]) if DIRECT_PARAM_GRADS else None
+            fb = _fused_views([s.query.bias, s.key.bias, s.value.bias]) if DIRECT_PARAM_GRADS else None
+            if fw is not None and fb is not None and torch.is_grad_enabled():
+                qkv_w, qkv_b = fw[0], fb[0]
+                self._qkv_grads.append((fw[1], fb[1]))
+            else:
+                qkv_w = torch.cat([s.query.weight, s.key.weight, s.value.weight], 0)
+                qkv_b = torch.cat([s.query.bias, s.key.bias, s.value.bias], 0)
+                self._qkv_grads.append((None, None))
             flat += [lyr.attention.LayerNorm.weight, lyr.attention.LayerNorm.bias,
-                     torch.cat([s.query.weight, s.key.weight, s.value.weight], 0),
-                     torch.cat([s.query.bias, s.key.bias, s.value.bias], 0),
+                     qkv_w, qkv_b,
                      lyr.attention.output.dense.weight, lyr.attention.output.dense.bias,
                      lyr.LayerNorm.weight, lyr.LayerNorm.bias,
                      lyr.intermediate.dense.weight, lyr.intermediate.dense.bias,

@@ -39,10 +39,33 @@ class FlatParams:
         if not params:
             raise ValueError("no trainable parameters")
         dev = params[0].device
-        offs, total = [], 0
+        # Sub-modules may ask for some parameters to sit back to back (`flat_param_groups()`: ESM-2 keeps the HF
+        # query / key / value Linears but runs ONE fused qkv GEMM; contiguous storage makes the fused [3d, d] weight a
+        # zero-copy view instead of a torch.cat per layer and step).  A group is placed where its first member
+        # would have been, members packed without padding (numel % 4 == 0 keeps them 16-byte aligned).
+        group_of = {}
+        for mod in module.modules():
+            fn = getattr(mod, "flat_param_groups", None)
+            if callable(fn):
+                for grp in fn():
+                    grp = [q for q in grp]
+                    if all(q.requires_grad and q.numel() % 4 == 0 for q in grp):
+                        for q in grp:
+                            group_of[id(q)] = grp
+        order, seen = [], set()
         for p in params:
+            if id(p) in seen:
+                continue
+            grp = group_of.get(id(p), [p])
+            for q in grp:
+                if id(q) not in seen:
+                    seen.add(id(q))
+                    order.append((q, q is grp[-1]))               # pad to the alignment only after the last member
+        params = [q for q, _ in order]
+        offs, total = [], 0
+        for p, pad in order:
             offs.append(total)
-            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+            total += ((p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN) if pad else p.numel()
         chunk = _ALIGN * max(world_size, 1)
         total = (total + chunk - 1) // chunk * chunk          # shard size stays _ALIGN-aligned
         self.params, self.offsets, self.numel = params, offs, total

@@ -143,3 +143,35 @@ def test_tri_modal_loss_and_collate(monkeypatch):
     assert rna.shape == (2, 5, 4) and rbp.shape == (2, 7, 6)
     assert create_padding_mask(rna).tolist() == [[True] * 3 + [False] * 2, [True] * 5]
     assert torch.isnan(rbp[1, 2:]).all()
+
+
+def test_flat_buffer_groups_qkv_for_zero_copy_fusion(monkeypatch):
+    """FusedAdamW stores ESM's query / key / value weights (and biases) back to back, so the fused [3d, d] qkv weight
+    and its gradient are views, not torch.cat results; state_dict keys stay the HF ones."""
+    ops_emulator.install(monkeypatch)
+    import clip_dplm_amd as K
+    from clip_dplm_amd import encoders as E
+    torch.manual_seed(0)
+    enc = K.ESM2Encoder(num_layers=2, hidden_size=96, num_heads=4, intermediate_size=384)
+    ref_cat = [torch.cat([l.attention.self.query.weight, l.attention.self.key.weight, l.attention.self.value.weight], 0)
+               .detach().clone() for l in enc.encoder.layer]
+    assert E._fused_views([enc.encoder.layer[0].attention.self.query.weight,
+                           enc.encoder.layer[0].attention.self.key.weight,
+                           enc.encoder.layer[0].attention.self.value.weight]) is None      # no flat buffer yet
+    opt = K.FusedAdamW(enc, lr=1e-3)
+    opt.zero_grad()
+    for i, l in enumerate(enc.encoder.layer):
+        s_ = l.attention.self
+        fw = E._fused_views([s_.query.weight, s_.key.weight, s_.value.weight])
+        fb = E._fused_views([s_.query.bias, s_.key.bias, s_.value.bias])
+        assert fw is not None and fb is not None
+        assert fw[0].shape == (288, 96) and torch.equal(fw[0], ref_cat[i])
+        assert fw[0].data_ptr() == s_.query.weight.data_ptr() and fw[1].data_ptr() == s_.query.weight.grad.data_ptr()
+    assert any(k.endswith("attention.self.query.weight") for k in enc.state_dict())
+    # a step through the fused views updates all three Linears
+    ids = torch.randint(4, 24, (3, 10))
+    before = enc.encoder.layer[1].attention.self.value.weight.detach().clone()
+    enc(ids).square().mean().backward()
+    assert enc.encoder.layer[1].attention.self.value.weight.grad.abs().max() > 0
+    opt.step()
+    assert not torch.equal(before, enc.encoder.layer[1].attention.self.value.weight.detach())
