@@ -86,12 +86,18 @@ def main():
     ap.add_argument("--seq-len", type=int, default=256)
     ap.add_argument("--esm", default="esm2_t12_35M_UR50D")
     ap.add_argument("--freeze-esm", action="store_true", help="reference behaviour (3_esm_integration.py:83-84)")
-    ap.add_argument("--single-stream", action="store_true",
-                    help="enqueue both encoder towers on one HIP stream (default: one stream per tower)")
+    ap.add_argument("--dual-stream", action="store_true",
+                    help="enqueue the two towers on separate HIP streams (+1.5 %% pairs/s; a kernel's HIP-event time "
+                         "then includes waiting for the other tower's kernels, so the per-kernel numbers are not "
+                         "the kernels' own durations any more)")
+    ap.add_argument("--single-stream", action="store_true", help="(default; kept for older command lines)")
     ap.add_argument("--micro-batches", type=int, default=1, help="stream pairs per step (batch split over them)")
     ap.add_argument("--wgrad-stream", action="store_true", help="weight-gradient GEMMs on a side stream per tower")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--all-kernel-timers", action="store_true",
+                    help="HIP events around EVERY kernel launch of the timed region (costs ~1 %% of the step); "
+                         "default: only the dominant kernel, clipk_gemm_nt")
     args = ap.parse_args()
 
     import clip_dplm_amd as K
@@ -116,7 +122,7 @@ def main():
     for m in model.modules():                             # training-step timing with dropout p = 0
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
-    model.dual_stream = not args.single_stream
+    model.dual_stream = bool(args.dual_stream) and not args.single_stream
     model.micro_batches = args.micro_batches
     import clip_dplm_amd.encoders as _enc
     _enc.WGRAD_SIDE_STREAM = args.wgrad_stream
@@ -140,7 +146,8 @@ def main():
             print(f"[bench] warm-up step {i}: {time.perf_counter() - tw:.2f} s since start", file=sys.stderr, flush=True)
     timer = None
     if not args.no_kernel_timers:
-        timer = ops.KernelTimer()
+        # timed region: only the dominant kernel (the roofline object); --all-kernel-timers times every launch
+        timer = ops.KernelTimer(None if args.all_kernel_timers else ("gemm_nt",))
         ops.set_kernel_timer(timer)
     if world > 1:
         dist.barrier()
@@ -153,20 +160,22 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     ops.set_kernel_timer(None)
-    # With two HIP streams a kernel's event time includes the other tower's kernels it shares (or waits for) the chip
-    # with.  For reference, two more steps OUTSIDE the timed region with both towers on one stream: the same kernels
-    # timed alone (reported next to the timed-region numbers, never instead of them).
+    # Two more steps OUTSIDE the timed region, one HIP stream, HIP events around every launch: the per-class breakdown
+    # (`kernels`) without taxing the timed region (~1 % when every launch is timed), and with --dual-stream also the
+    # dominant kernel's own rate (`roofline.one_stream`): with two streams a kernel's event time includes waiting
+    # for the other tower's kernels.
     timer_alone = None
-    if timer is not None and model.dual_stream and rank == 0 and world == 1:
+    was_dual = model.dual_stream
+    if timer is not None and rank == 0 and world == 1 and (was_dual or not args.all_kernel_timers):
         model.dual_stream = False
         step(); torch.cuda.synchronize()
-        timer_alone = ops.KernelTimer()
+        timer_alone = ops.KernelTimer()            # outside the timed region: every kernel class
         ops.set_kernel_timer(timer_alone)
         for _ in range(2):
             step()
         torch.cuda.synchronize()
         ops.set_kernel_timer(None)
-        model.dual_stream = True
+        model.dual_stream = was_dual
     tmax = torch.tensor([dt], device=device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -190,7 +199,7 @@ def main():
                                f"B={B} pairs/GPU, L={L}, full training step (fwd + fused InfoNCE + bwd + fused AdamW/clip), "
                                + ("ESM frozen" if args.freeze_esm else "both encoders trained"),
                    "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}",
-                   "projection_dim": 512, "hip_streams": 1 if args.single_stream else 2},
+                   "projection_dim": 512, "hip_streams": 2 if model.dual_stream else 1},
         "loss": round(float(loss.item()), 5),
     }
     if timer is not None:
@@ -203,7 +212,7 @@ def main():
                                "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
                                "avg_launch_us": round(g["avg_us"], 2), "launches": g["launches"],
                                "share_of_step": round(g["total_ms"] / (1e3 * dt), 4)}
-            if timer_alone is not None:
+            if timer_alone is not None and was_dual:
                 ga = timer_alone.summary().get("gemm_nt")
                 if ga:
                     ach = ga["work"] / (ga["total_ms"] * 1e-3) / 1e12
@@ -211,11 +220,15 @@ def main():
                                                      "avg_launch_us": round(ga["avg_us"], 2), "launches": ga["launches"],
                                                      "note": "same kernels, 2 extra steps outside the timed region "
                                                              "with both towers on one HIP stream"}
-        out["kernels"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 2),
-                              "share_of_step": round(v["total_ms"] / (1e3 * dt), 4),
+        # per-class breakdown: from the timed region with --all-kernel-timers, else from the two extra one-stream steps
+        src, steps_src, tag = (summ, args.steps, "timed region") if (args.all_kernel_timers or timer_alone is None) \
+            else (timer_alone.summary(), 2, "2 extra steps, one HIP stream, outside the timed region")
+        out["kernels"] = {k: {"launches_per_step": v["launches"] // steps_src, "avg_us": round(v["avg_us"], 2),
+                              "ms_per_step": round(v["total_ms"] / steps_src, 3),
                               "rate": round(v["work"] / (v["total_ms"] * 1e-3) / 1e12, 3),
                               "rate_unit": "TFLOP/s" if ("gemm" in k or "attn" in k) else "TB/s"}
-                          for k, v in summ.items()}
+                          for k, v in src.items()}
+        out["kernels"]["_source"] = tag
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sd_cpu, {"rna_dim": 768, "esm_layers": nl, "esm_heads": h, "rna_layers": 6,
                                                     "rna_heads": 8}, L)

@@ -34,6 +34,8 @@ struct AP {
   const unsigned short* dout; float* delta; unsigned short* dqkv;
   int B, L, H, D;
   float scale;
+  int pre_rot;      // backward: q / k in `qkv` are already rotated (clipk_rope_qk): stage them as they are, the
+                    // gradients still leave through RoPE^T
 };
 
 constexpr float LOG2E = 1.4426950408889634f;
@@ -103,8 +105,10 @@ __device__ __forceinline__ void rope_regs(RowRegs<NCH>& r, const float* cosr, co
     const float c0 = cosr[j], c1 = cosr[j + 1], s0 = sinr[j], s1 = sinr[j + 1];
     const float x1a = bf16_to_f32(wa & 0xffffu), x1b = bf16_to_f32(wa >> 16);
     const float x2a = bf16_to_f32(wb & 0xffffu), x2b = bf16_to_f32(wb >> 16);
-    wa = pack_bf16x2(x1a * c0 - x2a * s0, x1b * c1 - x2b * s1);
-    wb = pack_bf16x2(x2a * c0 + x1a * s0, x2b * c1 + x1b * s1);
+    // explicit mul + fma: the same rounding in every kernel that rotates (contraction left to the compiler differs
+    // from kernel to kernel by an ulp, and pre-rotated and staged-rotated paths must agree bit for bit)
+    wa = pack_bf16x2(fmaf(x1a, c0, -(x2a * s0)), fmaf(x1b, c1, -(x2b * s1)));
+    wb = pack_bf16x2(fmaf(x2a, c0, x1a * s0), fmaf(x2b, c1, x1b * s1));
     r.c[ja >> 3][(ja & 7) >> 1] = wa;
     r.c[jb >> 3][(jb & 7) >> 1] = wb;
   }
@@ -165,7 +169,7 @@ struct PairStager {
   __device__ __forceinline__ void store(char* a_tile, char* b_tile, int RS, const AP& p, int L, bool rope_a) {
     if (!active) return;
     if (DR > 0) {
-      if (rope_a && is_a) {
+      if (rope_a && is_a && !p.pre_rot) {
         const int pc = pos < L ? pos : L - 1;
         rope_regs<(DR > 0 ? DR : 2), NCH>(r, p.cosT + (long)pc * (DR / 2), p.sinT + (long)pc * (DR / 2));
       }
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_FWD) void attn_fwd_kernel(const AP
   if (tid < 128) {
     if (DR > 0) {
       int pq = q0 + tid; pq = pq < L ? pq : L - 1;
-      rope_regs<(DR > 0 ? DR : 2), NCH>(rq, p.cosT + (long)pq * (DR / 2), p.sinT + (long)pq * (DR / 2));
+      if (!p.pre_rot) rope_regs<(DR > 0 ? DR : 2), NCH>(rq, p.cosT + (long)pq * (DR / 2), p.sinT + (long)pq * (DR / 2));
     }
     store_row<NCH>(rq, smem + tid * RS);
   }
@@ -768,6 +772,28 @@ int launch_bwd(const AP& p, hipStream_t st) {
   return clipk_check_launch();
 }
 
+// In-place rotate-half RoPE of the q and k sections of qkv [B*L, 3*H*D]: one thread per (token, q|k, head) row.
+// The three attention kernels stage every K row 5 times and every Q row 4 times per layer (two query-block
+// workgroups per head in the forward and dQ kernels, two key-block workgroups in the dK/dV kernel) and rotated it
+// each time: ~160 VALU per row next to a ~150-instruction inner loop per 64 keys.  Rotating once after the qkv
+// GEMM makes those stagings plain copies.
+template <int D>
+__global__ __launch_bounds__(256) void rope_qk_kernel(unsigned short* qkv, const float* cosT, const float* sinT,
+                                                      long rows, int L, int H) {
+  constexpr int NCH = D / 8;
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  const long t = i / (2 * H);
+  const int r = (int)(i - t * 2 * H);                      // r < H: q head r;  r >= H: k head r - H (adjacent in memory)
+  unsigned short* rowp = qkv + t * 3L * H * D + (long)r * D;
+  const int pos = (int)(t % L);
+  RowRegs<NCH> rr;
+  load_row<NCH>(rr, rowp, NCH);
+  rope_regs<D, NCH>(rr, cosT + (long)pos * (D / 2), sinT + (long)pos * (D / 2));
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) *reinterpret_cast<u32x4*>(rowp + 8 * c) = rr.c[c];
+}
+
 int check_common(const void* qkv, int B, int L, int H, int D, bool rope) {
   if (!qkv || B <= 0 || L <= 0 || H <= 0 || D <= 0) return CLIPK_ERR_BAD_ARG;
   if ((D & 7) || D > 160) return CLIPK_ERR_UNSUPPORTED;
@@ -810,9 +836,28 @@ extern "C" int clipk_attn_fwd(const void* qkv, const uint8_t* key_mask, const fl
   ATTN_DISPATCH(launch_fwd, D, rope, p, (hipStream_t)stream);
 }
 
+extern "C" int clipk_rope_qk(void* qkv, const float* rope_cos, const float* rope_sin, int B, int L, int H, int D,
+                             void* stream) {
+  if (!rope_cos || !rope_sin) return CLIPK_ERR_BAD_ARG;
+  int rc = check_common(qkv, B, L, H, D, true);
+  if (rc) return rc;
+  const long rows = (long)B * L * 2 * H;
+  const dim3 grid((unsigned)((rows + 255) / 256)), blk(256);
+  unsigned short* q = (unsigned short*)qkv;
+  hipStream_t st = (hipStream_t)stream;
+  switch (D) {
+    case 16: hipLaunchKernelGGL(rope_qk_kernel<16>, grid, blk, 0, st, q, rope_cos, rope_sin, rows, L, H); break;
+    case 24: hipLaunchKernelGGL(rope_qk_kernel<24>, grid, blk, 0, st, q, rope_cos, rope_sin, rows, L, H); break;
+    case 32: hipLaunchKernelGGL(rope_qk_kernel<32>, grid, blk, 0, st, q, rope_cos, rope_sin, rows, L, H); break;
+    case 64: hipLaunchKernelGGL(rope_qk_kernel<64>, grid, blk, 0, st, q, rope_cos, rope_sin, rows, L, H); break;
+    default: hipLaunchKernelGGL(rope_qk_kernel<128>, grid, blk, 0, st, q, rope_cos, rope_sin, rows, L, H); break;
+  }
+  return clipk_check_launch();
+}
+
 extern "C" int clipk_attn_bwd(const void* qkv, const uint8_t* key_mask, const float* rope_cos, const float* rope_sin,
                               const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
-                              int B, int L, int H, int D, float q_scale, void* stream) {
+                              int B, int L, int H, int D, float q_scale, int prerotated, void* stream) {
   if ((rope_cos == nullptr) != (rope_sin == nullptr)) return CLIPK_ERR_BAD_ARG;
   const bool rope = rope_cos != nullptr;
   int rc = check_common(qkv, B, L, H, D, rope);
@@ -824,5 +869,6 @@ extern "C" int clipk_attn_bwd(const void* qkv, const uint8_t* key_mask, const fl
   p.out = (unsigned short*)out; p.lse = const_cast<float*>(lse);
   p.dout = (const unsigned short*)dout; p.delta = delta; p.dqkv = (unsigned short*)dqkv;
   p.B = B; p.L = L; p.H = H; p.D = D; p.scale = q_scale;
+  p.pre_rot = (rope && prerotated) ? 1 : 0;
   ATTN_DISPATCH(launch_bwd, D, rope, p, (hipStream_t)stream);
 }

@@ -16,6 +16,8 @@ from __future__ import annotations
 import math
 from typing import List, Optional
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -35,6 +37,7 @@ WGRAD_SIDE_STREAM = False
 _SIDE = {}
 
 
+PREROTATE_QK = os.environ.get("CLIPK_PREROTATE", "1") != "0"   # ESM: RoPE on q / k once after the qkv GEMM, not at every staging
 DIRECT_PARAM_GRADS = True      # weight-gradient kernels accumulate straight into existing .grad buffers
 
 
@@ -132,7 +135,13 @@ def _esm_layer_fwd(x, p, meta):
     B, L, H, D, mask, rope, eps = meta
     _, h1, m1, r1 = ops.layernorm_fwd(x, p["ln1_w"], p["ln1_b"], eps, want_f32=False, want_bf16=True)
     qkv = ops.gemm_nt(h1, p["qkv"].wb, bias=p["qkv"].b)
-    ctx, lse = ops.attn_fwd(qkv, B, L, H, D, key_mask=mask, rope=rope, q_scale=D ** -0.5)
+    if PREROTATE_QK and rope is not None:
+        # RoPE once, in place: the attention kernels would otherwise rotate every K row 5x and every Q row 4x per
+        # layer while staging it.  `qkv` (saved for backward) then holds rotated q / k.
+        ops.rope_qk_(qkv, B, L, H, D, rope)
+        ctx, lse = ops.attn_fwd(qkv, B, L, H, D, key_mask=mask, rope=None, q_scale=D ** -0.5)
+    else:
+        ctx, lse = ops.attn_fwd(qkv, B, L, H, D, key_mask=mask, rope=rope, q_scale=D ** -0.5)
     x2 = ops.gemm_nt(ctx, p["out"].wb, bias=p["out"].b, residual=x, out_dtype=torch.float32)
     _, h2, m2, r2 = ops.layernorm_fwd(x2, p["ln2_w"], p["ln2_b"], eps, want_f32=False, want_bf16=True)
     g, u = ops.gemm_nt(h2, p["fc1"].wb, bias=p["fc1"].b, act="gelu", out_preact=True)
@@ -155,7 +164,8 @@ def _esm_layer_bwd(dy, dyb, p, saved, meta, need_dx_bf16):
                                                   want_f32=True, want_bf16=True)
     dctx = ops.gemm_nt(dx2b, p["out"].wtb)
     gr["out_w"], gr["out_b"] = _wgrad(dx2b, ctx, p["out"])
-    dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, H, D, key_mask=mask, rope=rope, q_scale=D ** -0.5)
+    dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, H, D, key_mask=mask, rope=rope, q_scale=D ** -0.5,
+                        prerotated=PREROTATE_QK and rope is not None)
     dh1 = ops.gemm_nt(dqkv, p["qkv"].wtb)
     gr["qkv_w"], gr["qkv_b"] = _wgrad(dqkv, h1, p["qkv"])
     dx, dxb, gr["ln1_w"], gr["ln1_b"] = _ln_bwd(dh1, x, p["ln1_w"], p["ln1_b"], m1, r1, dx_add=dx2,

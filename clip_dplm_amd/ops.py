@@ -20,8 +20,10 @@ class KernelTimer:
     """Optional HIP-event timing of individual kernel launches on torch's current stream (the stream the
     kernels are enqueued on).  bench.py uses it for the live roofline numbers; off by default."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = {}          # name -> list of (start_event, end_event, algorithmic work)
+        self.only = None if only is None else set(only)    # restrict to these kernel names (two events per launch cost
+                                                           # ~1 % of a training step when every launch is timed)
 
     def add(self, name, s, e, work):
         self.records.setdefault(name, []).append((s, e, work))
@@ -45,7 +47,7 @@ def set_kernel_timer(t: Optional[KernelTimer]) -> None:
 
 
 def _timed(name: str, work: float, fn):
-    if _TIMER is None:
+    if _TIMER is None or (_TIMER.only is not None and name not in _TIMER.only):
         return fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
@@ -329,7 +331,16 @@ def attn_fwd(qkv, B, L, H, D, key_mask=None, rope=None, q_scale=1.0):
     return out, lse
 
 
-def attn_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=None, rope=None, q_scale=1.0):
+def rope_qk_(qkv, B, L, H, D, rope):
+    """In-place RoPE of the q and k sections of qkv (then: attn_fwd(rope=None), attn_bwd(rope=..., prerotated=True))."""
+    _need_cuda(qkv)
+    assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous() and qkv.shape == (B * L, 3 * H * D)
+    cos, sin = rope
+    check(_lib().clipk_rope_qk(qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), B, L, H, D, _stream()), "clipk_rope_qk")
+    return qkv
+
+
+def attn_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=None, rope=None, q_scale=1.0, prerotated=False):
     _need_cuda(qkv, out, dout, lse)
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
@@ -337,7 +348,7 @@ def attn_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=None, rope=None, q_scale=
     check(_timed("attn_bwd", 10.0 * B * H * L * L * D,
                  lambda: _lib().clipk_attn_bwd(qkv.data_ptr(), ptr(key_mask), ptr(cos), ptr(sin), out.data_ptr(),
                                                dout.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), B, L,
-                                               H, D, float(q_scale), _stream())), "clipk_attn_bwd")
+                                               H, D, float(q_scale), int(bool(prerotated)), _stream())), "clipk_attn_bwd")
     return dqkv
 
 

@@ -182,7 +182,11 @@ int clipk_attn_fwd(const void* qkv, const uint8_t* key_mask, const float* rope_c
  * delta: f32 [B,H,L] scratch (rowsum(dout*out)) provided by the caller. */
 int clipk_attn_bwd(const void* qkv, const uint8_t* key_mask, const float* rope_cos, const float* rope_sin,
                    const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
-                   int B, int L, int H, int D, float q_scale, void* stream);
+                   int B, int L, int H, int D, float q_scale, int prerotated, void* stream);
+/* Rotate-half RoPE (transformers modeling_esm.py:88-110) applied ONCE, in place, to the q and k sections of
+ * qkv bf16 [B*L, 3*H*D].  Afterwards call clipk_attn_fwd WITHOUT rope tables and clipk_attn_bwd with the tables and
+ * prerotated = 1: q / k are then staged as they are and only the gradients go through RoPE^T. */
+int clipk_rope_qk(void* qkv, const float* rope_cos, const float* rope_sin, int B, int L, int H, int D, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Token embedding (ESM-2): x[t,:] = table[ids[t],:] * scale[b] * mask[t], with the token-dropout

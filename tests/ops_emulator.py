@@ -202,11 +202,36 @@ def attn_fwd(qkv, B, L, H, D, key_mask=None, rope=None, q_scale=1.0):
     return o.to(BF), lse
 
 
-def attn_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=None, rope=None, q_scale=1.0):
+def _rope_qk(x, B, L, H, D, rope):
+    """rotate the q and k sections of x [B*L, 3*H*D] (f32 math)"""
+    cos, sin = rope
+    cosf, sinf = torch.cat([cos, cos], -1)[None, :, None], torch.cat([sin, sin], -1)[None, :, None]
+    v = x.view(B, L, 3, H, D)
+
+    def rot(t):
+        return torch.cat([-t[..., D // 2:], t[..., : D // 2]], -1)
+    qk = v[:, :, :2]
+    qk = qk * cosf[:, :, None] + rot(qk) * sinf[:, :, None]
+    return torch.cat([qk, v[:, :, 2:]], 2).reshape(B * L, 3 * H * D)
+
+
+def rope_qk_(qkv, B, L, H, D, rope):
+    qkv.copy_(_rope_qk(qkv.float(), B, L, H, D, rope).to(BF))
+    return qkv
+
+
+def attn_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=None, rope=None, q_scale=1.0, prerotated=False):
     with torch.enable_grad():
         q = qkv.float().detach().requires_grad_(True)
-        o, _ = _attn_math(q, B, L, H, D, key_mask, rope, q_scale)
-        g, = torch.autograd.grad(o, q, dout.float())
+        if prerotated and rope is not None:
+            # q, k are rotated already: gradient w.r.t. the rotated rows, then through RoPE^T (= vjp of the rotation)
+            o, _ = _attn_math(q, B, L, H, D, key_mask, None, q_scale)
+            g_rot, = torch.autograd.grad(o, q, dout.float())
+            z = torch.zeros_like(q).requires_grad_(True)
+            g, = torch.autograd.grad(_rope_qk(z, B, L, H, D, rope), z, g_rot)
+        else:
+            o, _ = _attn_math(q, B, L, H, D, key_mask, rope, q_scale)
+            g, = torch.autograd.grad(o, q, dout.float())
     return g.to(BF)
 
 

@@ -183,6 +183,28 @@ def test_weight_cache_batched_refresh(dev):
             assert torch.equal(c.wtb, c.src.detach().t().contiguous().to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("B,L,H,D", [(3, 100, 4, 24), (2, 256, 20, 24), (2, 130, 2, 64)])
+def test_rope_prerotation_equals_rotation_at_staging(dev, B, L, H, D):
+    """clipk_rope_qk (in place, once) + attention without forward rotation == attention that rotates q / k while
+    staging them: identical bf16 values reach the MFMAs, so outputs, LSE and dqkv are bit-identical."""
+    ops = _ops()
+    qkv = _rand((B * L, 3 * H * D), dev, 60, dtype=torch.bfloat16)
+    dout = _rand((B * L, H * D), dev, 61, dtype=torch.bfloat16)
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
+    fr = torch.arange(L, dtype=torch.float32)[:, None] * inv[None]
+    rope = (fr.cos().contiguous().to(dev), fr.sin().contiguous().to(dev))
+    lens = torch.tensor([L] + [max(1, L - 17 * (i + 1)) for i in range(B - 1)])
+    mask = (torch.arange(L)[None] < lens[:, None]).to(torch.uint8).contiguous().to(dev)
+    o1, lse1 = ops.attn_fwd(qkv, B, L, H, D, key_mask=mask, rope=rope, q_scale=D ** -0.5)
+    g1 = ops.attn_bwd(qkv, o1, dout, lse1, B, L, H, D, key_mask=mask, rope=rope, q_scale=D ** -0.5)
+    rot = ops.rope_qk_(qkv.clone(), B, L, H, D, rope)
+    assert torch.equal(rot.view(B * L, 3, H * D)[:, 2], qkv.view(B * L, 3, H * D)[:, 2])        # v untouched
+    o2, lse2 = ops.attn_fwd(rot, B, L, H, D, key_mask=mask, rope=None, q_scale=D ** -0.5)
+    g2 = ops.attn_bwd(rot, o2, dout, lse2, B, L, H, D, key_mask=mask, rope=rope, q_scale=D ** -0.5, prerotated=True)
+    assert torch.equal(o1, o2) and torch.equal(lse1, lse2)
+    assert torch.equal(g1, g2)
+
+
 # ------------------------------------------------------------------------------------------------ simce
 def _unit(shape, dev, seed):
     return F.normalize(_rand(shape, dev, seed), dim=-1).contiguous()
