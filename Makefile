@@ -20,7 +20,7 @@ $(LIB): $(OBJ)
 
 probes: tools/probes/probe_layouts
 tools/probes/probe_layouts: tools/probes/probe_layouts.hip
-	$(HIPCC) --offload-arch=$(ARCH) -O2 -o $@ $<
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -Wno-unused-value -o $@ $<
 
 clean:
 	rm -rf build $(LIB) tools/probes/probe_layouts
