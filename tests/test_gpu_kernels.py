@@ -82,7 +82,7 @@ def test_gemm_nt_epilogue(dev, act):
     assert torch.allclose(outd, (a.float() @ b.float().t()) * gref, rtol=1e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize("kernel", ["v2", "v3", "v2generic", "v3generic"])
+@pytest.mark.parametrize("kernel", ["v2", "v3", "v4", "v2generic", "v3generic", "v4generic"])
 @pytest.mark.parametrize("M,N,K", [(2048, 256, 128), (2500, 360, 160), (4096, 1440, 480), (2304, 480, 1920),
                                    (3000, 776, 192), (66000, 520, 480), (40000, 1000, 224)])
 def test_gemm_nt_specialised_epilogues(dev, monkeypatch, kernel, M, N, K):
@@ -92,6 +92,7 @@ def test_gemm_nt_specialised_epilogues(dev, monkeypatch, kernel, M, N, K):
     next-tile prefetch under the epilogue and the store-tolerant vmcnt bookkeeping."""
     ops = _ops()
     monkeypatch.setenv("CLIPK_GEMM_V3", "1" if kernel.startswith("v3") else "0")
+    monkeypatch.setenv("CLIPK_GEMM_V4", "1" if kernel.startswith("v4") else "0")
     if kernel.endswith("generic"):
         monkeypatch.setenv("CLIPK_GEMM_EPI_GENERIC", "1")
     a = _rand((M, K), dev, 11, dtype=torch.bfloat16)
