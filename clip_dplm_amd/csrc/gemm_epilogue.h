@@ -13,6 +13,7 @@
 // the stores in flight.
 #pragma once
 #include "common.h"
+#include <stdlib.h>
 
 struct EpiArgs {
   void* C; long ldc; int c_f32;
@@ -23,6 +24,7 @@ struct EpiArgs {
   const unsigned short* dact_aux; long ldd; int dact;
   const void* residual; long ldr; int r_f32;
   float alpha;
+  int nt;           // 1: non-temporal (streaming) output stores (epi_args_from decides)
 };
 
 enum {
@@ -88,6 +90,12 @@ __device__ __forceinline__ void epi_load_bias(const EpiArgs& p, int gn, float (&
   epi_retire_bias(b0, b1, bv);
 }
 
+// output store through a buffer descriptor; nt = streaming hint (the aux bits must be immediates, hence the branch)
+__device__ __forceinline__ void epi_store(u32x4 v, __amdgpu_buffer_rsrc_t rsrc, unsigned off, int nt) {
+  if (nt) __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, off, 0, 2);
+  else __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, off, 0, 0);
+}
+
 // eb: wave-private slab; mbase: first output row of this wave; gn: this lane's first column; bv: epi_load_bias
 template <int MODE, int NJ, bool SWZ = false>
 __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][NJ], float* eb, int lane, int mbase,
@@ -148,15 +156,15 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
 #pragma unroll
         for (int c = 0; c < 4; ++c) o[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
         const unsigned off = ok ? (unsigned)(((long)gm * p.ldc + gn) * 2) : OOB;
-        __builtin_amdgcn_raw_buffer_store_b128(o, c_rsrc, off, 0, 0);
+        epi_store(o, c_rsrc, off, p.nt);
       } else if constexpr (MODE == EPI_RES32) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) { v[c] += r0[c]; v[4 + c] += r1[c]; }
         const unsigned off = ok ? (unsigned)(((long)gm * p.ldc + gn) * 4) : OOB;
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
-                                                     __float_as_uint(v[3])}, c_rsrc, off, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]),
-                                                     __float_as_uint(v[7])}, c_rsrc, off + 16, 0, 0);
+        epi_store(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
+                                                     __float_as_uint(v[3])}, c_rsrc, off, p.nt);
+        epi_store(u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]),
+                                                     __float_as_uint(v[7])}, c_rsrc, off + 16, p.nt);
       } else if constexpr (MODE == EPI_GELU_PRE) {
         u32x4 u, o;
 #pragma unroll
@@ -168,8 +176,8 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
         }
         const unsigned offu = ok ? (unsigned)(((long)gm * p.ldp + gn) * 2) : OOB;
         const unsigned off = ok ? (unsigned)(((long)gm * p.ldc + gn) * 2) : OOB;
-        __builtin_amdgcn_raw_buffer_store_b128(u, u_rsrc, offu, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(o, c_rsrc, off, 0, 0);
+        epi_store(u, u_rsrc, offu, p.nt);
+        epi_store(o, c_rsrc, off, p.nt);
       } else {  // EPI_DGELU
         u32x4 o;
 #pragma unroll
@@ -179,7 +187,7 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
           o[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
         }
         const unsigned off = ok ? (unsigned)(((long)gm * p.ldc + gn) * 2) : OOB;
-        __builtin_amdgcn_raw_buffer_store_b128(o, c_rsrc, off, 0, 0);
+        epi_store(o, c_rsrc, off, p.nt);
       }
       r0 = n0; r1 = n1; ax = nx;
     }
@@ -260,5 +268,10 @@ static inline EpiArgs epi_args_from(const clipk_gemm_args* a) {
   e.dact_aux = (const unsigned short*)a->dact_aux; e.ldd = a->ldd; e.dact = a->dact;
   e.residual = a->residual; e.ldr = a->ldr; e.r_f32 = (a->r_dtype == CLIPK_F32);
   e.alpha = a->alpha;
+  // Streaming (non-temporal) output stores, CLIPK_EPI_NT=1.  In the kernel microbenchmark they are worth 7 % on the
+  // hot shapes (the output stream stops evicting operand panels from L2: esm qkv 256 -> 192 us; f32 residual outputs
+  // get slower), in the training step nothing (96.8 vs 96.6 ms): there the consumer of the output runs next and finds
+  // less of it in the Infinity Cache.  Off by default.
+  { const char* nt = getenv("CLIPK_EPI_NT"); e.nt = nt ? atoi(nt) : 0; }
   return e;
 }

@@ -54,6 +54,9 @@ def bench_gemm():
     the specialised straight-line epilogue, 256^2 phase-interleaved kernel (CLIPK_GEMM_V3)"""
     arms = [("v2gen", {"CLIPK_GEMM_EPI_GENERIC": "1", "CLIPK_GEMM_V3": "0"}), ("v2", {"CLIPK_GEMM_V3": "0"}),
             ("v3", {"CLIPK_GEMM_V3": "1"})]
+    if os.environ.get("BENCH_NT"):
+        arms.append(("v3nt0", {"CLIPK_GEMM_V3": "1", "CLIPK_EPI_NT": "0"}))
+        arms.append(("v3nt1", {"CLIPK_GEMM_V3": "1", "CLIPK_EPI_NT": "1"}))
     if os.environ.get("BENCH_V4"):
         arms.append(("v4", {"CLIPK_GEMM_V4": "1"}))
     for ab in os.environ.get("BENCH_ABL", "").split():
@@ -78,7 +81,7 @@ def bench_gemm():
             kw = {"dact_aux": rnd((M, N)), "dact": "gelu"}
         out = {}
         for n, env in arms:
-            for k in ("CLIPK_GEMM_EPI_GENERIC", "CLIPK_GEMM_V3", "CLIPK_GEMM_V4", "CLIPK_GEMM_STAGGER", "CLIPK_GEMM_ABL", "CLIPK_GEMM_NWG"):
+            for k in ("CLIPK_GEMM_EPI_GENERIC", "CLIPK_GEMM_V3", "CLIPK_GEMM_V4", "CLIPK_EPI_NT", "CLIPK_GEMM_STAGGER", "CLIPK_GEMM_ABL", "CLIPK_GEMM_NWG"):
                 os.environ.pop(k, None)
             os.environ.update(env)
             med, mn = timeit(lambda: ops.gemm_nt(a, b, **kw))
@@ -90,7 +93,7 @@ def bench_gemm():
               + f" | {out['v2gen'] / out['v2']:.2f}x {out['v2'] / out['v3']:.2f}x"
               + (f" v3/v4 {out['v3'] / out['v4']:.2f}x" if "v4" in out else ""), flush=True)
         del a, b, kw
-    for k in ("CLIPK_GEMM_EPI_GENERIC", "CLIPK_GEMM_V3", "CLIPK_GEMM_V4", "CLIPK_GEMM_STAGGER", "CLIPK_GEMM_ABL", "CLIPK_GEMM_NWG"):
+    for k in ("CLIPK_GEMM_EPI_GENERIC", "CLIPK_GEMM_V3", "CLIPK_GEMM_V4", "CLIPK_EPI_NT", "CLIPK_GEMM_STAGGER", "CLIPK_GEMM_ABL", "CLIPK_GEMM_NWG"):
         os.environ.pop(k, None)
     print("sum: " + ", ".join(f"{n} {tot[n]:.2f} ms" for n, _ in arms))
 
