@@ -51,10 +51,15 @@ def test_gemm_nt_plain(dev, M, N, K):
     assert torch.allclose(c16.float(), ref, rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("kernel,M", [("v2", 384), ("v3", 2304), ("v4", 2304)])
 @pytest.mark.parametrize("act", [None, "relu", "gelu"])
-def test_gemm_nt_epilogue(dev, act):
+def test_gemm_nt_epilogue(dev, monkeypatch, act, kernel, M):
+    """run-time (generic) epilogue combinations — f32 out + residual + pre-activation, bf16 residual, act' — through
+    all three tile structures"""
+    monkeypatch.setenv("CLIPK_GEMM_V3", "1" if kernel == "v3" else "0")
+    monkeypatch.setenv("CLIPK_GEMM_V4", "1" if kernel == "v4" else "0")
     ops = _ops()
-    M, N, K = 384, 256, 192
+    N, K = 256, 192
     a = _rand((M, K), dev, 3, dtype=torch.bfloat16)
     b = _rand((N, K), dev, 4, 0.1, dtype=torch.bfloat16)
     bias = _rand((N,), dev, 5)
