@@ -23,6 +23,7 @@
 //     7 MFMA products instead of 5, but no float atomics and bitwise-reproducible gradients.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -34,6 +35,7 @@ struct AP {
   const unsigned short* dout; float* delta; unsigned short* dqkv;
   int B, L, H, D;
   float scale;
+  int stagger, ncu; // whole-head backward: start-up phase offset of the second resident workgroup per CU
   int pre_rot;      // backward: q / k in `qkv` are already rotated (clipk_rope_qk): stage them as they are, the
                     // gradients still leave through RoPE^T
 };
@@ -46,9 +48,8 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // Work-item order: the G = (blocks per sequence) x H workgroups of one batch element read the same token rows
 // (each head only D*2 bytes of a 3*H*D*2-byte row), so keep them on ONE XCD's L2: blocks b and b+8 share an XCD
 // (round-robin dispatch), hence XCD x gets batch elements x, x+8, ...  Falls back to the plain order when B % 8 != 0.
-__device__ __forceinline__ void work_item(int nblk, int H, int B, int& blk, int& h, int& b) {
+__device__ __forceinline__ void work_item_at(int w, int nblk, int H, int B, int& blk, int& h, int& b) {
   const int G = nblk * H;
-  int w = blockIdx.x;
   if ((B & 7) == 0) {
     const int xcd = w & 7, slot = w >> 3;
     w = ((slot / G) * 8 + xcd) * G + (slot % G);
@@ -57,6 +58,9 @@ __device__ __forceinline__ void work_item(int nblk, int H, int B, int& blk, int&
   const int r = w - b * G;
   h = r / nblk;
   blk = r - h * nblk;
+}
+__device__ __forceinline__ void work_item(int nblk, int H, int B, int& blk, int& h, int& b) {
+  work_item_at(blockIdx.x, nblk, H, B, blk, h, b);
 }
 
 template <int DP> struct Geo {
@@ -374,6 +378,43 @@ __device__ __forceinline__ void store_grad_rows(const float* img, int ILD, unsig
 #pragma unroll
     for (int e = 0; e < 4; ++e) w[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
     *reinterpret_cast<u32x4*>(base + (long)pos * tokstride + ch * 8) = w;
+  }
+}
+
+// Whole-head backward epilogue: one thread per token row.  The rotate-half tables of the row are loaded into
+// registers BEFORE the next head's rows are requested: vmcnt retires in order, so a table load issued after that
+// prefetch would have to wait for all of it.
+template <int D> struct RopeRow { f32x4 cs[D / 8], sn[D / 8]; };
+
+template <int D>
+__device__ __forceinline__ void load_rope_row(RopeRow<D>& T, const float* cosT, const float* sinT, int pos) {
+#pragma unroll
+  for (int i = 0; i < D / 8; ++i) {
+    T.cs[i] = *reinterpret_cast<const f32x4*>(cosT + pos * (D / 2) + 4 * i);
+    T.sn[i] = *reinterpret_cast<const f32x4*>(sinT + pos * (D / 2) + 4 * i);
+  }
+}
+// f32 image row (gradient w.r.t. the rotated q / k) -> RoPE^T -> bf16 row of dqkv
+template <bool ROPE, int D>
+__device__ __forceinline__ void store_grad_row(const float* row, unsigned short* dst, const RopeRow<D>& T) {
+  constexpr int NG = D / 4;
+  f32x4 x[NG];
+#pragma unroll
+  for (int i = 0; i < NG; ++i) x[i] = *reinterpret_cast<const f32x4*>(row + 4 * i);
+  if (ROPE) {
+#pragma unroll
+    for (int i = 0; i < NG / 2; ++i) {
+      const f32x4 lo = x[i], hi = x[i + NG / 2];
+      x[i] = lo * T.cs[i] + hi * T.sn[i];
+      x[i + NG / 2] = hi * T.cs[i] - lo * T.sn[i];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < D / 8; ++c) {
+    u32x4 w;
+    w[0] = pack_bf16x2(x[2 * c][0], x[2 * c][1]); w[1] = pack_bf16x2(x[2 * c][2], x[2 * c][3]);
+    w[2] = pack_bf16x2(x[2 * c + 1][0], x[2 * c + 1][1]); w[3] = pack_bf16x2(x[2 * c + 1][2], x[2 * c + 1][3]);
+    *reinterpret_cast<u32x4*>(dst + 8 * c) = w;
   }
 }
 
@@ -732,6 +773,334 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dkv_kernel(cons
   store_grad_rows<false>(img, ILD, dvbase, tokstride, k0, KVB, L, D, p.cosT, p.sinT, tid);
 }
 
+// =================================================================================================
+// backward, whole head in one workgroup (head dim <= 32, 128 < L <= 256): 5 MFMA products instead of 7 and the
+// exponentials once instead of twice.
+//
+// The short-head backward is VALU-bound (one 16x16 score tile = 5 x 16 MFMA cycles against ~200 VALU cycles of
+// softmax / dS arithmetic), so recomputing S and dP in a second kernel doubles the cost that matters.  Here one
+// workgroup owns one (batch, head): all 256 Q and dO rows sit in LDS (64-byte rows, 16-byte chunks XOR-swizzled by
+// (row >> 1) & 3: conflict-free for the b128 row reads and the transposed reads, tools/lds_conflicts.py), wave w owns
+// keys [64w, 64w + 64) with their K / V fragments and the dK / dV accumulators in registers, and sweeps the eight
+// 32-query blocks.  dS leaves the accumulators once more, transposed: written as bf16 [key][query] rows to a private
+// 2 x 2 KiB LDS buffer and read back with ds_read_b64_tr_b16 as the B operand of dQ^T += K^T dS^T.  Each wave's dQ
+// contribution covers its 64 keys only; the four waves walk the query blocks ROTATED (wave w takes block (s + w) & 7
+// at step s), so at every step they add into four different rows of the f32 dQ image in LDS with plain
+// read-add-write, one barrier per step, and every dQ element is summed in a fixed order: no float atomics, the
+// gradients stay bitwise reproducible.
+// =================================================================================================
+__device__ __forceinline__ int swz64(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 3)) << 4); }
+
+// transposed fragment from a swizzled 64-byte-row tile: `off` = this lane's byte offset for rows [0, 16) (rows
+// 16..31 are 1024 bytes further, same swizzle)
+__device__ __forceinline__ bf16x8 tr_frag_off(const char* tile, int off) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(tile + off));
+  const s16x4 hi =
+      __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(tile + off + 1024));
+  bf16x8 f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
+
+constexpr int FUSED_LMAX = 256;
+__host__ __device__ constexpr size_t lds_fused(int D) {
+  // the bf16 dV image of the epilogue sits behind the dK image inside the dead Q / dO / dS^T region when both fit
+  // (D <= 24), behind everything otherwise
+  return (size_t)2 * FUSED_LMAX * 64 + 4 * 4096 + (size_t)FUSED_LMAX * (D + 4) * 4 + 2 * FUSED_LMAX * 4 +
+         (D > 24 ? (size_t)FUSED_LMAX * 64 : 0);
+}
+
+// one head's rows as this thread holds them between the loads and the LDS staging: chunk (tid & 3) of rows
+// (tid >> 2) + 64 * pass of K, V, Q, dO and O, this thread's lse and the mask bytes of its four key columns
+struct HeadRegs {
+  u32x4 k[4], v[4], q[4], d[4], o[4];
+  float lse;
+  unsigned char km[4];
+};
+
+// a zero the optimiser cannot see through: values derived from `tid + opaque_zero()` inside a loop are recomputed
+// there instead of being hoisted out and kept alive (and then spilled) across the register-tight sweep
+__device__ __forceinline__ int opaque_zero() {
+  int z;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+  return z;
+}
+
+template <bool ROPE, int D>
+__global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(const AP p) {
+  constexpr int DT = 2, KTW = 4, LQ = FUSED_LMAX;
+  constexpr int ILD = D + 4, cpr = D / 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* qtile = smem;                                     // [256 q][64 B]   (first: this head's K rows)
+  char* dotile = smem + LQ * 64;                          // [256 q][64 B]   (first: this head's V rows)
+  char* dst_all = smem + 2 * LQ * 64;                     // 4 waves x 2 x [32 keys][32 q] bf16
+  float* img = reinterpret_cast<float*>(dst_all + 4 * 4096);   // dQ image [256][D + 4] f32
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int L = p.L, H = p.H;
+  float* lse_l = img + LQ * ILD;                          // [256], already times log2(e); +inf past the end
+  float* dl_l = lse_l + LQ;                               // [256]
+  const long tokstride = 3L * H * D, ostride = (long)H * D;
+  const float c2 = p.scale * LOG2E;
+  const int nheads = p.B * H;
+
+  // Staging: four lanes per token row (one 16-byte chunk each, the pad chunk zero), 64 rows per pass: a wave
+  // instruction covers 16 rows x D*2 contiguous bytes.  (One thread per row - the staging of the other kernels, needed
+  // there to rotate rows in registers - touches 64 different 128-byte lines per instruction.)
+  auto issue = [&](int w, HeadRegs& R) {
+    int blk_, h_, b_;
+    work_item_at(w, 1, H, p.B, blk_, h_, b_);
+    const int t = tid + opaque_zero();
+    const int ci = t & 3, r0 = t >> 2;
+    // uniform bases (SGPR pairs) + 32-bit element offsets: one VGPR per address
+    const unsigned short* qb = p.qkv + (long)b_ * L * tokstride + (long)h_ * D;
+    const unsigned short* dob = p.dout + (long)b_ * L * ostride + (long)h_ * D;
+    const unsigned short* ob = p.out + (long)b_ * L * ostride + (long)h_ * D;
+    const unsigned int HD = (unsigned int)(H * D);
+    // no branch around the loads (a lane whose chunk is the zero pad re-reads the last real chunk and drops it at
+    // staging time): loads under a divergent branch make every later s_waitcnt assume they may not have been issued
+    const unsigned int cc = 8u * (ci < cpr ? ci : cpr - 1);
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      int row = ps * 64 + r0; row = row < L ? row : L - 1;
+      const unsigned int qo = (unsigned int)row * 3u * HD + cc, oo = (unsigned int)row * HD + cc;
+      R.q[ps] = *reinterpret_cast<const u32x4*>(qb + qo);
+      R.k[ps] = *reinterpret_cast<const u32x4*>(qb + (qo + HD));
+      R.v[ps] = *reinterpret_cast<const u32x4*>(qb + (qo + 2u * HD));
+      R.d[ps] = *reinterpret_cast<const u32x4*>(dob + oo);
+      R.o[ps] = *reinterpret_cast<const u32x4*>(ob + oo);
+    }
+    R.lse = p.lse[((long)b_ * H + h_) * L + (t < L ? t : L - 1)];
+    const int lane_ = t & 63, wid_ = t >> 6;
+#pragma unroll
+    for (int kt = 0; kt < KTW; ++kt) {
+      const int key = wid_ * 64 + kt * 16 + (lane_ & 15);
+      R.km[kt] = p.key_mask ? p.key_mask[(long)b_ * L + (key < L ? key : L - 1)] : (unsigned char)1;
+    }
+  };
+
+  // per-lane offsets into the swizzled tiles (row-block bases are multiples of 16, which the swizzle ignores)
+  const int trow = 4 * g + (li >> 2);
+  const int off_rf = swz64(li, g);                                            // row li, chunk g (8 of the 32 d)
+  int off_tr[DT];                                                             // row trow, bytes dt*32 + 8*(li&3)
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) off_tr[dt] = swz64(trow, dt * 2 + ((li & 3) >> 1)) + 8 * (li & 1);
+  char* dst = dst_all + wid * 4096;
+  // dS^T write: key row ktl*16 + li, queries qq*16 + 4g .. +3 -> 8 bytes at byte column qq*32 + 8g
+  int off_dw[2];
+#pragma unroll
+  for (int qq = 0; qq < 2; ++qq) off_dw[qq] = swz64(li, qq * 2 + (g >> 1)) + 8 * (g & 1);
+  const bool dt1_live = 16 + 4 * g < D;                  // rows 16 + 4g .. of the second d tile are real head dims
+
+  // Persistent: 2 workgroups per CU, each walking heads w, w + gridDim.x, ...; the rows of the NEXT head are
+  // requested right after the sweep of the current one and land in registers while its gradients are written out.
+  // Every workgroup alternates a sweep (VALU / MFMA, memory idle) with a memory phase (gradients out, rows in), and
+  // workgroups launched together stay in lockstep - the whole chip alternates and the phase times add (525 us for
+  // the 10240 heads of the bench shape).  So the second workgroup of every CU starts p.stagger x 3.4 us late, once:
+  // the two then interleave for the rest of the kernel, one sweeping while the other moves data: 450 us.
+  HeadRegs R;
+  int w = blockIdx.x;
+  if (w < nheads) issue(w, R);
+  if (p.stagger > 0 && (int)blockIdx.x >= p.ncu)
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);             // 127 x 64 clocks each
+
+  for (; w < nheads; w += gridDim.x) {
+    int blk, h, b;
+    work_item_at(w, 1, H, p.B, blk, h, b);
+    const int tq = tid + opaque_zero();
+    const int ci = tq & 3, r0 = tq >> 2;
+    // ---- K / V rows to LDS, lse and delta = rowsum(dO * O) to their arrays, dQ image to zero
+    lse_l[tid] = tid < L ? R.lse * LOG2E : INFINITY;       // +inf: p = 2^-inf = 0 past the end
+    if (cpr < 4 && ci >= cpr) {                            // the pad chunk: zeros in LDS
+      const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) R.k[ps] = R.v[ps] = R.q[ps] = R.d[ps] = R.o[ps] = z;
+    }
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int row = ps * 64 + r0;
+      *reinterpret_cast<u32x4*>(qtile + swz64(row, ci)) = R.k[ps];
+      *reinterpret_cast<u32x4*>(dotile + swz64(row, ci)) = R.v[ps];
+      float acc = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc += bf16_to_f32(R.o[ps][e] & 0xffffu) * bf16_to_f32(R.d[ps][e] & 0xffffu);
+        acc += bf16_to_f32(R.o[ps][e] >> 16) * bf16_to_f32(R.d[ps][e] >> 16);
+      }
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      if (ci == 0) {
+        const bool ok = row < L;
+        dl_l[row] = ok ? acc : 0.f;
+        if (ok) p.delta[((long)b * H + h) * L + row] = acc;
+      }
+    }
+    for (int i = 0; i < ILD; i += 4) *reinterpret_cast<f32x4*>(img + tid * ILD + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    bf16x8 kf[KTW], vf[KTW], ktf[DT][2];
+    float kbias[KTW];
+#pragma unroll
+    for (int kt = 0; kt < KTW; ++kt) {
+      kf[kt] = *reinterpret_cast<const bf16x8*>(qtile + (wid * 64 + kt * 16) * 64 + off_rf);
+      vf[kt] = *reinterpret_cast<const bf16x8*>(dotile + (wid * 64 + kt * 16) * 64 + off_rf);
+      kbias[kt] = (wid * 64 + kt * 16 + li < L && R.km[kt]) ? 0.f : -INFINITY;
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) ktf[dt][c] = tr_frag_off(qtile + (wid * 64 + c * 32) * 64, off_tr[dt]);   // K~^T
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      *reinterpret_cast<u32x4*>(qtile + swz64(ps * 64 + r0, ci)) = R.q[ps];
+      *reinterpret_cast<u32x4*>(dotile + swz64(ps * 64 + r0, ci)) = R.d[ps];
+    }
+    __syncthreads();
+
+    f32x4 dk[DT][KTW], dv[DT][KTW];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int kt = 0; kt < KTW; ++kt) { dk[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt][kt] = dk[dt][kt]; }
+
+#pragma unroll 1
+    for (int step = 0; step < LQ / 32; ++step) {
+      const int j = (step + wid) & (LQ / 32 - 1);
+      if (j * 32 < L) {                                     // wave-uniform
+        const char* qt_ = qtile + j * 32 * 64;
+        const char* dt_ = dotile + j * 32 * 64;
+        f32x4 s[2][KTW], dp[2][KTW];
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+          const bf16x8 qa = *reinterpret_cast<const bf16x8*>(qt_ + qq * 1024 + off_rf);
+          const bf16x8 da = *reinterpret_cast<const bf16x8*>(dt_ + qq * 1024 + off_rf);
+#pragma unroll
+          for (int kt = 0; kt < KTW; ++kt) {
+            // columns of S are this lane's keys: start the accumulator at 0 / -inf for a valid / masked key
+            s[qq][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                qa, kf[kt], f32x4{kbias[kt], kbias[kt], kbias[kt], kbias[kt]}, 0, 0, 0);
+            dp[qq][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          }
+        }
+        // rows of the accumulators are queries (4g + r), columns are this lane's key
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+          const f32x4 ls = *reinterpret_cast<const f32x4*>(lse_l + j * 32 + qq * 16 + 4 * g);
+          const f32x4 dd = *reinterpret_cast<const f32x4*>(dl_l + j * 32 + qq * 16 + 4 * g);
+#pragma unroll
+          for (int kt = 0; kt < KTW; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float pv = fast_exp2(s[qq][kt][r] * c2 - ls[r]);
+              s[qq][kt][r] = pv;                                  // P
+              dp[qq][kt][r] = pv * (dp[qq][kt][r] - dd[r]);       // dS
+            }
+        }
+        bf16x8 dot_f[DT], qt_f[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          dot_f[dt] = tr_frag_off(dt_, off_tr[dt]);               // dO^T
+          qt_f[dt] = tr_frag_off(qt_, off_tr[dt]);                // Q~^T
+        }
+        f32x4 dq[DT][2];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { dq[dt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dq[dt][1] = dq[dt][0]; }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+          for (int ktl = 0; ktl < 2; ++ktl) {
+            const int kt = 2 * c + ktl;
+            const bf16x8 pbf = pack_acc_pair(s[0][kt], s[1][kt]);
+            const bf16x8 dsf = pack_acc_pair(dp[0][kt], dp[1][kt]);
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+              u32x2 wv;
+              wv[0] = ((unsigned int)(unsigned short)dsf[4 * qq + 0]) | ((unsigned int)(unsigned short)dsf[4 * qq + 1] << 16);
+              wv[1] = ((unsigned int)(unsigned short)dsf[4 * qq + 2]) | ((unsigned int)(unsigned short)dsf[4 * qq + 3] << 16);
+              *reinterpret_cast<u32x2*>(dst + c * 2048 + ktl * 1024 + off_dw[qq]) = wv;
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+              dv[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_f[dt], pbf, dv[dt][kt], 0, 0, 0);
+              dk[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_f[dt], dsf, dk[dt][kt], 0, 0, 0);
+            }
+          }
+          // dQ^T[d][q] += K~^T[d][32 keys of chunk c] dS^T[32 keys][q]
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq) {
+            const bf16x8 dsb = tr_frag_off(dst + c * 2048, swz64(trow, qq * 2 + ((li & 3) >> 1)) + 8 * (li & 1));
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+              dq[dt][qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[dt][c], dsb, dq[dt][qq], 0, 0, 0);
+          }
+        }
+        // this wave's 64-key share of dQ for query block j: plain read-add-write, no other wave is on block j now
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+          float* row = img + (j * 32 + qq * 16 + li) * ILD + 4 * g;
+          f32x4 a = *reinterpret_cast<f32x4*>(row);
+          a += dq[0][qq] * p.scale;
+          *reinterpret_cast<f32x4*>(row) = a;
+          if (dt1_live) {
+            f32x4 c1 = *reinterpret_cast<f32x4*>(row + 16);
+            c1 += dq[1][qq] * p.scale;
+            *reinterpret_cast<f32x4*>(row + 16) = c1;
+          }
+        }
+      }
+      __syncthreads();
+    }
+
+    // ---- this thread's rotate-half table row first, then the next head's rows (consumed at the top of the next
+    // iteration).  The request is unconditional - the last head of a workgroup asks for its own rows again, L2 hits
+    // nobody consumes - because a branch here makes the compiler wait for vmcnt(0) at the first use of the tables
+    // (on the not-taken path they are the youngest loads), which waits for the whole prefetch as well.
+    RopeRow<D> T;
+    if (ROPE) load_rope_row<D>(T, p.cosT, p.sinT, tq < L ? tq : L - 1);
+    issue(w + (int)gridDim.x < nheads ? w + (int)gridDim.x : w, R);
+
+    // ---- dQ rows from the image; dK~ (f32, RoPE^T wants f32 pairs) and dV (bf16) through images over the now dead
+    // Q / dO / dS^T region
+    float* img2 = reinterpret_cast<float*>(smem);
+    char* dvimg = D <= 24 ? smem + LQ * ILD * 4 : reinterpret_cast<char*>(dl_l + LQ);   // bf16 [256][64 B]
+#pragma unroll
+    for (int kt = 0; kt < KTW; ++kt)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+        if (dt == 0 || dt1_live) {
+          const int key = wid * 64 + kt * 16 + li, d = dt * 16 + 4 * g;
+          *reinterpret_cast<f32x4*>(img2 + key * ILD + d) = dk[dt][kt] * p.scale;
+          u32x2 wv;
+          wv[0] = pack_bf16x2(dv[dt][kt][0], dv[dt][kt][1]);
+          wv[1] = pack_bf16x2(dv[dt][kt][2], dv[dt][kt][3]);
+          *reinterpret_cast<u32x2*>(dvimg + key * 64 + d * 2) = wv;
+        }
+    __syncthreads();
+    if (tq < L) {
+      unsigned short* dqrow = p.dqkv + (long)b * L * tokstride + (long)h * D + (unsigned int)tq * (unsigned int)tokstride;
+      store_grad_row<ROPE, D>(img + tq * ILD, dqrow, T);
+      store_grad_row<ROPE, D>(img2 + tq * ILD, dqrow + H * D, T);
+#pragma unroll
+      for (int c = 0; c < cpr; ++c)
+        *reinterpret_cast<u32x4*>(dqrow + 2 * H * D + 8 * c) = *reinterpret_cast<const u32x4*>(dvimg + tq * 64 + 16 * c);
+    }
+    __syncthreads();                                       // the images are read; the next head may stage over them
+  }
+}
+
+int attn_cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
 template <int DP> constexpr size_t lds_fwd() { return (size_t)2 * Geo<DP>::KVB * Geo<DP>::RS + 256; }
 template <int DP> constexpr size_t lds_dq() {
   const size_t rows = 256 * (size_t)Geo<DP>::RS + 128 * 4 + 256;
@@ -755,8 +1124,43 @@ int launch_fwd(const AP& p, hipStream_t st) {
   return clipk_check_launch();
 }
 
+template <bool ROPE, int D>
+void launch_fused(const AP& p, int nwg, hipStream_t st) {
+  constexpr size_t lds = lds_fused(D);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused32_kernel<ROPE, D>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_bwd_fused32_kernel<ROPE, D>), dim3(nwg), dim3(256), lds, st, p);
+}
+
 template <int DP, int DR>
 int launch_bwd(const AP& p, hipStream_t st) {
+  if constexpr (DP == 32) {
+    // whole-head kernel for the short-head encoders (ESM-2 8M / 35M / 150M at L <= 256); CLIPK_ATTN_FUSED_BWD=0
+    // keeps the two-kernel path (tests compare the two)
+    const char* fe = getenv("CLIPK_ATTN_FUSED_BWD");       // read per call: the tests flip it
+    const bool fused_on = !(fe && atoi(fe) == 0);
+    // q / k must arrive rotated (clipk_rope_qk) or unrotated-by-design: the chunk-per-lane staging cannot rotate
+    if (fused_on && p.L > 128 && p.L <= FUSED_LMAX && p.D >= 16 && (DR == 0 || p.pre_rot)) {
+      AP pp = p;
+      pp.ncu = attn_cu_count();
+      int nwg = 2 * pp.ncu;                               // two resident workgroups per CU (LDS: 78 KiB each at D = 24)
+      if (nwg > p.H * p.B) nwg = p.H * p.B;
+      // start-up offset of the second workgroup of every CU: about half a head time (26 us per head at L = 256,
+      // one unit = s_sleep 127 = 3.4 us), nothing when there are not even two heads per workgroup to interleave
+      pp.stagger = (p.H * p.B >= 2 * nwg) ? (int)(5.0 * p.L * p.L / 65536.0 + 0.5) : 0;
+      { const char* e = getenv("CLIPK_ATTN_STAGGER"); if (e) pp.stagger = atoi(e); }
+      switch (p.D) {
+        case 16: launch_fused<(DR > 0), 16>(pp, nwg, st); break;
+        case 24: launch_fused<(DR > 0), 24>(pp, nwg, st); break;
+        default: launch_fused<(DR > 0), 32>(pp, nwg, st); break;
+      }
+      return clipk_check_launch();
+    }
+  }
   constexpr size_t l1 = lds_dq<DP>(), l2 = lds_dkv<DP>();
   if (l1 > 65536)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<DP, DR>),

@@ -190,10 +190,11 @@ def test_weight_cache_batched_refresh(dev):
 
 
 @pytest.mark.parametrize("B,L,H,D", [(3, 100, 4, 24), (2, 256, 20, 24), (2, 130, 2, 64)])
-def test_rope_prerotation_equals_rotation_at_staging(dev, B, L, H, D):
+def test_rope_prerotation_equals_rotation_at_staging(dev, B, L, H, D, monkeypatch):
     """clipk_rope_qk (in place, once) + attention without forward rotation == attention that rotates q / k while
-    staging them: identical bf16 values reach the MFMAs, so outputs, LSE and dqkv are bit-identical."""
+    staging them: identical bf16 values reach the MFMAs, so outputs, LSE and dqkv (same kernels) are bit-identical."""
     ops = _ops()
+    monkeypatch.setenv("CLIPK_ATTN_FUSED_BWD", "0")
     qkv = _rand((B * L, 3 * H * D), dev, 60, dtype=torch.bfloat16)
     dout = _rand((B * L, H * D), dev, 61, dtype=torch.bfloat16)
     inv = 1.0 / (10000 ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
@@ -209,6 +210,12 @@ def test_rope_prerotation_equals_rotation_at_staging(dev, B, L, H, D):
     g2 = ops.attn_bwd(rot, o2, dout, lse2, B, L, H, D, key_mask=mask, rope=rope, q_scale=D ** -0.5, prerotated=True)
     assert torch.equal(o1, o2) and torch.equal(lse1, lse2)
     assert torch.equal(g1, g2)
+    # default dispatch: short heads at 128 < L <= 256 take the whole-head backward when q / k arrive rotated; it sums
+    # in another order, so agreement there is to bf16 rounding
+    monkeypatch.delenv("CLIPK_ATTN_FUSED_BWD")
+    g3 = ops.attn_bwd(rot, o2, dout, lse2, B, L, H, D, key_mask=mask, rope=rope, q_scale=D ** -0.5, prerotated=True)
+    m3 = mask.view(B * L, 1).float()
+    assert ((g3.float() - g1.float()) * m3).abs().max().item() < 8e-3 * (g1.float() * m3).abs().max().item()
 
 
 # ------------------------------------------------------------------------------------------------ simce
@@ -382,6 +389,10 @@ def _rope_tables(L, D, dev):
     (1, 300, 2, 160, False, True),     # notebook RBP head dim (1280/8)
     (2, 1024, 2, 64, True, False),     # ESM-2-650M head shape, L = 1024
     (1, 130, 3, 128, True, True),
+    (3, 200, 4, 24, True, True),       # whole-head backward kernel (hd <= 32, 128 < L <= 256): ragged + padding
+    (2, 256, 4, 32, True, True),
+    (2, 130, 3, 16, False, True),
+    (9, 256, 5, 24, False, False),     # batch not a multiple of 8 (plain work-item order)
 ])
 def test_attention_fwd_bwd(dev, B, L, H, D, use_rope, use_mask):
     ops = _ops()
@@ -414,6 +425,34 @@ def test_attention_fwd_bwd(dev, B, L, H, D, use_rope, use_mask):
     # determinism: same inputs, bitwise same gradient
     dqkv2 = ops.attn_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=mask, rope=rope, q_scale=scale)
     assert torch.equal(dqkv, dqkv2)
+
+
+@pytest.mark.parametrize("B,L,H,D,use_rope", [(8, 256, 20, 24, True), (3, 190, 4, 32, False), (2, 256, 3, 16, True)])
+def test_attention_bwd_whole_head_vs_two_kernel(dev, B, L, H, D, use_rope, monkeypatch):
+    """The whole-head backward (one workgroup per head, 5 products) against the dQ + dK/dV kernel pair (7 products)
+    on the same inputs: same arithmetic up to the f32 summation order over query / key blocks, so they agree to bf16 rounding."""
+    ops = _ops()
+    qkv = _rand((B * L, 3 * H * D), dev, 70, 1.0, dtype=torch.bfloat16)
+    dout = _rand((B * L, H * D), dev, 71, 1.0, dtype=torch.bfloat16)
+    scale = D ** -0.5
+    rope = _rope_tables(L, D, dev) if use_rope else None
+    lens = torch.tensor([L] + [max(1, L - 23 * (i + 1)) for i in range(B - 1)])
+    mask = (torch.arange(L)[None] < lens[:, None]).to(torch.uint8).contiguous().to(dev)
+    dout = (dout.view(B, L, -1) * mask[..., None].to(dout.dtype)).view(B * L, -1).contiguous()
+    if use_rope:
+        qkv = ops.rope_qk_(qkv, B, L, H, D, rope)               # the whole-head kernel wants q / k rotated already
+    out, lse = ops.attn_fwd(qkv, B, L, H, D, key_mask=mask, rope=None, q_scale=scale)
+    kw = dict(key_mask=mask, rope=rope, q_scale=scale, prerotated=use_rope)
+    monkeypatch.setenv("CLIPK_ATTN_FUSED_BWD", "0")
+    g2 = ops.attn_bwd(qkv, out, dout, lse, B, L, H, D, **kw).float()
+    monkeypatch.setenv("CLIPK_ATTN_FUSED_BWD", "1")
+    g1 = ops.attn_bwd(qkv, out, dout, lse, B, L, H, D, **kw).float()
+    assert torch.equal(g1, ops.attn_bwd(qkv, out, dout, lse, B, L, H, D, **kw).float())      # reproducible
+    m3 = mask.view(B * L, 1).float()
+    g1, g2 = g1 * m3, g2 * m3
+    assert torch.isfinite(g1).all()
+    denom = g2.abs().max().item()
+    assert (g1 - g2).abs().max().item() / denom < 8e-3       # one bf16 ulp of the largest gradient
 
 
 # ------------------------------------------------------------------------------------------------ misc
