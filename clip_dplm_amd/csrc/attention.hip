@@ -35,7 +35,6 @@ struct AP {
   const unsigned short* dout; float* delta; unsigned short* dqkv;
   int B, L, H, D;
   float scale;
-  int stagger, ncu; // whole-head backward: start-up phase offset of the second resident workgroup per CU
   int pre_rot;      // backward: q / k in `qkv` are already rotated (clipk_rope_qk): stage them as they are, the
                     // gradients still leave through RoPE^T
 };
@@ -895,15 +894,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(const AP p) {
 
   // Persistent: 2 workgroups per CU, each walking heads w, w + gridDim.x, ...; the rows of the NEXT head are
   // requested right after the sweep of the current one and land in registers while its gradients are written out.
-  // Every workgroup alternates a sweep (VALU / MFMA, memory idle) with a memory phase (gradients out, rows in), and
-  // workgroups launched together stay in lockstep - the whole chip alternates and the phase times add (525 us for
-  // the 10240 heads of the bench shape).  So the second workgroup of every CU starts p.stagger x 3.4 us late, once:
-  // the two then interleave for the rest of the kernel, one sweeping while the other moves data: 450 us.
+  // (Tried and dropped: a start-up offset between the two workgroups of a CU so that one sweeps while the other moves
+  // data.  Timed in interleaved rounds on a warm GPU it changes nothing - 450 us with or without; the gain first
+  // measured came from the clock ramp of the first few hundred launches of a process.)
   HeadRegs R;
   int w = blockIdx.x;
   if (w < nheads) issue(w, R);
-  if (p.stagger > 0 && (int)blockIdx.x >= p.ncu)
-    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);             // 127 x 64 clocks each
 
   for (; w < nheads; w += gridDim.x) {
     int blk, h, b;
@@ -1145,18 +1141,12 @@ int launch_bwd(const AP& p, hipStream_t st) {
     const bool fused_on = !(fe && atoi(fe) == 0);
     // q / k must arrive rotated (clipk_rope_qk) or unrotated-by-design: the chunk-per-lane staging cannot rotate
     if (fused_on && p.L > 128 && p.L <= FUSED_LMAX && p.D >= 16 && (DR == 0 || p.pre_rot)) {
-      AP pp = p;
-      pp.ncu = attn_cu_count();
-      int nwg = 2 * pp.ncu;                               // two resident workgroups per CU (LDS: 78 KiB each at D = 24)
+      int nwg = 2 * attn_cu_count();                      // two resident workgroups per CU (LDS: 78 KiB each at D = 24)
       if (nwg > p.H * p.B) nwg = p.H * p.B;
-      // start-up offset of the second workgroup of every CU: about half a head time (26 us per head at L = 256,
-      // one unit = s_sleep 127 = 3.4 us), nothing when there are not even two heads per workgroup to interleave
-      pp.stagger = (p.H * p.B >= 2 * nwg) ? (int)(5.0 * p.L * p.L / 65536.0 + 0.5) : 0;
-      { const char* e = getenv("CLIPK_ATTN_STAGGER"); if (e) pp.stagger = atoi(e); }
       switch (p.D) {
-        case 16: launch_fused<(DR > 0), 16>(pp, nwg, st); break;
-        case 24: launch_fused<(DR > 0), 24>(pp, nwg, st); break;
-        default: launch_fused<(DR > 0), 32>(pp, nwg, st); break;
+        case 16: launch_fused<(DR > 0), 16>(p, nwg, st); break;
+        case 24: launch_fused<(DR > 0), 24>(p, nwg, st); break;
+        default: launch_fused<(DR > 0), 32>(p, nwg, st); break;
       }
       return clipk_check_launch();
     }

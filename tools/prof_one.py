@@ -35,9 +35,11 @@ if which in ("attn_esm_bwd", "attn_rna_bwd"):
         inv = 1.0 / (10000 ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
         fr = torch.arange(L, dtype=torch.float32)[:, None] * inv[None]
         r = (fr.cos().contiguous().to(dev), fr.sin().contiguous().to(dev))
-    out, lse = ops.attn_fwd(qkv, B, L, H, D, rope=r, q_scale=D ** -0.5)
+    if r is not None:
+        qkv = ops.rope_qk_(qkv, B, L, H, D, r)                # as the encoder does: rotate once, attention sees rotated q / k
+    out, lse = ops.attn_fwd(qkv, B, L, H, D, rope=None, q_scale=D ** -0.5)
     dout = rnd((B * L, H * D))
-    f = lambda: ops.attn_bwd(qkv, out, dout, lse, B, L, H, D, rope=r, q_scale=D ** -0.5)
+    f = lambda: ops.attn_bwd(qkv, out, dout, lse, B, L, H, D, rope=r, q_scale=D ** -0.5, prerotated=r is not None)
 for _ in range(5):
     f()
 torch.cuda.synchronize()
