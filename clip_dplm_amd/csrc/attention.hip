@@ -131,10 +131,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int RS, int row0, in
   return f;
 }
 __device__ __forceinline__ bf16x8 pack_acc_pair(const f32x4 a, const f32x4 b) {
-  bf16x8 f;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) { f[r] = (short)f32_to_bf16(a[r]); f[4 + r] = (short)f32_to_bf16(b[r]); }
-  return f;
+  const u32x4 w = {pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
+  return __builtin_bit_cast(bf16x8, w);
 }
 __device__ __forceinline__ float group_max(float v) {   // across the 4 lane groups sharing lane&15
   v = fmaxf(v, __shfl_xor(v, 16, 64));
@@ -1012,10 +1010,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(const AP p) {
             const bf16x8 dsf = pack_acc_pair(dp[0][kt], dp[1][kt]);
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
-              u32x2 wv;
-              wv[0] = ((unsigned int)(unsigned short)dsf[4 * qq + 0]) | ((unsigned int)(unsigned short)dsf[4 * qq + 1] << 16);
-              wv[1] = ((unsigned int)(unsigned short)dsf[4 * qq + 2]) | ((unsigned int)(unsigned short)dsf[4 * qq + 3] << 16);
-              *reinterpret_cast<u32x2*>(dst + c * 2048 + ktl * 1024 + off_dw[qq]) = wv;
+              const u32x4 dsw = __builtin_bit_cast(u32x4, dsf);
+              *reinterpret_cast<u32x2*>(dst + c * 2048 + ktl * 1024 + off_dw[qq]) = u32x2{dsw[2 * qq], dsw[2 * qq + 1]};
             }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {

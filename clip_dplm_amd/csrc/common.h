@@ -23,8 +23,12 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
   __bf16 b = (__bf16)f;
   return __builtin_bit_cast(unsigned short, b);
 }
+// two at a time: ONE v_cvt_pk_bf16_f32 (converting the halves separately costs two of them plus an sdwa-or)
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
-  return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+  typedef __attribute__((ext_vector_type(2))) float v2f;
+  typedef __attribute__((ext_vector_type(2))) __bf16 v2b;
+  const v2b v = __builtin_convertvector(v2f{lo, hi}, v2b);
+  return __builtin_bit_cast(unsigned int, v);
 }
 
 // erf-GELU with erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7: f32-rounding level, far below the bf16
