@@ -71,11 +71,9 @@ template <int DP> struct Geo {
   // minimum resident workgroups per CU asked of the register allocator.  Left alone hipcc spends 296 / 308 VGPRs on
   // the D = 96 backward kernels (one wave per SIMD, every LDS / HBM latency exposed); capped at 256 they spill 32 /
   // 72 registers and still run 1.3x faster (1330 -> 1010 us), D = 24: 915 -> 815 us backward, 380 -> 330 us forward
-  // Backward kernels: element-wise part two scores at a time on the packed-f32 pipe (v_pk_fma/add/mul) with the key
-  // mask folded into the accumulator start value.  Measured and left OFF: D = 24 backward 816 -> 837 us (the pairs
-  // cost registers and moves), D = 96 dK/dV 72 -> 147 spilled VGPRs.  The forward kernel's packed softmax is unconditional
-  // (329 -> 315 us at D = 24, 323 -> 307 us at D = 96).
-  static constexpr bool PACKED_SOFTMAX = false;
+  // (Tried for the backward kernels and dropped: the element-wise part two scores at a time on the packed-f32 pipe.
+  // D = 24: 816 -> 837 us, the pairs cost registers and moves; D = 96 dK/dV: 72 -> 147 spilled VGPRs.  The forward
+  // kernel's packed softmax stays: 329 -> 315 us at D = 24, 323 -> 307 us at D = 96.)
   static constexpr int WG_FWD = (DP <= 32) ? 4 : (DP <= 96 ? 2 : 1);
   static constexpr int WG_BWD = (DP <= 32) ? 3 : (DP <= 96 ? 2 : 1);
 };
@@ -393,11 +391,11 @@ __device__ __forceinline__ void load_rope_row(RopeRow<D>& T, const float* cosT, 
 }
 // f32 image row (gradient w.r.t. the rotated q / k) -> RoPE^T -> bf16 row of dqkv
 template <bool ROPE, int D>
-__device__ __forceinline__ void store_grad_row(const float* row, unsigned short* dst, const RopeRow<D>& T) {
+__device__ __forceinline__ void store_grad_row(const float* row, unsigned short* dst, const RopeRow<D>& T, float scale) {
   constexpr int NG = D / 4;
   f32x4 x[NG];
 #pragma unroll
-  for (int i = 0; i < NG; ++i) x[i] = *reinterpret_cast<const f32x4*>(row + 4 * i);
+  for (int i = 0; i < NG; ++i) x[i] = *reinterpret_cast<const f32x4*>(row + 4 * i) * scale;
   if (ROPE) {
 #pragma unroll
     for (int i = 0; i < NG / 2; ++i) {
@@ -513,7 +511,9 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dq_kernel(const
 #pragma unroll
         for (int r = 0; r < 4; ++r) s[kt][0][r] = ((mk >> (8 * r)) & 0xffu) ? 0.f : -INFINITY;
         s[kt][1] = s[kt][0];
-        dp[kt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[kt][1] = dp[kt][0];
+        // dP accumulators start at -delta of their query column: the MFMAs deliver dP - delta, no subtraction per score
+        dp[kt][0] = f32x4{-dl[0], -dl[0], -dl[0], -dl[0]};
+        dp[kt][1] = f32x4{-dl[1], -dl[1], -dl[1], -dl[1]};
       }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
@@ -527,31 +527,16 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dq_kernel(const
           dp[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[1][ks], dp[kt][1], 0, 0, 0);
         }
       // dS^T = P (dP - delta), P = 2^(s c2 - lse + kb), kb = 0 / -inf for a valid / masked key (one select per key
-      // row instead of one per element).  The two query tiles of a lane share the packed-f32 pipe: 4 packed
-      // instructions + 2 v_exp per element pair.
-      if constexpr (Geo<DP>::PACKED_SOFTMAX) {
-        const f32x2 cc = splat2(c2), nl = {-lse2[0], -lse2[1]}, dl2 = {dl[0], dl[1]};
+      // row instead of one per element)
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
+      for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const f32x2 a = __builtin_elementwise_fma(f32x2{s[kt][0][r], s[kt][1][r]}, cc, nl);
-            const f32x2 pv = {fast_exp2(a[0]), fast_exp2(a[1])};
-            const f32x2 ds = pv * (f32x2{dp[kt][0][r], dp[kt][1][r]} - dl2);    // dS^T (w.r.t. the scaled score)
-            s[kt][0][r] = ds[0]; s[kt][1][r] = ds[1];
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) {
+            const float pv = fast_exp2(s[kt][qt][r] * c2 - lse2[qt]);
+            s[kt][qt][r] = pv * dp[kt][qt][r];                     // dS^T (w.r.t. the scaled score)
           }
-        }
-      } else {
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-              const float pv = fast_exp2(s[kt][qt][r] * c2 - lse2[qt]);
-              s[kt][qt][r] = pv * (dp[kt][qt][r] - dl[qt]);          // dS^T (w.r.t. the scaled score)
-            }
-      }
       bf16x8 db[2][2];
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
@@ -662,7 +647,7 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dkv_kernel(cons
       const bool ok = q < L;
       // queries past the end: lse = +inf makes p = exp2(-inf) = 0
       lse_l[tid] = ok ? p.lse[((long)b * H + h) * L + q] * LOG2E : INFINITY;
-      dl_l[tid] = ok ? p.delta[((long)b * H + h) * L + q] : 0.f;
+      dl_l[tid] = ok ? -p.delta[((long)b * H + h) * L + q] : 0.f;      // NEGATED: the dP accumulators start from it
     }
     __syncthreads();
     if (qb + 1 < nqb) st.load(qbase, tokstride, dobase, ostride, (qb + 1) * QB, L, cpr);   // prefetch under the MFMAs
@@ -670,68 +655,44 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dkv_kernel(cons
 #pragma unroll
     for (int s2 = 0; s2 < NS2; ++s2) {                     // 32 queries at a time
       if (qb * QB + s2 * 32 >= L) break;
-      f32x4 s[2][KTW], dp[2][KTW];
+      // one 16-query tile at a time: its P and dS leave the f32 accumulators as packed bf16 before the next tile's
+      // accumulators are needed.  Rows of the accumulators are queries (4g + r), columns are this lane's key: S
+      // starts at 0 / -inf for a valid / masked key, dP at -delta of its row (the MFMAs then deliver dP - delta)
+      u32x2 pk[2][KTW], dsk[2][KTW];
 #pragma unroll
-      for (int qq = 0; qq < 2; ++qq)
+      for (int qq = 0; qq < 2; ++qq) {
+        const int row = (2 * s2 + qq) * 16 + li;
+        const f32x4 nd = *reinterpret_cast<const f32x4*>(dl_l + (2 * s2 + qq) * 16 + 4 * g);
+        f32x4 s[KTW], dp[KTW];
 #pragma unroll
-        for (int kt = 0; kt < KTW; ++kt) {
-          // columns of S are this lane's keys: start the accumulator at 0 / -inf for a valid / masked key
-          s[qq][kt] = f32x4{kbias[kt], kbias[kt], kbias[kt], kbias[kt]};
-          dp[qq][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int kt = 0; kt < KTW; ++kt) { s[kt] = f32x4{kbias[kt], kbias[kt], kbias[kt], kbias[kt]}; dp[kt] = nd; }
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int qq = 0; qq < 2; ++qq) {
-          const int row = (2 * s2 + qq) * 16 + li;
+        for (int ks = 0; ks < KS; ++ks) {
           const bf16x8 qa = row_frag(qtile, RS, row, ks, lane);
           const bf16x8 da = row_frag(dotile, RS, row, ks, lane);
 #pragma unroll
           for (int kt = 0; kt < KTW; ++kt) {
-            s[qq][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kt][ks], s[qq][kt], 0, 0, 0);
-            dp[qq][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kt][ks], dp[qq][kt], 0, 0, 0);
+            s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kt][ks], s[kt], 0, 0, 0);
+            dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kt][ks], dp[kt], 0, 0, 0);
           }
         }
-      // rows of the accumulators are queries (4g+r), columns are this lane's key
-      if constexpr (Geo<DP>::PACKED_SOFTMAX) {
-        // P = 2^(s c2 - lse + kb[kt]) with kb = 0 / -inf for this lane's key; the two query tiles share the packed-
-        // f32 pipe (4 packed instructions + 2 v_exp per element pair, no select)
-        const f32x4 ls0 = *reinterpret_cast<const f32x4*>(lse_l + (2 * s2 + 0) * 16 + 4 * g);
-        const f32x4 ls1 = *reinterpret_cast<const f32x4*>(lse_l + (2 * s2 + 1) * 16 + 4 * g);
-        const f32x4 dd0 = *reinterpret_cast<const f32x4*>(dl_l + (2 * s2 + 0) * 16 + 4 * g);
-        const f32x4 dd1 = *reinterpret_cast<const f32x4*>(dl_l + (2 * s2 + 1) * 16 + 4 * g);
-        const f32x2 cc = splat2(c2);
+        const f32x4 ls = *reinterpret_cast<const f32x4*>(lse_l + (2 * s2 + qq) * 16 + 4 * g);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const f32x2 nl = {-ls0[r], -ls1[r]}, dd = {dd0[r], dd1[r]};
+        for (int kt = 0; kt < KTW; ++kt) {
 #pragma unroll
-          for (int kt = 0; kt < KTW; ++kt) {
-            const f32x2 a = __builtin_elementwise_fma(f32x2{s[0][kt][r], s[1][kt][r]}, cc, nl);
-            const f32x2 pv = {fast_exp2(a[0]), fast_exp2(a[1])};
-            const f32x2 ds = pv * (f32x2{dp[0][kt][r], dp[1][kt][r]} - dd);
-            s[0][kt][r] = pv[0]; s[1][kt][r] = pv[1];             // P
-            dp[0][kt][r] = ds[0]; dp[1][kt][r] = ds[1];           // dS
+          for (int r = 0; r < 4; ++r) {
+            const float pv = fast_exp2(s[kt][r] * c2 - ls[r]);
+            s[kt][r] = pv;                                      // P
+            dp[kt][r] = pv * dp[kt][r];                         // dS = P (dP - delta)
           }
-        }
-      } else {
-#pragma unroll
-        for (int qq = 0; qq < 2; ++qq) {
-          const f32x4 ls = *reinterpret_cast<const f32x4*>(lse_l + (2 * s2 + qq) * 16 + 4 * g);
-          const f32x4 dd = *reinterpret_cast<const f32x4*>(dl_l + (2 * s2 + qq) * 16 + 4 * g);
-#pragma unroll
-          for (int kt = 0; kt < KTW; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float pv = fast_exp2(s[qq][kt][r] * c2 - ls[r]);
-              s[qq][kt][r] = pv;                                  // P
-              dp[qq][kt][r] = pv * (dp[qq][kt][r] - dd[r]);       // dS
-            }
+          pk[qq][kt] = u32x2{pack_bf16x2(s[kt][0], s[kt][1]), pack_bf16x2(s[kt][2], s[kt][3])};
+          dsk[qq][kt] = u32x2{pack_bf16x2(dp[kt][0], dp[kt][1]), pack_bf16x2(dp[kt][2], dp[kt][3])};
         }
       }
 #pragma unroll
       for (int kt = 0; kt < KTW; ++kt) {
-        const bf16x8 pbf = pack_acc_pair(s[0][kt], s[1][kt]);
-        const bf16x8 dsf = pack_acc_pair(dp[0][kt], dp[1][kt]);
+        const bf16x8 pbf = __builtin_bit_cast(bf16x8, u32x4{pk[0][kt][0], pk[0][kt][1], pk[1][kt][0], pk[1][kt][1]});
+        const bf16x8 dsf = __builtin_bit_cast(bf16x8, u32x4{dsk[0][kt][0], dsk[0][kt][1], dsk[1][kt][0], dsk[1][kt][1]});
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
           if (dt < dtv) {
@@ -926,7 +887,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(const AP p) {
       acc += __shfl_xor(acc, 2, 64);
       if (ci == 0) {
         const bool ok = row < L;
-        dl_l[row] = ok ? acc : 0.f;
+        dl_l[row] = ok ? -acc : 0.f;                       // NEGATED: the dP accumulators start from it
         if (ok) p.delta[((long)b * H + h) * L + row] = acc;
       }
     }
@@ -965,32 +926,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(const AP p) {
       if (j * 32 < L) {                                     // wave-uniform
         const char* qt_ = qtile + j * 32 * 64;
         const char* dt_ = dotile + j * 32 * 64;
-        f32x4 s[2][KTW], dp[2][KTW];
+        // one 16-query tile at a time: its P and dS leave the f32 accumulators as packed bf16 (2 + 2 registers per
+        // key tile) before the next tile's 32 accumulator registers are needed
+        u32x2 pk[2][KTW], dsk[2][KTW];
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq) {
           const bf16x8 qa = *reinterpret_cast<const bf16x8*>(qt_ + qq * 1024 + off_rf);
           const bf16x8 da = *reinterpret_cast<const bf16x8*>(dt_ + qq * 1024 + off_rf);
+          // rows of the accumulators are queries (4g + r), columns are this lane's key.  dP starts at -delta of its
+          // row, so the MFMA delivers dP - delta; S starts at 0 / -inf for a valid / masked key
+          const f32x4 nd = *reinterpret_cast<const f32x4*>(dl_l + j * 32 + qq * 16 + 4 * g);
+          f32x4 s[KTW], dp[KTW];
 #pragma unroll
           for (int kt = 0; kt < KTW; ++kt) {
-            // columns of S are this lane's keys: start the accumulator at 0 / -inf for a valid / masked key
-            s[qq][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+            s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                 qa, kf[kt], f32x4{kbias[kt], kbias[kt], kbias[kt], kbias[kt]}, 0, 0, 0);
-            dp[qq][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kt], nd, 0, 0, 0);
           }
-        }
-        // rows of the accumulators are queries (4g + r), columns are this lane's key
-#pragma unroll
-        for (int qq = 0; qq < 2; ++qq) {
           const f32x4 ls = *reinterpret_cast<const f32x4*>(lse_l + j * 32 + qq * 16 + 4 * g);
-          const f32x4 dd = *reinterpret_cast<const f32x4*>(dl_l + j * 32 + qq * 16 + 4 * g);
 #pragma unroll
-          for (int kt = 0; kt < KTW; ++kt)
+          for (int kt = 0; kt < KTW; ++kt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float pv = fast_exp2(s[qq][kt][r] * c2 - ls[r]);
-              s[qq][kt][r] = pv;                                  // P
-              dp[qq][kt][r] = pv * (dp[qq][kt][r] - dd[r]);       // dS
+              const float pv = fast_exp2(s[kt][r] * c2 - ls[r]);
+              s[kt][r] = pv;                                      // P
+              dp[kt][r] = pv * dp[kt][r];                         // dS = P (dP - delta)
             }
+            pk[qq][kt] = u32x2{pack_bf16x2(s[kt][0], s[kt][1]), pack_bf16x2(s[kt][2], s[kt][3])};
+            dsk[qq][kt] = u32x2{pack_bf16x2(dp[kt][0], dp[kt][1]), pack_bf16x2(dp[kt][2], dp[kt][3])};
+          }
         }
         bf16x8 dot_f[DT], qt_f[DT];
 #pragma unroll
@@ -1006,13 +970,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(const AP p) {
 #pragma unroll
           for (int ktl = 0; ktl < 2; ++ktl) {
             const int kt = 2 * c + ktl;
-            const bf16x8 pbf = pack_acc_pair(s[0][kt], s[1][kt]);
-            const bf16x8 dsf = pack_acc_pair(dp[0][kt], dp[1][kt]);
+            const bf16x8 pbf = __builtin_bit_cast(bf16x8, u32x4{pk[0][kt][0], pk[0][kt][1], pk[1][kt][0], pk[1][kt][1]});
+            const bf16x8 dsf = __builtin_bit_cast(bf16x8, u32x4{dsk[0][kt][0], dsk[0][kt][1], dsk[1][kt][0], dsk[1][kt][1]});
 #pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-              const u32x4 dsw = __builtin_bit_cast(u32x4, dsf);
-              *reinterpret_cast<u32x2*>(dst + c * 2048 + ktl * 1024 + off_dw[qq]) = u32x2{dsw[2 * qq], dsw[2 * qq + 1]};
-            }
+            for (int qq = 0; qq < 2; ++qq) *reinterpret_cast<u32x2*>(dst + c * 2048 + ktl * 1024 + off_dw[qq]) = dsk[qq][kt];
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
               dv[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_f[dt], pbf, dv[dt][kt], 0, 0, 0);
@@ -1033,11 +994,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(const AP p) {
         for (int qq = 0; qq < 2; ++qq) {
           float* row = img + (j * 32 + qq * 16 + li) * ILD + 4 * g;
           f32x4 a = *reinterpret_cast<f32x4*>(row);
-          a += dq[0][qq] * p.scale;
+          a += dq[0][qq];                                       // unscaled: store_grad_row applies q_scale once
           *reinterpret_cast<f32x4*>(row) = a;
           if (dt1_live) {
             f32x4 c1 = *reinterpret_cast<f32x4*>(row + 16);
-            c1 += dq[1][qq] * p.scale;
+            c1 += dq[1][qq];
             *reinterpret_cast<f32x4*>(row + 16) = c1;
           }
         }
@@ -1063,7 +1024,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(const AP p) {
       for (int dt = 0; dt < DT; ++dt)
         if (dt == 0 || dt1_live) {
           const int key = wid * 64 + kt * 16 + li, d = dt * 16 + 4 * g;
-          *reinterpret_cast<f32x4*>(img2 + key * ILD + d) = dk[dt][kt] * p.scale;
+          *reinterpret_cast<f32x4*>(img2 + key * ILD + d) = dk[dt][kt];
           u32x2 wv;
           wv[0] = pack_bf16x2(dv[dt][kt][0], dv[dt][kt][1]);
           wv[1] = pack_bf16x2(dv[dt][kt][2], dv[dt][kt][3]);
@@ -1072,8 +1033,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(const AP p) {
     __syncthreads();
     if (tq < L) {
       unsigned short* dqrow = p.dqkv + (long)b * L * tokstride + (long)h * D + (unsigned int)tq * (unsigned int)tokstride;
-      store_grad_row<ROPE, D>(img + tq * ILD, dqrow, T);
-      store_grad_row<ROPE, D>(img2 + tq * ILD, dqrow + H * D, T);
+      store_grad_row<ROPE, D>(img + tq * ILD, dqrow, T, p.scale);            // q_scale: once per element, here
+      store_grad_row<ROPE, D>(img2 + tq * ILD, dqrow + H * D, T, p.scale);
 #pragma unroll
       for (int c = 0; c < cpr; ++c)
         *reinterpret_cast<u32x4*>(dqrow + 2 * H * D + 8 * c) = *reinterpret_cast<const u32x4*>(dvimg + tq * 64 + 16 * c);

@@ -57,3 +57,15 @@ g1 = bwd().float()
 os.environ["CLIPK_ATTN_FUSED_BWD"] = "0"
 g0 = bwd().float()
 print(f"max rel diff {(g1 - g0).abs().max().item() / g0.abs().max().item():.2e}")
+
+# RNA encoder head shape (dQ + dK/dV pair: the whole-head kernel needs hd <= 32)
+B2, L2, H2, D2 = 512, 256, 8, 96
+q2 = torch.randn(B2 * L2, 3 * H2 * D2, generator=g).to(torch.bfloat16).to(dev)
+do2 = torch.randn(B2 * L2, H2 * D2, generator=g).to(torch.bfloat16).to(dev)
+o2, l2 = ops.attn_fwd(q2, B2, L2, H2, D2, rope=None, q_scale=D2 ** -0.5)
+t = [timeit(lambda: ops.attn_bwd(q2, o2, do2, l2, B2, L2, H2, D2, rope=None, q_scale=D2 ** -0.5)) for _ in range(3)]
+print("hd 96 backward    ", " ".join(f"{x:7.1f}" for x in t), "us")
+t = [timeit(lambda: ops.attn_fwd(q2, B2, L2, H2, D2, rope=None, q_scale=D2 ** -0.5)) for _ in range(3)]
+print("hd 96 forward     ", " ".join(f"{x:7.1f}" for x in t), "us")
+t = [timeit(lambda: ops.attn_fwd(rot, B, L, H, D, rope=None, q_scale=D ** -0.5)) for _ in range(3)]
+print("hd 24 forward     ", " ".join(f"{x:7.1f}" for x in t), "us")
