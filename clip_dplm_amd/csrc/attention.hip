@@ -177,6 +177,87 @@ struct PairStager {
   }
 };
 
+// a zero the optimiser cannot see through: values derived from `tid + opaque_zero()` inside a loop are recomputed
+// there instead of being hoisted out and kept alive (and then spilled) across the register-tight sweep
+__device__ __forceinline__ int opaque_zero() {
+  int z;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+  return z;
+}
+
+// Chunk-per-lane staging of the same block pair for the heads that need no rotation (DR == 0): consecutive lanes
+// take consecutive 16-byte chunks of a row, so one wave instruction reads whole 128-byte lines.  The row-owner form
+// above reads 16 bytes from each of 64 different lines per instruction; with 4 waves x 2 operands in flight the lines
+// do not survive in the 32 KiB L1 until the row's next chunk is asked for, and every chunk pulls a full line from
+// L2 again (8x the bytes through the L1 fill path, which is what bounded the hd = 96 kernels).
+template <int DP, int BLK>
+struct ChunkStager {
+  static constexpr int NCH = Geo<DP>::NCH;
+  static constexpr int PER_OP = BLK * NCH / 256;           // tasks per thread and operand (BLK * NCH % 256 == 0)
+  static_assert((BLK * NCH) % 256 == 0, "chunk tasks must tile the workgroup");
+  u32x4 c[2 * PER_OP];
+  int tid_, cpr_;
+
+  __device__ __forceinline__ void init(int tid) { tid_ = tid; }
+  // 32-bit element offsets from the two (uniform) bases, recomputed at every call from an opaque copy of the thread
+  // id: left to itself the compiler hoists the 2 * PER_OP 64-bit addresses out of the key / query loop and spills
+  __device__ __forceinline__ void load(const unsigned short* a_base, long a_stride, const unsigned short* b_base,
+                                       long b_stride, int pos0, int L, int cpr) {
+    cpr_ = cpr;
+    const int t = tid_ + opaque_zero();
+#pragma unroll
+    for (int it = 0; it < 2 * PER_OP; ++it) {
+      const int idl = (it % PER_OP) * 256 + t;
+      const int row = idl / NCH, ch = idl - row * NCH;
+      int pos = pos0 + row; pos = pos < L ? pos : L - 1;
+      const int chc = ch < cpr ? ch : cpr - 1;             // pad chunks re-read the last real one (dropped in store):
+      const unsigned int off = (unsigned int)pos * (unsigned int)((it < PER_OP) ? a_stride : b_stride) + 8u * chc;
+      c[it] = *reinterpret_cast<const u32x4*>(((it < PER_OP) ? a_base : b_base) + off);   // no branch around a load
+    }
+  }
+  __device__ __forceinline__ void store(char* a_tile, char* b_tile, int RS, const AP&, int, bool) {
+    const int t = tid_ + opaque_zero();
+#pragma unroll
+    for (int it = 0; it < 2 * PER_OP; ++it) {
+      const int idl = (it % PER_OP) * 256 + t;
+      const int row = idl / NCH, ch = idl - row * NCH;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(((it < PER_OP) ? a_tile : b_tile) + row * RS + ch * 16) = ch < cpr_ ? c[it] : z;
+    }
+  }
+};
+// one operand, ROWS rows (the query-side prologues)
+template <int DP, int ROWS>
+struct ChunkRows {
+  static constexpr int NCH = Geo<DP>::NCH;
+  static constexpr int NT = ROWS * NCH / 256;
+  static_assert((ROWS * NCH) % 256 == 0, "chunk tasks must tile the workgroup");
+  u32x4 c[NT];
+
+  __device__ __forceinline__ void load(const unsigned short* base, long stride, int pos0, int L, int cpr, int tid) {
+    const int t = tid + opaque_zero();
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+      const int idl = it * 256 + t;
+      const int row = idl / NCH, ch = idl - row * NCH;
+      int pos = pos0 + row; pos = pos < L ? pos : L - 1;
+      c[it] = *reinterpret_cast<const u32x4*>(base + ((unsigned int)pos * (unsigned int)stride + 8u * (ch < cpr ? ch : cpr - 1)));
+    }
+  }
+  __device__ __forceinline__ void store(char* tile, int RS, int cpr, int tid) const {
+    const int t = tid + opaque_zero();
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+      const int idl = it * 256 + t;
+      const int row = idl / NCH, ch = idl - row * NCH;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(tile + row * RS + ch * 16) = ch < cpr ? c[it] : z;
+    }
+  }
+};
+template <int DP, int DR, int BLK> struct StagerFor { typedef PairStager<DP, DR, BLK> type; };
+template <int DP, int BLK> struct StagerFor<DP, 0, BLK> { typedef ChunkStager<DP, BLK> type; };
+
 // =================================================================================================
 // forward: one workgroup = 128 queries of one (batch, head); 4 waves x 32 queries; KVB-key staged blocks
 // =================================================================================================
@@ -202,22 +283,24 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_FWD) void attn_fwd_kernel(const AP
   const int dtv = (D + 15) >> 4;
   const float c2 = p.scale * LOG2E;
 
-  // ---- issue every first-use load up front: this thread's Q row and its row of K/V block 0
-  RowRegs<NCH> rq;
-  if (tid < 128) {
-    int pq = q0 + tid; pq = pq < L ? pq : L - 1;
-    load_row<NCH>(rq, qbase + (long)pq * tokstride, cpr);
-  }
-  PairStager<DP, DR, KVB> kv;
+  // ---- issue every first-use load up front: the Q rows and K/V block 0.  The 128 Q rows borrow the [K|V] region
+  // before K/V land there
+  typename StagerFor<DP, DR, KVB>::type kv;
   kv.init(tid);
-  kv.load(kbase, tokstride, vbase, tokstride, 0, L, cpr);
-  // Q rows: RoPE in registers, then to LDS (the 128 Q rows borrow the [K|V] region before K/V land there)
-  if (tid < 128) {
-    if (DR > 0) {
-      int pq = q0 + tid; pq = pq < L ? pq : L - 1;
+  if constexpr (DR == 0) {
+    ChunkRows<DP, 128> cq;
+    cq.load(qbase, tokstride, q0, L, cpr, tid);
+    kv.load(kbase, tokstride, vbase, tokstride, 0, L, cpr);
+    cq.store(smem, RS, cpr, tid);
+  } else {
+    RowRegs<NCH> rq;                                       // row owner: RoPE in registers, then to LDS
+    int pq = q0 + tid; pq = pq < L ? pq : L - 1;
+    if (tid < 128) load_row<NCH>(rq, qbase + (long)pq * tokstride, cpr);
+    kv.load(kbase, tokstride, vbase, tokstride, 0, L, cpr);
+    if (tid < 128) {
       if (!p.pre_rot) rope_regs<(DR > 0 ? DR : 2), NCH>(rq, p.cosT + (long)pq * (DR / 2), p.sinT + (long)pq * (DR / 2));
+      store_row<NCH>(rq, smem + tid * RS);
     }
-    store_row<NCH>(rq, smem + tid * RS);
   }
   __syncthreads();
   bf16x8 qf[2][KS];
@@ -442,8 +525,42 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dq_kernel(const
   const int dtv = (D + 15) >> 4;
   const float c2 = p.scale * LOG2E;
 
-  // ---- prologue: Q rows (threads 0..127, rotated) and dO rows (threads 128..255, which also form delta)
-  {
+  // ---- prologue: Q and dO rows to LDS, delta = rowsum(dO * O) to delta_l and to global (the dK/dV kernel reads it)
+  typename StagerFor<DP, DR, KVB>::type kv;
+  kv.init(tid);
+  if constexpr (DR == 0) {
+    // chunk per lane: every (row, 16-byte chunk) task leaves its 8-term share of the row's dot product in LDS and
+    // thread r adds the shares of row r in chunk order (deterministic)
+    float* part = reinterpret_cast<float*>(mask_l + 256);              // [128 * NCH]
+    ChunkRows<DP, 128> cq, cd, co;
+    cq.load(qbase, tokstride, q0, L, cpr, tid);
+    cd.load(dobase, ostride, q0, L, cpr, tid);
+    co.load(obase, ostride, q0, L, cpr, tid);
+    kv.load(kbase, tokstride, vbase, tokstride, 0, L, cpr);
+    cq.store(smem, RS, cpr, tid);
+    cd.store(smem + 128 * RS, RS, cpr, tid);
+#pragma unroll
+    for (int it = 0; it < ChunkRows<DP, 128>::NT; ++it) {
+      const int idl = it * 256 + tid;
+      float acc = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc += bf16_to_f32(co.c[it][e] & 0xffffu) * bf16_to_f32(cd.c[it][e] & 0xffffu);
+        acc += bf16_to_f32(co.c[it][e] >> 16) * bf16_to_f32(cd.c[it][e] >> 16);
+      }
+      part[idl] = (idl % NCH) < cpr ? acc : 0.f;                        // pad chunks hold a re-read real chunk
+    }
+    __syncthreads();
+    if (tid < 128) {
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) acc += part[tid * NCH + c];
+      delta_l[tid] = acc;
+      if (q0 + tid < L) p.delta[((long)b * H + h) * L + q0 + tid] = acc;
+    }
+  } else {
+    // row owner (rows are rotated in registers): Q rows on threads 0..127, dO rows on threads 128..255, which also
+    // form delta
     PairStager<DP, DR, 128> qd;
     qd.init(tid);
     qd.load(qbase, tokstride, dobase, ostride, q0, L, cpr);
@@ -460,13 +577,11 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dq_kernel(const
           acc += bf16_to_f32(ro.c[i][e] >> 16) * bf16_to_f32(qd.r.c[i][e] >> 16);
         }
       delta_l[qd.row] = acc;
-      if (qd.pos < L) p.delta[((long)b * H + h) * L + qd.pos] = acc;      // consumed by the dK/dV kernel
+      if (qd.pos < L) p.delta[((long)b * H + h) * L + qd.pos] = acc;
     }
     qd.store(smem, smem + 128 * RS, RS, p, L, true);
+    kv.load(kbase, tokstride, vbase, tokstride, 0, L, cpr);
   }
-  PairStager<DP, DR, KVB> kv;
-  kv.init(tid);
-  kv.load(kbase, tokstride, vbase, tokstride, 0, L, cpr);
   __syncthreads();
   bf16x8 qf[2][KS], dof[2][KS];
 #pragma unroll
@@ -607,7 +722,7 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dkv_kernel(cons
   const float c2 = p.scale * LOG2E;
 
   // ---- this workgroup's keys: K (rotated) and V as B fragments B[k = d][col = key], kept in registers
-  PairStager<DP, DR, KVB> st;
+  typename StagerFor<DP, DR, KVB>::type st;
   st.init(tid);
   st.load(kbase, tokstride, vbase, tokstride, k0, L, cpr);
   st.store(qtile, dotile, RS, p, L, true);
@@ -776,14 +891,6 @@ struct HeadRegs {
   float lse;
   unsigned char km[4];
 };
-
-// a zero the optimiser cannot see through: values derived from `tid + opaque_zero()` inside a loop are recomputed
-// there instead of being hoisted out and kept alive (and then spilled) across the register-tight sweep
-__device__ __forceinline__ int opaque_zero() {
-  int z;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(z));
-  return z;
-}
 
 template <bool ROPE, int D>
 __global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(const AP p) {
@@ -1056,7 +1163,7 @@ int attn_cu_count() {
 
 template <int DP> constexpr size_t lds_fwd() { return (size_t)2 * Geo<DP>::KVB * Geo<DP>::RS + 256; }
 template <int DP> constexpr size_t lds_dq() {
-  const size_t rows = 256 * (size_t)Geo<DP>::RS + 128 * 4 + 256;
+  const size_t rows = 256 * (size_t)Geo<DP>::RS + 128 * 4 + 256 + 128 * (size_t)Geo<DP>::NCH * 4;   // + delta shares
   const size_t img = 128 * (size_t)(DP + 4) * 4;
   return rows > img ? rows : img;
 }
