@@ -68,6 +68,10 @@ template <int DP> struct Geo {
   static constexpr int DT = DP / 16;         // 16-wide d tiles
   static constexpr int NCH = DP / 8;         // 16-byte chunks per (padded) row
   static constexpr int KVB = (DP <= 96) ? 128 : 64;   // keys (or queries) per staged block
+  // keys per dK/dV workgroup.  At DP = 96 a wave owning 32 keys needs 96 accumulator + 48 fragment + 48 prefetch
+  // registers and hipcc kept part of the accumulators in scratch INSIDE the sweep, each reload waiting (vmcnt is in
+  // order) for the whole query-block prefetch; with 16 keys per wave everything stays in registers
+  static constexpr int KPB = (DP == 96) ? 64 : KVB;
   // minimum resident workgroups per CU asked of the register allocator.  Left alone hipcc spends 296 / 308 VGPRs on
   // the D = 96 backward kernels (one wave per SIMD, every LDS / HBM latency exposed); capped at 256 they spill 32 /
   // 72 registers and still run 1.3x faster (1330 -> 1010 us), D = 24: 915 -> 815 us backward, 380 -> 330 us forward
@@ -261,7 +265,7 @@ template <int DP, int BLK> struct StagerFor<DP, 0, BLK> { typedef ChunkStager<DP
 // =================================================================================================
 // forward: one workgroup = 128 queries of one (batch, head); 4 waves x 32 queries; KVB-key staged blocks
 // =================================================================================================
-template <int DP, int DR>
+template <int DP, int DR, int DX>
 __global__ __launch_bounds__(256, Geo<DP>::WG_FWD) void attn_fwd_kernel(const AP p) {
   constexpr int RS = Geo<DP>::RS, KS = Geo<DP>::KS, DT = Geo<DP>::DT, NCH = Geo<DP>::NCH, KVB = Geo<DP>::KVB;
   constexpr int NSUB = KVB / 64;
@@ -271,7 +275,9 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_FWD) void attn_fwd_kernel(const AP
   unsigned char* mask_l = reinterpret_cast<unsigned char*>(smem + 2 * KVB * RS);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
-  const int D = p.D, L = p.L, H = p.H;
+  // the head dim as a compile-time constant whenever the dispatcher knows it (DX): the `dt < dtv` guards of the
+  // d-tile loops fold away - as run-time branches they pushed the dK / dV accumulators through scratch memory
+  const int D = DX > 0 ? DX : p.D, L = p.L, H = p.H;
   int qb, h, b;
   work_item((L + 127) / 128, H, p.B, qb, h, b);
   const int cpr = D >> 3;
@@ -499,7 +505,7 @@ __device__ __forceinline__ void store_grad_row(const float* row, unsigned short*
 // =================================================================================================
 // backward dQ (+ delta): one workgroup = 128 queries, sweeps KVB-key blocks
 // =================================================================================================
-template <int DP, int DR>
+template <int DP, int DR, int DX>
 __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dq_kernel(const AP p) {
   constexpr int RS = Geo<DP>::RS, KS = Geo<DP>::KS, DT = Geo<DP>::DT, NCH = Geo<DP>::NCH, KVB = Geo<DP>::KVB;
   constexpr int NSUB = KVB / 64, ILD = DP + 4;
@@ -511,7 +517,9 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dq_kernel(const
   unsigned char* mask_l = reinterpret_cast<unsigned char*>(delta_l + 128);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
-  const int D = p.D, L = p.L, H = p.H;
+  // the head dim as a compile-time constant whenever the dispatcher knows it (DX): the `dt < dtv` guards of the
+  // d-tile loops fold away - as run-time branches they pushed the dK / dV accumulators through scratch memory
+  const int D = DX > 0 ? DX : p.D, L = p.L, H = p.H;
   int qb, h, b;
   work_item((L + 127) / 128, H, p.B, qb, h, b);
   const int cpr = D >> 3;
@@ -696,10 +704,11 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dq_kernel(const
 // =================================================================================================
 // backward dK/dV: one workgroup = KVB keys (4 waves x KVB/4), sweeps KVB-query blocks
 // =================================================================================================
-template <int DP, int DR>
+template <int DP, int DR, int DX>
 __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dkv_kernel(const AP p) {
   constexpr int RS = Geo<DP>::RS, KS = Geo<DP>::KS, DT = Geo<DP>::DT, KVB = Geo<DP>::KVB, ILD = DP + 4;
-  constexpr int KTW = KVB / 64;                           // 16-key tiles per wave
+  constexpr int KPB = Geo<DP>::KPB;                       // this workgroup's keys
+  constexpr int KTW = KPB / 64;                           // 16-key tiles per wave
   constexpr int KPW = 16 * KTW, QB = KVB, NS2 = QB / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* qtile = smem;                                     // [QB q][RS]   (first holds this workgroup's K rows)
@@ -708,25 +717,31 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dkv_kernel(cons
   float* dl_l = lse_l + QB;                                      // [QB]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
-  const int D = p.D, L = p.L, H = p.H;
+  // the head dim as a compile-time constant whenever the dispatcher knows it (DX): the `dt < dtv` guards of the
+  // d-tile loops fold away - as run-time branches they pushed the dK / dV accumulators through scratch memory
+  const int D = DX > 0 ? DX : p.D, L = p.L, H = p.H;
   int kbk, h, b;
-  work_item((L + KVB - 1) / KVB, H, p.B, kbk, h, b);
+  work_item((L + KPB - 1) / KPB, H, p.B, kbk, h, b);
   const int cpr = D >> 3;
   const long tokstride = 3L * H * D, ostride = (long)H * D;
   const unsigned short* qbase = p.qkv + (long)b * L * tokstride + (long)h * D;
   const unsigned short* kbase = qbase + (long)H * D;
   const unsigned short* vbase = qbase + 2L * H * D;
   const unsigned short* dobase = p.dout + (long)b * L * ostride + (long)h * D;
-  const int k0 = kbk * KVB;
+  const int k0 = kbk * KPB;
   const int dtv = (D + 15) >> 4;
   const float c2 = p.scale * LOG2E;
 
   // ---- this workgroup's keys: K (rotated) and V as B fragments B[k = d][col = key], kept in registers
-  typename StagerFor<DP, DR, KVB>::type st;
+  typename StagerFor<DP, DR, QB>::type st;
   st.init(tid);
-  st.load(kbase, tokstride, vbase, tokstride, k0, L, cpr);
-  st.store(qtile, dotile, RS, p, L, true);
-  st.load(qbase, tokstride, dobase, ostride, 0, L, cpr);            // first query block: in flight during the fragment reads
+  {
+    typename StagerFor<DP, DR, KPB>::type sk;
+    sk.init(tid);
+    sk.load(kbase, tokstride, vbase, tokstride, k0, L, cpr);
+    st.load(qbase, tokstride, dobase, ostride, 0, L, cpr);          // first query block: in flight during the fragment reads
+    sk.store(qtile, dotile, RS, p, L, true);
+  }
   __syncthreads();
   bf16x8 kf[KTW][KS], vf[KTW][KS];
 #pragma unroll
@@ -833,7 +848,7 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dkv_kernel(cons
       for (int r = 0; r < 4; ++r)
         img[(wid * KPW + kt * 16 + li) * ILD + dt * 16 + 4 * g + r] = dk[dt][kt][r] * p.scale;
   __syncthreads();
-  store_grad_rows<(DR > 0)>(img, ILD, dkbase, tokstride, k0, KVB, L, D, p.cosT, p.sinT, tid);
+  store_grad_rows<(DR > 0)>(img, ILD, dkbase, tokstride, k0, KPB, L, D, p.cosT, p.sinT, tid);
   __syncthreads();
 #pragma unroll
   for (int kt = 0; kt < KTW; ++kt)
@@ -843,7 +858,7 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dkv_kernel(cons
       for (int r = 0; r < 4; ++r)
         img[(wid * KPW + kt * 16 + li) * ILD + dt * 16 + 4 * g + r] = dv[dt][kt][r];
   __syncthreads();
-  store_grad_rows<false>(img, ILD, dvbase, tokstride, k0, KVB, L, D, p.cosT, p.sinT, tid);
+  store_grad_rows<false>(img, ILD, dvbase, tokstride, k0, KPB, L, D, p.cosT, p.sinT, tid);
 }
 
 // =================================================================================================
@@ -1173,14 +1188,14 @@ template <int DP> constexpr size_t lds_dkv() {
   return rows > img ? rows : img;
 }
 
-template <int DP, int DR>
+template <int DP, int DR, int DX>
 int launch_fwd(const AP& p, hipStream_t st) {
   constexpr size_t lds = lds_fwd<DP>();
   if (lds > 65536)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<DP, DR>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<DP, DR, DX>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   dim3 grid(((p.L + 127) / 128) * p.H * p.B);
-  hipLaunchKernelGGL((attn_fwd_kernel<DP, DR>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((attn_fwd_kernel<DP, DR, DX>), grid, dim3(256), lds, st, p);
   return clipk_check_launch();
 }
 
@@ -1196,7 +1211,7 @@ void launch_fused(const AP& p, int nwg, hipStream_t st) {
   hipLaunchKernelGGL((attn_bwd_fused32_kernel<ROPE, D>), dim3(nwg), dim3(256), lds, st, p);
 }
 
-template <int DP, int DR>
+template <int DP, int DR, int DX>
 int launch_bwd(const AP& p, hipStream_t st) {
   if constexpr (DP == 32) {
     // whole-head kernel for the short-head encoders (ESM-2 8M / 35M / 150M at L <= 256); CLIPK_ATTN_FUSED_BWD=0
@@ -1217,16 +1232,16 @@ int launch_bwd(const AP& p, hipStream_t st) {
   }
   constexpr size_t l1 = lds_dq<DP>(), l2 = lds_dkv<DP>();
   if (l1 > 65536)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<DP, DR>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<DP, DR, DX>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1);
   if (l2 > 65536)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<DP, DR>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<DP, DR, DX>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
   dim3 gq(((p.L + 127) / 128) * p.H * p.B);
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<DP, DR>), gq, dim3(256), l1, st, p);
-  constexpr int KVB = Geo<DP>::KVB;
-  dim3 gk(((p.L + KVB - 1) / KVB) * p.H * p.B);
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, DR>), gk, dim3(256), l2, st, p);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<DP, DR, DX>), gq, dim3(256), l1, st, p);
+  constexpr int KPB = Geo<DP>::KPB;
+  dim3 gk(((p.L + KPB - 1) / KPB) * p.H * p.B);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, DR, DX>), gk, dim3(256), l2, st, p);
   return clipk_check_launch();
 }
 
@@ -1263,22 +1278,33 @@ int check_common(const void* qkv, int B, int L, int H, int D, bool rope) {
 
 }  // namespace
 
+// DX = the head dim when it is one the dispatcher can name at compile time (every RoPE case; multiples of 32
+// otherwise), 0 = run time
 #define ATTN_DISPATCH(FN, D, ROPE, P, ST)                                   \
   do {                                                                      \
     if (ROPE) {                                                             \
       switch (D) {                                                          \
-        case 16: return FN<32, 16>(P, ST);                                  \
-        case 24: return FN<32, 24>(P, ST);                                  \
-        case 32: return FN<32, 32>(P, ST);                                  \
-        case 64: return FN<64, 64>(P, ST);                                  \
-        default: return FN<128, 128>(P, ST);                                \
+        case 16: return FN<32, 16, 16>(P, ST);                              \
+        case 24: return FN<32, 24, 24>(P, ST);                              \
+        case 32: return FN<32, 32, 32>(P, ST);                              \
+        case 64: return FN<64, 64, 64>(P, ST);                              \
+        default: return FN<128, 128, 128>(P, ST);                           \
       }                                                                     \
     }                                                                       \
-    if ((D) <= 32) return FN<32, 0>(P, ST);                                 \
-    if ((D) <= 64) return FN<64, 0>(P, ST);                                 \
-    if ((D) <= 96) return FN<96, 0>(P, ST);                                 \
-    if ((D) <= 128) return FN<128, 0>(P, ST);                               \
-    return FN<160, 0>(P, ST);                                               \
+    switch (D) {                                                            \
+      case 24: return FN<32, 0, 24>(P, ST);                                 \
+      case 32: return FN<32, 0, 32>(P, ST);                                 \
+      case 64: return FN<64, 0, 64>(P, ST);                                 \
+      case 96: return FN<96, 0, 96>(P, ST);                                 \
+      case 128: return FN<128, 0, 128>(P, ST);                              \
+      case 160: return FN<160, 0, 160>(P, ST);                              \
+      default: break;                                                       \
+    }                                                                       \
+    if ((D) <= 32) return FN<32, 0, 0>(P, ST);                              \
+    if ((D) <= 64) return FN<64, 0, 0>(P, ST);                              \
+    if ((D) <= 96) return FN<96, 0, 0>(P, ST);                              \
+    if ((D) <= 128) return FN<128, 0, 0>(P, ST);                            \
+    return FN<160, 0, 0>(P, ST);                                            \
   } while (0)
 
 extern "C" int clipk_attn_fwd(const void* qkv, const uint8_t* key_mask, const float* rope_cos, const float* rope_sin,
