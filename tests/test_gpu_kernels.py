@@ -427,7 +427,8 @@ def test_attention_fwd_bwd(dev, B, L, H, D, use_rope, use_mask):
     assert torch.equal(dqkv, dqkv2)
 
 
-@pytest.mark.parametrize("B,L,H,D,use_rope", [(8, 256, 20, 24, True), (3, 190, 4, 32, False), (2, 256, 3, 16, True)])
+@pytest.mark.parametrize("B,L,H,D,use_rope", [(8, 256, 20, 24, True), (3, 190, 4, 32, False), (2, 256, 3, 16, True),
+                                                 (2, 129, 2, 24, True), (5, 255, 3, 32, True), (1, 256, 1, 24, False)])
 def test_attention_bwd_whole_head_vs_two_kernel(dev, B, L, H, D, use_rope, monkeypatch):
     """The whole-head backward (one workgroup per head, 5 products) against the dQ + dK/dV kernel pair (7 products)
     on the same inputs: same arithmetic up to the f32 summation order over query / key blocks, so they agree to bf16 rounding."""
