@@ -18,11 +18,15 @@ $(LIB): $(OBJ)
 	@mkdir -p clip_dplm_amd/lib
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ)
 
-probes: tools/probes/probe_layouts
+probes: tools/probes/probe_layouts tools/probes/probe_gather tools/probes/probe_store_shapes
 tools/probes/probe_layouts: tools/probes/probe_layouts.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -Wno-unused-value -o $@ $<
+tools/probes/probe_gather: tools/probes/probe_gather.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-value -o $@ $<
+tools/probes/probe_store_shapes: tools/probes/probe_store_shapes.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-value -o $@ $<
 
 clean:
-	rm -rf build $(LIB) tools/probes/probe_layouts
+	rm -rf build $(LIB) tools/probes/probe_layouts tools/probes/probe_gather tools/probes/probe_store_shapes
 
 .PHONY: all clean probes
