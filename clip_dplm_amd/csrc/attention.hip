@@ -900,21 +900,29 @@ __host__ __device__ constexpr size_t lds_fused(int D) {
 }
 
 // one head's rows as this thread holds them between the loads and the LDS staging: chunk (tid & 3) of rows
-// (tid >> 2) + 64 * pass of K, V, Q, dO and O, this thread's lse and the mask bytes of its four key columns
+// (tid >> 2) + (threads / 4) * pass of K, V, Q, dO and O, this thread's lse and the mask bytes of its key columns
+template <int NPS, int KTW>
 struct HeadRegs {
-  u32x4 k[4], v[4], q[4], d[4], o[4];
+  u32x4 k[NPS], v[NPS], q[NPS], d[NPS], o[NPS];
   float lse;
-  unsigned char km[4];
+  unsigned char km[KTW];
 };
 
-template <bool ROPE, int D>
-__global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(const AP p) {
-  constexpr int DT = 2, KTW = 4, LQ = FUSED_LMAX;
+// NW = waves per workgroup.  4 (the default): two workgroups per CU, a wave owns 64 keys, the next head's rows can
+// only be requested after the sweep (the sweep needs 239 of the 256 registers).  8 (kept for A/B, slower - see
+// launch_fused): one workgroup per CU, a wave owns 32 keys - half the accumulators and fragments, and the rows of a
+// head spread over twice the threads (40 prefetch registers instead of 80) - so the next head is requested BEFORE
+// the sweep and its gather runs under it.
+template <bool ROPE, int D, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_kernel(const AP p) {
+  constexpr int DT = 2, LQ = FUSED_LMAX;
+  constexpr int NT = 64 * NW, KTW = 16 / NW, KW = 16 * KTW, NCK = KTW / 2, NPS = LQ * 4 / NT;
   constexpr int ILD = D + 4, cpr = D / 8;
+  typedef HeadRegs<NPS, KTW> Regs;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* qtile = smem;                                     // [256 q][64 B]   (first: this head's K rows)
   char* dotile = smem + LQ * 64;                          // [256 q][64 B]   (first: this head's V rows)
-  char* dst_all = smem + 2 * LQ * 64;                     // 4 waves x 2 x [32 keys][32 q] bf16
+  char* dst_all = smem + 2 * LQ * 64;                     // NW waves x NCK x [32 keys][32 q] bf16 = 16 KiB
   float* img = reinterpret_cast<float*>(dst_all + 4 * 4096);   // dQ image [256][D + 4] f32
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
@@ -928,7 +936,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(const AP p) {
   // Staging: four lanes per token row (one 16-byte chunk each, the pad chunk zero), 64 rows per pass: a wave
   // instruction covers 16 rows x D*2 contiguous bytes.  (One thread per row - the staging of the other kernels, needed
   // there to rotate rows in registers - touches 64 different 128-byte lines per instruction.)
-  auto issue = [&](int w, HeadRegs& R) {
+  auto issue = [&](int w, Regs& R) {
     int blk_, h_, b_;
     work_item_at(w, 1, H, p.B, blk_, h_, b_);
     const int t = tid + opaque_zero();
@@ -942,8 +950,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(const AP p) {
     // staging time): loads under a divergent branch make every later s_waitcnt assume they may not have been issued
     const unsigned int cc = 8u * (ci < cpr ? ci : cpr - 1);
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      int row = ps * 64 + r0; row = row < L ? row : L - 1;
+    for (int ps = 0; ps < NPS; ++ps) {
+      int row = ps * (NT / 4) + r0; row = row < L ? row : L - 1;
       const unsigned int qo = (unsigned int)row * 3u * HD + cc, oo = (unsigned int)row * HD + cc;
       R.q[ps] = *reinterpret_cast<const u32x4*>(qb + qo);
       R.k[ps] = *reinterpret_cast<const u32x4*>(qb + (qo + HD));
@@ -955,7 +963,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(const AP p) {
     const int lane_ = t & 63, wid_ = t >> 6;
 #pragma unroll
     for (int kt = 0; kt < KTW; ++kt) {
-      const int key = wid_ * 64 + kt * 16 + (lane_ & 15);
+      const int key = wid_ * KW + kt * 16 + (lane_ & 15);
       R.km[kt] = p.key_mask ? p.key_mask[(long)b_ * L + (key < L ? key : L - 1)] : (unsigned char)1;
     }
   };
@@ -966,7 +974,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(const AP p) {
   int off_tr[DT];                                                             // row trow, bytes dt*32 + 8*(li&3)
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) off_tr[dt] = swz64(trow, dt * 2 + ((li & 3) >> 1)) + 8 * (li & 1);
-  char* dst = dst_all + wid * 4096;
+  char* dst = dst_all + wid * (NCK * 2048);
   // dS^T write: key row ktl*16 + li, queries qq*16 + 4g .. +3 -> 8 bytes at byte column qq*32 + 8g
   int off_dw[2];
 #pragma unroll
@@ -978,7 +986,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(const AP p) {
   // (Tried and dropped: a start-up offset between the two workgroups of a CU so that one sweeps while the other moves
   // data.  Timed in interleaved rounds on a warm GPU it changes nothing - 450 us with or without; the gain first
   // measured came from the clock ramp of the first few hundred launches of a process.)
-  HeadRegs R;
+  Regs R;
   int w = blockIdx.x;
   if (w < nheads) issue(w, R);
 
@@ -988,15 +996,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(const AP p) {
     const int tq = tid + opaque_zero();
     const int ci = tq & 3, r0 = tq >> 2;
     // ---- K / V rows to LDS, lse and delta = rowsum(dO * O) to their arrays, dQ image to zero
-    lse_l[tid] = tid < L ? R.lse * LOG2E : INFINITY;       // +inf: p = 2^-inf = 0 past the end
+    if (tid < LQ) lse_l[tid] = tid < L ? R.lse * LOG2E : INFINITY;       // +inf: p = 2^-inf = 0 past the end
     if (cpr < 4 && ci >= cpr) {                            // the pad chunk: zeros in LDS
       const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int ps = 0; ps < 4; ++ps) R.k[ps] = R.v[ps] = R.q[ps] = R.d[ps] = R.o[ps] = z;
+      for (int ps = 0; ps < NPS; ++ps) R.k[ps] = R.v[ps] = R.q[ps] = R.d[ps] = R.o[ps] = z;
     }
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      const int row = ps * 64 + r0;
+    for (int ps = 0; ps < NPS; ++ps) {
+      const int row = ps * (NT / 4) + r0;
       *reinterpret_cast<u32x4*>(qtile + swz64(row, ci)) = R.k[ps];
       *reinterpret_cast<u32x4*>(dotile + swz64(row, ci)) = R.v[ps];
       float acc = 0.f;
@@ -1013,27 +1021,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(const AP p) {
         if (ok) p.delta[((long)b * H + h) * L + row] = acc;
       }
     }
-    for (int i = 0; i < ILD; i += 4) *reinterpret_cast<f32x4*>(img + tid * ILD + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < LQ)
+      for (int i = 0; i < ILD; i += 4) *reinterpret_cast<f32x4*>(img + tid * ILD + i) = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
-    bf16x8 kf[KTW], vf[KTW], ktf[DT][2];
+    bf16x8 kf[KTW], vf[KTW], ktf[DT][NCK];
     float kbias[KTW];
 #pragma unroll
     for (int kt = 0; kt < KTW; ++kt) {
-      kf[kt] = *reinterpret_cast<const bf16x8*>(qtile + (wid * 64 + kt * 16) * 64 + off_rf);
-      vf[kt] = *reinterpret_cast<const bf16x8*>(dotile + (wid * 64 + kt * 16) * 64 + off_rf);
-      kbias[kt] = (wid * 64 + kt * 16 + li < L && R.km[kt]) ? 0.f : -INFINITY;
+      kf[kt] = *reinterpret_cast<const bf16x8*>(qtile + (wid * KW + kt * 16) * 64 + off_rf);
+      vf[kt] = *reinterpret_cast<const bf16x8*>(dotile + (wid * KW + kt * 16) * 64 + off_rf);
+      kbias[kt] = (wid * KW + kt * 16 + li < L && R.km[kt]) ? 0.f : -INFINITY;
     }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-      for (int c = 0; c < 2; ++c) ktf[dt][c] = tr_frag_off(qtile + (wid * 64 + c * 32) * 64, off_tr[dt]);   // K~^T
+      for (int c = 0; c < NCK; ++c) ktf[dt][c] = tr_frag_off(qtile + (wid * KW + c * 32) * 64, off_tr[dt]);   // K~^T
     __syncthreads();
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      *reinterpret_cast<u32x4*>(qtile + swz64(ps * 64 + r0, ci)) = R.q[ps];
-      *reinterpret_cast<u32x4*>(dotile + swz64(ps * 64 + r0, ci)) = R.d[ps];
+    for (int ps = 0; ps < NPS; ++ps) {
+      *reinterpret_cast<u32x4*>(qtile + swz64(ps * (NT / 4) + r0, ci)) = R.q[ps];
+      *reinterpret_cast<u32x4*>(dotile + swz64(ps * (NT / 4) + r0, ci)) = R.d[ps];
     }
+    // eight waves: R is free now and the sweep leaves room for it - request the next head here, its gather runs
+    // under the sweep.  (Unconditional, see below; the last head of a workgroup re-requests its own rows.)
+    if constexpr (NW == 8) issue(w + (int)gridDim.x < nheads ? w + (int)gridDim.x : w, R);
     __syncthreads();
 
     f32x4 dk[DT][KTW], dv[DT][KTW];
@@ -1088,7 +1100,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(const AP p) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) { dq[dt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dq[dt][1] = dq[dt][0]; }
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < NCK; ++c) {
 #pragma unroll
           for (int ktl = 0; ktl < 2; ++ktl) {
             const int kt = 2 * c + ktl;
@@ -1111,7 +1123,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(const AP p) {
               dq[dt][qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[dt][c], dsb, dq[dt][qq], 0, 0, 0);
           }
         }
-        // this wave's 64-key share of dQ for query block j: plain read-add-write, no other wave is on block j now
+        // this wave's share of dQ (its keys only) for query block j: plain read-add-write, no other wave is on block j now
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq) {
           float* row = img + (j * 32 + qq * 16 + li) * ILD + 4 * g;
@@ -1132,9 +1144,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(const AP p) {
     // iteration).  The request is unconditional - the last head of a workgroup asks for its own rows again, L2 hits
     // nobody consumes - because a branch here makes the compiler wait for vmcnt(0) at the first use of the tables
     // (on the not-taken path they are the youngest loads), which waits for the whole prefetch as well.
+    // (Eight waves: the rows were requested before the sweep and have landed; the tables simply come now.)
     RopeRow<D> T;
     if (ROPE) load_rope_row<D>(T, p.cosT, p.sinT, tq < L ? tq : L - 1);
-    issue(w + (int)gridDim.x < nheads ? w + (int)gridDim.x : w, R);
+    if constexpr (NW == 4) issue(w + (int)gridDim.x < nheads ? w + (int)gridDim.x : w, R);
 
     // ---- dQ rows from the image; dK~ (f32, RoPE^T wants f32 pairs) and dV (bf16) through images over the now dead
     // Q / dO / dS^T region
@@ -1145,7 +1158,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(const AP p) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
         if (dt == 0 || dt1_live) {
-          const int key = wid * 64 + kt * 16 + li, d = dt * 16 + 4 * g;
+          const int key = wid * KW + kt * 16 + li, d = dt * 16 + 4 * g;
           *reinterpret_cast<f32x4*>(img2 + key * ILD + d) = dk[dt][kt];
           u32x2 wv;
           wv[0] = pack_bf16x2(dv[dt][kt][0], dv[dt][kt][1]);
@@ -1199,16 +1212,27 @@ int launch_fwd(const AP& p, hipStream_t st) {
   return clipk_check_launch();
 }
 
-template <bool ROPE, int D>
-void launch_fused(const AP& p, int nwg, hipStream_t st) {
+template <bool ROPE, int D, int NW>
+void launch_fused_nw(const AP& p, hipStream_t st) {
   constexpr size_t lds = lds_fused(D);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused32_kernel<ROPE, D>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused32_kernel<ROPE, D, NW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((attn_bwd_fused32_kernel<ROPE, D>), dim3(nwg), dim3(256), lds, st, p);
+  int nwg = (NW == 4 ? 2 : 1) * attn_cu_count();          // persistent: the resident workgroups walk the heads
+  if (nwg > p.H * p.B) nwg = p.H * p.B;
+  hipLaunchKernelGGL((attn_bwd_fused32_kernel<ROPE, D, NW>), dim3(nwg), dim3(64 * NW), lds, st, p);
+}
+template <bool ROPE, int D>
+void launch_fused(const AP& p, hipStream_t st) {
+  // 4 waves (default) or 8 (CLIPK_ATTN_FUSED_WAVES=8).  Measured, ESM-2-35M shape, warm, interleaved rounds: 435 us
+  // with 4 waves, 585 us with 8 - the gather does run under the sweep, but with ONE workgroup per CU every barrier
+  // (eight per head in the sweep, six around it) stalls the whole CU and the steps are half as long.
+  const char* e = getenv("CLIPK_ATTN_FUSED_WAVES");
+  if (e && atoi(e) == 8) launch_fused_nw<ROPE, D, 8>(p, st);
+  else launch_fused_nw<ROPE, D, 4>(p, st);
 }
 
 template <int DP, int DR, int DX>
@@ -1220,12 +1244,10 @@ int launch_bwd(const AP& p, hipStream_t st) {
     const bool fused_on = !(fe && atoi(fe) == 0);
     // q / k must arrive rotated (clipk_rope_qk) or unrotated-by-design: the chunk-per-lane staging cannot rotate
     if (fused_on && p.L > 128 && p.L <= FUSED_LMAX && p.D >= 16 && (DR == 0 || p.pre_rot)) {
-      int nwg = 2 * attn_cu_count();                      // two resident workgroups per CU (LDS: 78 KiB each at D = 24)
-      if (nwg > p.H * p.B) nwg = p.H * p.B;
       switch (p.D) {
-        case 16: launch_fused<(DR > 0), 16>(p, nwg, st); break;
-        case 24: launch_fused<(DR > 0), 24>(p, nwg, st); break;
-        default: launch_fused<(DR > 0), 32>(p, nwg, st); break;
+        case 16: launch_fused<(DR > 0), 16>(p, st); break;
+        case 24: launch_fused<(DR > 0), 24>(p, st); break;
+        default: launch_fused<(DR > 0), 32>(p, st); break;
       }
       return clipk_check_launch();
     }

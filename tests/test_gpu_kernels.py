@@ -429,7 +429,8 @@ def test_attention_fwd_bwd(dev, B, L, H, D, use_rope, use_mask):
 
 @pytest.mark.parametrize("B,L,H,D,use_rope", [(8, 256, 20, 24, True), (3, 190, 4, 32, False), (2, 256, 3, 16, True),
                                                  (2, 129, 2, 24, True), (5, 255, 3, 32, True), (1, 256, 1, 24, False)])
-def test_attention_bwd_whole_head_vs_two_kernel(dev, B, L, H, D, use_rope, monkeypatch):
+@pytest.mark.parametrize("waves", ["4", "8"])
+def test_attention_bwd_whole_head_vs_two_kernel(dev, B, L, H, D, use_rope, waves, monkeypatch):
     """The whole-head backward (one workgroup per head, 5 products) against the dQ + dK/dV kernel pair (7 products)
     on the same inputs: same arithmetic up to the f32 summation order over query / key blocks, so they agree to bf16 rounding."""
     ops = _ops()
@@ -447,6 +448,7 @@ def test_attention_bwd_whole_head_vs_two_kernel(dev, B, L, H, D, use_rope, monke
     monkeypatch.setenv("CLIPK_ATTN_FUSED_BWD", "0")
     g2 = ops.attn_bwd(qkv, out, dout, lse, B, L, H, D, **kw).float()
     monkeypatch.setenv("CLIPK_ATTN_FUSED_BWD", "1")
+    monkeypatch.setenv("CLIPK_ATTN_FUSED_WAVES", waves)      # 4 (default): two 256-thread workgroups per CU; 8: one of 512
     g1 = ops.attn_bwd(qkv, out, dout, lse, B, L, H, D, **kw).float()
     assert torch.equal(g1, ops.attn_bwd(qkv, out, dout, lse, B, L, H, D, **kw).float())      # reproducible
     m3 = mask.view(B * L, 1).float()

@@ -47,12 +47,14 @@ for _ in range(200):
 torch.cuda.synchronize()
 res = collections.defaultdict(list)
 for rnd in range(4):
-    for mode, name in (("1", "whole-head"), ("0", "dQ + dK/dV pair")):
+    for mode, waves, name in (("1", "8", "whole-head, 8 waves"), ("1", "4", "whole-head, 4 waves"), ("0", "8", "dQ + dK/dV pair")):
         os.environ["CLIPK_ATTN_FUSED_BWD"] = mode
+        os.environ["CLIPK_ATTN_FUSED_WAVES"] = waves
         res[name].append(timeit(bwd))
 for k, v in res.items():
-    print(f"{k:18s}", " ".join(f"{x:7.1f}" for x in v), "us")
+    print(f"{k:20s}", " ".join(f"{x:7.1f}" for x in v), "us")
 os.environ["CLIPK_ATTN_FUSED_BWD"] = "1"
+os.environ["CLIPK_ATTN_FUSED_WAVES"] = "4"
 g1 = bwd().float()
 os.environ["CLIPK_ATTN_FUSED_BWD"] = "0"
 g0 = bwd().float()
