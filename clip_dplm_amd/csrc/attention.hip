@@ -18,9 +18,14 @@
 //     path) and writes the finished row to LDS: q/k are read once from HBM, no rotated copy is ever written and
 //     no in-LDS rotation pass or extra barrier exists.  The same registers prefetch the next key (or query) block
 //     while the MFMAs of the current one run;
-//   * backward = a dQ kernel (one workgroup per 128 queries, sweeping keys; it also produces delta = rowsum(dO*O)
-//     from the rows it already holds) and a dK/dV kernel (one workgroup per 128 or 64 keys, sweeping queries):
-//     7 MFMA products instead of 5, but no float atomics and bitwise-reproducible gradients.
+//   * rows that need no rotation in registers (no RoPE, or q / k rotated once by clipk_rope_qk) are staged chunk per
+//     lane instead: consecutive lanes on consecutive 16-byte chunks, whole 128-byte lines per wave instruction;
+//   * backward, general shape = a dQ kernel (one workgroup per 128 queries, sweeping keys; it also produces
+//     delta = rowsum(dO*O) from the rows it already holds) and a dK/dV kernel (one workgroup per 128 or 64 keys,
+//     sweeping queries): 7 MFMA products instead of 5, but no float atomics and bitwise-reproducible gradients;
+//   * backward, short heads (hd <= 32, 128 < L <= 256, the ESM-2 8M / 35M / 150M encoders) = ONE kernel, a whole
+//     (batch, head) per persistent workgroup: 5 products, one softmax pass, dS transposed through LDS, dQ summed
+//     over the key-owning waves in a rotated fixed order (attn_bwd_fused32_kernel below) - still no atomics.
 #include "common.h"
 #include <math.h>
 #include <stdlib.h>
