@@ -1183,6 +1183,166 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
   }
 }
 
+// =================================================================================================
+// forward, whole head in one workgroup (head dim <= 32, 128 < L <= 256, rows that need no rotation): all 256 K and V
+// rows are staged ONCE per head (the general kernel's two 128-query workgroups each stage all of them) and stay in
+// LDS while the four waves take two passes of 32 queries each.  Same tiles, same 64-key sub-block order and the
+// same arithmetic per query as attn_fwd_kernel, so outputs and LSE are bit-identical to it.
+// =================================================================================================
+template <int D>
+__global__ __launch_bounds__(256, 4) void attn_fwd_whole32_kernel(const AP p) {
+  constexpr int DT = 2, LQ = FUSED_LMAX, cpr = D / 8, dtv = (D + 15) >> 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ktile = smem;                                     // [256][64 B], 16-byte chunks swizzled by (row >> 1) & 3
+  char* vtile = smem + LQ * 64;
+  unsigned char* mask_l = reinterpret_cast<unsigned char*>(smem + 2 * LQ * 64);   // [256]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int L = p.L, H = p.H;
+  int blk, h, b;
+  work_item(1, H, p.B, blk, h, b);
+  const float c2 = p.scale * LOG2E;
+  u32x4 qfr[2][2];
+  {
+    // four lanes per token row, one 16-byte chunk each (the pad chunk re-reads the last real one and is dropped)
+    const int ci = tid & 3, r0 = tid >> 2;
+    const unsigned int HD = (unsigned int)(H * D), cc = 8u * (ci < cpr ? ci : cpr - 1);
+    const unsigned short* qb = p.qkv + (long)b * L * 3 * HD + (long)h * D;
+    u32x4 ck[4], cv[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      int row = ps * 64 + r0; row = row < L ? row : L - 1;
+      const unsigned int qo = (unsigned int)row * 3u * HD + cc;
+      ck[ps] = *reinterpret_cast<const u32x4*>(qb + (qo + HD));
+      cv[ps] = *reinterpret_cast<const u32x4*>(qb + (qo + 2u * HD));
+    }
+    // Q never touches LDS: lane (li, g) reads chunk g of query row li of its tile - the MFMA fragment as it is
+#pragma unroll
+    for (int qh = 0; qh < 2; ++qh)
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        int row = qh * 128 + wid * 32 + qt * 16 + li; row = row < L ? row : L - 1;
+        qfr[qh][qt] = *reinterpret_cast<const u32x4*>(qb + ((unsigned int)row * 3u * HD + 8u * (g < cpr ? g : cpr - 1)));
+      }
+    mask_l[tid] = (tid < L && (!p.key_mask || p.key_mask[(long)b * L + tid])) ? 1 : 0;
+    const bool pad = cpr < 4 && ci >= cpr;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int off = swz64(ps * 64 + r0, ci);
+      *reinterpret_cast<u32x4*>(ktile + off) = pad ? z : ck[ps];
+      *reinterpret_cast<u32x4*>(vtile + off) = pad ? z : cv[ps];
+    }
+    if (cpr < 4 && g >= cpr) {
+#pragma unroll
+      for (int qh = 0; qh < 2; ++qh) { qfr[qh][0] = z; qfr[qh][1] = z; }
+    }
+  }
+  __syncthreads();
+
+  const int trow = 4 * g + (li >> 2);
+  const int off_rf = swz64(li, g);
+  int off_tr[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) off_tr[dt] = swz64(trow, dt * 2 + ((li & 3) >> 1)) + 8 * (li & 1);
+
+#pragma unroll 1
+  for (int qh = 0; qh < 2; ++qh) {
+    const int q0 = qh * 128;
+    if (q0 >= L) break;
+    bf16x8 qf[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) qf[qt] = __builtin_bit_cast(bf16x8, qh == 0 ? qfr[0][qt] : qfr[1][qt]);
+    f32x4 o[DT][2];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { o[dt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o[dt][1] = o[dt][0]; }
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+#pragma unroll 1
+    for (int sub = 0; sub < LQ / 64; ++sub) {
+      if (sub * 64 >= L) break;                                  // wave-uniform: nothing valid in this sub-block
+      const char* kt_ = ktile + sub * 64 * 64;
+      const char* vt_ = vtile + sub * 64 * 64;
+      f32x4 s[4][2];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt_ + kt * 16 * 64 + off_rf);
+        s[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        s[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      }
+      if (p.key_mask != nullptr || sub * 64 + 64 > L) {          // wave-uniform: full, unmasked blocks skip this
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          const unsigned int mk = *reinterpret_cast<const unsigned int*>(mask_l + sub * 64 + kt * 16 + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (!((mk >> (8 * r)) & 0xffu)) { s[kt][0][r] = -INFINITY; s[kt][1][r] = -INFINITY; }
+        }
+      }
+      bf16x8 pb[2][2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
+        mx = group_max(mx);
+        const float m_new = fmaxf(m_run[qt], mx);
+        const bool dead = (m_new == -INFINITY);
+        const float alpha = dead ? 1.f : fast_exp2((m_run[qt] - m_new) * c2);
+        const f32x2 mc = splat2(dead ? -INFINITY : -m_new * c2);          // see attn_fwd_kernel
+        const f32x2 cc = splat2(c2);
+        f32x2 ls2 = {0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; r += 2) {
+            const f32x2 a = __builtin_elementwise_fma(f32x2{s[kt][qt][r], s[kt][qt][r + 1]}, cc, mc);
+            const f32x2 pv = {fast_exp2(a[0]), fast_exp2(a[1])};
+            s[kt][qt][r] = pv[0]; s[kt][qt][r + 1] = pv[1];
+            ls2 += pv;
+          }
+        const float ls = ls2[0] + ls2[1];
+        l_run[qt] = l_run[qt] * alpha + ls;
+        m_run[qt] = m_new;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt][qt] *= alpha;
+        pb[qt][0] = pack_acc_pair(s[0][qt], s[1][qt]);
+        pb[qt][1] = pack_acc_pair(s[2][qt], s[3][qt]);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+          if (dt < dtv) {
+            const bf16x8 vf = tr_frag_off(vt_ + s2 * 32 * 64, off_tr[dt]);
+            o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[0][s2], o[dt][0], 0, 0, 0);
+            o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[1][s2], o[dt][1], 0, 0, 0);
+          }
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const float lt = group_sum(l_run[qt]);
+      const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+      const int q = q0 + wid * 32 + qt * 16 + li;
+      if (q < L) {
+        if (g == 0) p.lse[((long)b * H + h) * L + q] = lt > 0.f ? m_run[qt] * p.scale + logf(lt) : -INFINITY;
+        unsigned short* orow = p.out + ((long)b * L + q) * ((long)H * D) + (long)h * D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int d = dt * 16 + 4 * g;
+          if (d < D) {
+            u32x2 w;
+            w[0] = pack_bf16x2(o[dt][qt][0] * inv, o[dt][qt][1] * inv);
+            w[1] = pack_bf16x2(o[dt][qt][2] * inv, o[dt][qt][3] * inv);
+            *reinterpret_cast<u32x2*>(orow + d) = w;
+          }
+        }
+      }
+    }
+  }
+}
+
 int attn_cu_count() {
   static int n = 0;
   if (n == 0) {
@@ -1206,8 +1366,26 @@ template <int DP> constexpr size_t lds_dkv() {
   return rows > img ? rows : img;
 }
 
+template <int D>
+void launch_fwd_whole(const AP& p, hipStream_t st) {
+  constexpr int lds = 2 * FUSED_LMAX * 64 + 256;
+  hipLaunchKernelGGL((attn_fwd_whole32_kernel<D>), dim3(p.H * p.B), dim3(256), lds, st, p);
+}
+
 template <int DP, int DR, int DX>
 int launch_fwd(const AP& p, hipStream_t st) {
+  if constexpr (DP == 32 && DR == 0) {
+    // short heads whose rows need no rotation: whole-head kernel (CLIPK_ATTN_WHOLE_FWD=0: the general one)
+    const char* fe = getenv("CLIPK_ATTN_WHOLE_FWD");
+    if (!(fe && atoi(fe) == 0) && p.L > 128 && p.L <= FUSED_LMAX && p.D >= 16) {
+      switch (p.D) {
+        case 16: launch_fwd_whole<16>(p, st); break;
+        case 24: launch_fwd_whole<24>(p, st); break;
+        default: launch_fwd_whole<32>(p, st); break;
+      }
+      return clipk_check_launch();
+    }
+  }
   constexpr size_t lds = lds_fwd<DP>();
   if (lds > 65536)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<DP, DR, DX>),

@@ -458,6 +458,22 @@ def test_attention_bwd_whole_head_vs_two_kernel(dev, B, L, H, D, use_rope, waves
     assert (g1 - g2).abs().max().item() / denom < 8e-3       # one bf16 ulp of the largest gradient
 
 
+@pytest.mark.parametrize("B,L,H,D", [(8, 256, 20, 24), (3, 190, 4, 32), (2, 129, 3, 16), (5, 255, 2, 24)])
+def test_attention_fwd_whole_head_equals_general(dev, B, L, H, D, monkeypatch):
+    """Short heads whose rows need no rotation take the whole-head forward (K / V staged once per head); it keeps the
+    general kernel's tiles, sub-block order and arithmetic, so outputs and LSE are bit-identical."""
+    ops = _ops()
+    qkv = _rand((B * L, 3 * H * D), dev, 80, 1.0, dtype=torch.bfloat16)
+    lens = torch.tensor([L] + [max(1, L - 29 * (i + 1)) for i in range(B - 1)])
+    mask = (torch.arange(L)[None] < lens[:, None]).to(torch.uint8).contiguous().to(dev)
+    for m in (None, mask):
+        monkeypatch.setenv("CLIPK_ATTN_WHOLE_FWD", "0")
+        o0, l0 = ops.attn_fwd(qkv, B, L, H, D, key_mask=m, rope=None, q_scale=D ** -0.5)
+        monkeypatch.setenv("CLIPK_ATTN_WHOLE_FWD", "1")
+        o1, l1 = ops.attn_fwd(qkv, B, L, H, D, key_mask=m, rope=None, q_scale=D ** -0.5)
+        assert torch.equal(o0, o1) and torch.equal(l0, l1)
+
+
 # ------------------------------------------------------------------------------------------------ misc
 def test_cast_and_transpose(dev):
     ops = _ops()

@@ -69,5 +69,10 @@ t = [timeit(lambda: ops.attn_bwd(q2, o2, do2, l2, B2, L2, H2, D2, rope=None, q_s
 print("hd 96 backward    ", " ".join(f"{x:7.1f}" for x in t), "us")
 t = [timeit(lambda: ops.attn_fwd(q2, B2, L2, H2, D2, rope=None, q_scale=D2 ** -0.5)) for _ in range(3)]
 print("hd 96 forward     ", " ".join(f"{x:7.1f}" for x in t), "us")
-t = [timeit(lambda: ops.attn_fwd(rot, B, L, H, D, rope=None, q_scale=D ** -0.5)) for _ in range(3)]
-print("hd 24 forward     ", " ".join(f"{x:7.1f}" for x in t), "us")
+fw = collections.defaultdict(list)
+for rnd in range(3):
+    for mode, name in (("1", "hd 24 forward, whole-head"), ("0", "hd 24 forward, general")):
+        os.environ["CLIPK_ATTN_WHOLE_FWD"] = mode
+        fw[name].append(timeit(lambda: ops.attn_fwd(rot, B, L, H, D, rope=None, q_scale=D ** -0.5)))
+for k, v in fw.items():
+    print(f"{k:26s}", " ".join(f"{x:7.1f}" for x in v), "us")
