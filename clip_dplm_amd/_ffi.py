@@ -69,6 +69,7 @@ SIGNATURES = {
     "clipk_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "clipk_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "clipk_rope_qk": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "clipk_attn_fwd_rot": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "clipk_embed_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     "clipk_embed_bwd_workspace": (_sz, [_i, _i, _i, _i]),
     "clipk_embed_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),

@@ -1189,13 +1189,18 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
 // LDS while the four waves take two passes of 32 queries each.  Same tiles, same 64-key sub-block order and the
 // same arithmetic per query as attn_fwd_kernel, so outputs and LSE are bit-identical to it.
 // =================================================================================================
-template <int D>
-__global__ __launch_bounds__(256, 4) void attn_fwd_whole32_kernel(const AP p) {
+// ROT: q / k arrive UNROTATED together with the RoPE tables; the kernel rotates them (one thread per row, in
+// registers, the same rope_regs as clipk_rope_qk: bit-identical values), uses them, and writes the rotated rows back
+// in place - one workgroup owns every row of its head, so nobody else ever reads them unrotated.  That is
+// clipk_rope_qk + clipk_attn_fwd in one pass over q / k (clipk_attn_fwd_rot).
+template <int D, bool ROT>
+__global__ __launch_bounds__(256, ROT ? 3 : 4) void attn_fwd_whole32_kernel(const AP p) {
   constexpr int DT = 2, LQ = FUSED_LMAX, cpr = D / 8, dtv = (D + 15) >> 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ktile = smem;                                     // [256][64 B], 16-byte chunks swizzled by (row >> 1) & 3
   char* vtile = smem + LQ * 64;
   unsigned char* mask_l = reinterpret_cast<unsigned char*>(smem + 2 * LQ * 64);   // [256]
+  char* qtile = smem + 2 * LQ * 64 + 256;                 // ROT only: [256][64 B]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
   const int L = p.L, H = p.H;
@@ -1213,27 +1218,50 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_whole32_kernel(const AP p) {
     for (int ps = 0; ps < 4; ++ps) {
       int row = ps * 64 + r0; row = row < L ? row : L - 1;
       const unsigned int qo = (unsigned int)row * 3u * HD + cc;
-      ck[ps] = *reinterpret_cast<const u32x4*>(qb + (qo + HD));
+      if (!ROT) ck[ps] = *reinterpret_cast<const u32x4*>(qb + (qo + HD));
       cv[ps] = *reinterpret_cast<const u32x4*>(qb + (qo + 2u * HD));
     }
-    // Q never touches LDS: lane (li, g) reads chunk g of query row li of its tile - the MFMA fragment as it is
+    RowRegs<4> rk, rq;                                     // ROT: thread t owns row t of K and of Q
+    const int pc = tid < L ? tid : L - 1;
+    if (ROT) {
+      load_row<4>(rk, qb + (unsigned int)pc * 3u * HD + HD, cpr);
+      load_row<4>(rq, qb + (unsigned int)pc * 3u * HD, cpr);
+    } else {
+      // Q never touches LDS: lane (li, g) reads chunk g of query row li of its tile - the MFMA fragment as it is
 #pragma unroll
-    for (int qh = 0; qh < 2; ++qh)
+      for (int qh = 0; qh < 2; ++qh)
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
-        int row = qh * 128 + wid * 32 + qt * 16 + li; row = row < L ? row : L - 1;
-        qfr[qh][qt] = *reinterpret_cast<const u32x4*>(qb + ((unsigned int)row * 3u * HD + 8u * (g < cpr ? g : cpr - 1)));
-      }
+        for (int qt = 0; qt < 2; ++qt) {
+          int row = qh * 128 + wid * 32 + qt * 16 + li; row = row < L ? row : L - 1;
+          qfr[qh][qt] = *reinterpret_cast<const u32x4*>(qb + ((unsigned int)row * 3u * HD + 8u * (g < cpr ? g : cpr - 1)));
+        }
+    }
     mask_l[tid] = (tid < L && (!p.key_mask || p.key_mask[(long)b * L + tid])) ? 1 : 0;
     const bool pad = cpr < 4 && ci >= cpr;
     const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
       const int off = swz64(ps * 64 + r0, ci);
-      *reinterpret_cast<u32x4*>(ktile + off) = pad ? z : ck[ps];
+      if (!ROT) *reinterpret_cast<u32x4*>(ktile + off) = pad ? z : ck[ps];
       *reinterpret_cast<u32x4*>(vtile + off) = pad ? z : cv[ps];
     }
-    if (cpr < 4 && g >= cpr) {
+    if (ROT) {
+      rope_regs<D, 4>(rk, p.cosT + (long)pc * (D / 2), p.sinT + (long)pc * (D / 2));
+      rope_regs<D, 4>(rq, p.cosT + (long)pc * (D / 2), p.sinT + (long)pc * (D / 2));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {                        // chunks cpr..3 are the zero pad (load_row)
+        *reinterpret_cast<u32x4*>(ktile + swz64(tid, i)) = rk.c[i];
+        *reinterpret_cast<u32x4*>(qtile + swz64(tid, i)) = rq.c[i];
+      }
+      if (tid < L) {
+        unsigned short* wq = const_cast<unsigned short*>(qb) + (unsigned int)tid * 3u * HD;
+#pragma unroll
+        for (int i = 0; i < cpr; ++i) {
+          *reinterpret_cast<u32x4*>(wq + 8 * i) = rq.c[i];
+          *reinterpret_cast<u32x4*>(wq + HD + 8 * i) = rk.c[i];
+        }
+      }
+    } else if (cpr < 4 && g >= cpr) {
 #pragma unroll
       for (int qh = 0; qh < 2; ++qh) { qfr[qh][0] = z; qfr[qh][1] = z; }
     }
@@ -1252,7 +1280,10 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_whole32_kernel(const AP p) {
     if (q0 >= L) break;
     bf16x8 qf[2];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) qf[qt] = __builtin_bit_cast(bf16x8, qh == 0 ? qfr[0][qt] : qfr[1][qt]);
+    for (int qt = 0; qt < 2; ++qt) {
+      if (ROT) qf[qt] = *reinterpret_cast<const bf16x8*>(qtile + (q0 + wid * 32 + qt * 16) * 64 + swz64(li, g));
+      else qf[qt] = __builtin_bit_cast(bf16x8, qh == 0 ? qfr[0][qt] : qfr[1][qt]);
+    }
     f32x4 o[DT][2];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) { o[dt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; o[dt][1] = o[dt][0]; }
@@ -1366,22 +1397,25 @@ template <int DP> constexpr size_t lds_dkv() {
   return rows > img ? rows : img;
 }
 
-template <int D>
+template <int D, bool ROT>
 void launch_fwd_whole(const AP& p, hipStream_t st) {
-  constexpr int lds = 2 * FUSED_LMAX * 64 + 256;
-  hipLaunchKernelGGL((attn_fwd_whole32_kernel<D>), dim3(p.H * p.B), dim3(256), lds, st, p);
+  constexpr int lds = (ROT ? 3 : 2) * FUSED_LMAX * 64 + 256;
+  hipLaunchKernelGGL((attn_fwd_whole32_kernel<D, ROT>), dim3(p.H * p.B), dim3(256), lds, st, p);
+}
+inline bool whole_fwd_applies(int L, int D) {
+  const char* fe = getenv("CLIPK_ATTN_WHOLE_FWD");          // read per call: the tests flip it
+  return !(fe && atoi(fe) == 0) && L > 128 && L <= FUSED_LMAX && (D == 16 || D == 24 || D == 32);
 }
 
 template <int DP, int DR, int DX>
 int launch_fwd(const AP& p, hipStream_t st) {
   if constexpr (DP == 32 && DR == 0) {
     // short heads whose rows need no rotation: whole-head kernel (CLIPK_ATTN_WHOLE_FWD=0: the general one)
-    const char* fe = getenv("CLIPK_ATTN_WHOLE_FWD");
-    if (!(fe && atoi(fe) == 0) && p.L > 128 && p.L <= FUSED_LMAX && p.D >= 16) {
+    if (whole_fwd_applies(p.L, p.D)) {
       switch (p.D) {
-        case 16: launch_fwd_whole<16>(p, st); break;
-        case 24: launch_fwd_whole<24>(p, st); break;
-        default: launch_fwd_whole<32>(p, st); break;
+        case 16: launch_fwd_whole<16, false>(p, st); break;
+        case 24: launch_fwd_whole<24, false>(p, st); break;
+        default: launch_fwd_whole<32, false>(p, st); break;
       }
       return clipk_check_launch();
     }
@@ -1540,6 +1574,29 @@ extern "C" int clipk_rope_qk(void* qkv, const float* rope_cos, const float* rope
     case 32: hipLaunchKernelGGL(rope_qk_kernel<32>, grid, blk, 0, st, q, rope_cos, rope_sin, rows, L, H); break;
     case 64: hipLaunchKernelGGL(rope_qk_kernel<64>, grid, blk, 0, st, q, rope_cos, rope_sin, rows, L, H); break;
     default: hipLaunchKernelGGL(rope_qk_kernel<128>, grid, blk, 0, st, q, rope_cos, rope_sin, rows, L, H); break;
+  }
+  return clipk_check_launch();
+}
+
+extern "C" int clipk_attn_fwd_rot(void* qkv, const uint8_t* key_mask, const float* rope_cos, const float* rope_sin,
+                                  void* out, float* lse, int B, int L, int H, int D, float q_scale, void* stream) {
+  if (!rope_cos || !rope_sin) return CLIPK_ERR_BAD_ARG;
+  int rc = check_common(qkv, B, L, H, D, true);
+  if (rc) return rc;
+  if (!out || !lse || !aligned16(out)) return CLIPK_ERR_BAD_ARG;
+  if (!whole_fwd_applies(L, D)) {                           // every other shape: the two calls it stands for
+    rc = clipk_rope_qk(qkv, rope_cos, rope_sin, B, L, H, D, stream);
+    if (rc) return rc;
+    return clipk_attn_fwd(qkv, key_mask, nullptr, nullptr, out, lse, B, L, H, D, q_scale, stream);
+  }
+  AP p{};
+  p.qkv = (const unsigned short*)qkv; p.key_mask = key_mask; p.cosT = rope_cos; p.sinT = rope_sin;
+  p.out = (unsigned short*)out; p.lse = lse; p.B = B; p.L = L; p.H = H; p.D = D; p.scale = q_scale;
+  hipStream_t st = (hipStream_t)stream;
+  switch (D) {
+    case 16: launch_fwd_whole<16, true>(p, st); break;
+    case 24: launch_fwd_whole<24, true>(p, st); break;
+    default: launch_fwd_whole<32, true>(p, st); break;
   }
   return clipk_check_launch();
 }

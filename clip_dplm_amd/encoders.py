@@ -138,8 +138,8 @@ def _esm_layer_fwd(x, p, meta):
     if PREROTATE_QK and rope is not None:
         # RoPE once, in place: the attention kernels would otherwise rotate every K row 5x and every Q row 4x per
         # layer while staging it.  `qkv` (saved for backward) then holds rotated q / k.
-        ops.rope_qk_(qkv, B, L, H, D, rope)
-        ctx, lse = ops.attn_fwd(qkv, B, L, H, D, key_mask=mask, rope=None, q_scale=D ** -0.5)
+        # (one call; for the short ESM heads also one kernel, which rotates the rows while it stages them.)
+        ctx, lse = ops.attn_fwd_rot_(qkv, B, L, H, D, rope, key_mask=mask, q_scale=D ** -0.5)
     else:
         ctx, lse = ops.attn_fwd(qkv, B, L, H, D, key_mask=mask, rope=rope, q_scale=D ** -0.5)
     x2 = ops.gemm_nt(ctx, p["out"].wb, bias=p["out"].b, residual=x, out_dtype=torch.float32)

@@ -340,6 +340,21 @@ def rope_qk_(qkv, B, L, H, D, rope):
     return qkv
 
 
+def attn_fwd_rot_(qkv, B, L, H, D, rope, key_mask=None, q_scale=1.0):
+    """rope_qk_ + attn_fwd(rope=None) in one call (one kernel for short heads): rotates q / k of `qkv` in place and
+    returns (out, lse) computed from the rotated values; backward: attn_bwd(rope=..., prerotated=True)."""
+    _need_cuda(qkv, key_mask)
+    assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous() and qkv.shape == (B * L, 3 * H * D)
+    out = torch.empty((B * L, H * D), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
+    cos, sin = rope
+    check(_timed("attn_fwd", 4.0 * B * H * L * L * D,
+                 lambda: _lib().clipk_attn_fwd_rot(qkv.data_ptr(), ptr(key_mask), cos.data_ptr(), sin.data_ptr(),
+                                                   out.data_ptr(), lse.data_ptr(), B, L, H, D, float(q_scale),
+                                                   _stream())), "clipk_attn_fwd_rot")
+    return out, lse
+
+
 def attn_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=None, rope=None, q_scale=1.0, prerotated=False):
     _need_cuda(qkv, out, dout, lse)
     dqkv = torch.empty_like(qkv)

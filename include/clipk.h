@@ -187,6 +187,12 @@ int clipk_attn_bwd(const void* qkv, const uint8_t* key_mask, const float* rope_c
  * qkv bf16 [B*L, 3*H*D].  Afterwards call clipk_attn_fwd WITHOUT rope tables and clipk_attn_bwd with the tables and
  * prerotated = 1: q / k are then staged as they are and only the gradients go through RoPE^T. */
 int clipk_rope_qk(void* qkv, const float* rope_cos, const float* rope_sin, int B, int L, int H, int D, void* stream);
+/* clipk_rope_qk followed by clipk_attn_fwd(rope = NULL) in one call: q / k in `qkv` are rotated IN PLACE and the
+ * attention output / lse computed from the rotated values (same bits as the two calls).  Short heads (D in
+ * {16, 24, 32}, 128 < L <= 256) do both in one kernel - one workgroup owns every row of a head, rotates it while
+ * staging and writes it back; other shapes make the two calls.  Backward: clipk_attn_bwd(..., prerotated = 1). */
+int clipk_attn_fwd_rot(void* qkv, const uint8_t* key_mask, const float* rope_cos, const float* rope_sin,
+                       void* out, float* lse, int B, int L, int H, int D, float q_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Token embedding (ESM-2): x[t,:] = table[ids[t],:] * scale[b] * mask[t], with the token-dropout

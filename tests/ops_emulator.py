@@ -220,6 +220,11 @@ def rope_qk_(qkv, B, L, H, D, rope):
     return qkv
 
 
+def attn_fwd_rot_(qkv, B, L, H, D, rope, key_mask=None, q_scale=1.0):
+    rope_qk_(qkv, B, L, H, D, rope)
+    return attn_fwd(qkv, B, L, H, D, key_mask=key_mask, rope=None, q_scale=q_scale)
+
+
 def attn_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=None, rope=None, q_scale=1.0, prerotated=False):
     with torch.enable_grad():
         q = qkv.float().detach().requires_grad_(True)

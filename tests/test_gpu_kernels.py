@@ -474,6 +474,24 @@ def test_attention_fwd_whole_head_equals_general(dev, B, L, H, D, monkeypatch):
         assert torch.equal(o0, o1) and torch.equal(l0, l1)
 
 
+@pytest.mark.parametrize("B,L,H,D", [(8, 256, 20, 24), (3, 190, 4, 32), (2, 129, 3, 16), (2, 100, 4, 24), (1, 300, 2, 64)])
+def test_attention_fwd_rot_equals_rope_then_fwd(dev, B, L, H, D):
+    """clipk_attn_fwd_rot == clipk_rope_qk + clipk_attn_fwd(rope = NULL), bit for bit: the rotated q / k left in the
+    buffer, the output and the LSE.  Short heads at 128 < L <= 256 take the one-kernel path, the rest the two calls."""
+    ops = _ops()
+    qkv = _rand((B * L, 3 * H * D), dev, 90, 1.0, dtype=torch.bfloat16)
+    rope = _rope_tables(L, D, dev)
+    lens = torch.tensor([L] + [max(1, L - 31 * (i + 1)) for i in range(B - 1)])
+    mask = (torch.arange(L)[None] < lens[:, None]).to(torch.uint8).contiguous().to(dev)
+    for m in (None, mask):
+        a = ops.rope_qk_(qkv.clone(), B, L, H, D, rope)
+        o0, l0 = ops.attn_fwd(a, B, L, H, D, key_mask=m, rope=None, q_scale=D ** -0.5)
+        b = qkv.clone()
+        o1, l1 = ops.attn_fwd_rot_(b, B, L, H, D, rope, key_mask=m, q_scale=D ** -0.5)
+        assert torch.equal(a, b)
+        assert torch.equal(o0, o1) and torch.equal(l0, l1)
+
+
 # ------------------------------------------------------------------------------------------------ misc
 def test_cast_and_transpose(dev):
     ops = _ops()

@@ -74,5 +74,11 @@ for rnd in range(3):
     for mode, name in (("1", "hd 24 forward, whole-head"), ("0", "hd 24 forward, general")):
         os.environ["CLIPK_ATTN_WHOLE_FWD"] = mode
         fw[name].append(timeit(lambda: ops.attn_fwd(rot, B, L, H, D, rope=None, q_scale=D ** -0.5)))
+    os.environ["CLIPK_ATTN_WHOLE_FWD"] = "1"
+    scratch = qkv.clone()
+    fw["hd 24 rope_qk_ + forward (two launches)"].append(timeit(
+        lambda: ops.attn_fwd(ops.rope_qk_(scratch, B, L, H, D, r), B, L, H, D, rope=None, q_scale=D ** -0.5)))
+    fw["hd 24 attn_fwd_rot_ (one kernel)"].append(timeit(
+        lambda: ops.attn_fwd_rot_(scratch, B, L, H, D, r, q_scale=D ** -0.5)))
 for k, v in fw.items():
-    print(f"{k:26s}", " ".join(f"{x:7.1f}" for x in v), "us")
+    print(f"{k:40s}", " ".join(f"{x:7.1f}" for x in v), "us")
