@@ -14,6 +14,10 @@ if which == "gemm_fc1":
 elif which == "gemm_qkv":
     a, b, bias = rnd((T, 480)), rnd((1440, 480), 0.05), torch.randn(1440, device=dev)
     f = lambda: ops.gemm_nt(a, b, bias=bias)
+elif which == "gemm_fc2":
+    a, b, bias = rnd((T, 1920)), rnd((480, 1920), 0.05), torch.randn(480, device=dev)
+    res = torch.randn(T, 480, device=dev)
+    f = lambda: ops.gemm_nt(a, b, bias=bias, residual=res, out_dtype=torch.float32)
 elif which == "gemm_rnaqkv":
     a, b, bias = rnd((T, 768)), rnd((2304, 768), 0.05), torch.randn(2304, device=dev)
     f = lambda: ops.gemm_nt(a, b, bias=bias)
