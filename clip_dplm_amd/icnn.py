@@ -174,11 +174,10 @@ class SingleCellICNN(nn.Module):
         psi = z @ self.final.weight.t() + self.final.bias                     # [B,1] dot with one row: plumbing
         return psi, (x, xh, m0, r0, saved, act)
 
-    def forward(self, x: torch.Tensor, return_intermediates: bool = False):
-        if not self.training:
-            psi, _ = self._forward(x)
-            return psi, None
-        x = self.input_norm(x.float())                    # differentiable path (:156-179)
+    def _forward_diff(self, x: torch.Tensor, return_intermediates: bool = False):
+        """Differentiable (to any order) forward, :156-179: matrix products on the exact-f32 MFMA kernel through the
+        re-differentiable _MatmulNT, LayerNorm / activation by ATen.  Train mode, and hessian() in either mode."""
+        x = self.input_norm(x.float())
         inter = [] if return_intermediates else None
         z = None
         for layer in self.layers:
@@ -186,6 +185,12 @@ class SingleCellICNN(nn.Module):
             if return_intermediates:
                 inter.append(z)
         return _linear_f32(z, self.final.weight, self.final.bias), inter
+
+    def forward(self, x: torch.Tensor, return_intermediates: bool = False):
+        if not self.training:
+            psi, _ = self._forward(x)
+            return psi, None
+        return self._forward_diff(x, return_intermediates)
 
     def gradient(self, x: torch.Tensor, create_graph: bool = True) -> torch.Tensor:
         """T(x) = dPsi/dx.  Eval: hand-derived on kernels, no graph.  Train: autograd.grad with create_graph (:181-211),
@@ -199,6 +204,25 @@ class SingleCellICNN(nn.Module):
             gn = grad.norm(dim=-1, keepdim=True)
             return torch.where(gn > self.config.gradient_clip, grad * self.config.gradient_clip / gn, grad)
         return self._gradient_eval(x)
+
+    @torch.enable_grad()
+    def hessian(self, x: torch.Tensor) -> torch.Tensor:
+        """H[b, j, i] = d T_i(x_b) / d x_{b,j} (2_icnn_core.py:213-241): one autograd pass over the (create_graph)
+        transport map per output coordinate, the reference's convexity check.  Train mode differentiates the
+        norm-clipped T of the training branch and adds hessian_reg * I.  Like the reference it keeps the graph
+        (create_graph=True) so that a Hessian penalty can be trained through."""
+        x = x if x.requires_grad else x.detach().requires_grad_(True)
+        y = self._forward_diff(x)[0]
+        grad, = torch.autograd.grad(y.sum(), x, create_graph=True, retain_graph=True)
+        if self.training:
+            gn = grad.norm(dim=-1, keepdim=True)
+            grad = torch.where(gn > self.config.gradient_clip, grad * self.config.gradient_clip / gn, grad)
+        cols = [torch.autograd.grad(grad[..., i].sum(), x, create_graph=True, retain_graph=True)[0]
+                for i in range(grad.shape[-1])]
+        hess = torch.stack(cols, dim=-1)
+        if self.training:
+            hess = hess + self.config.hessian_reg * torch.eye(hess.shape[-1], device=hess.device).expand_as(hess)
+        return hess
 
     @torch.no_grad()
     def _gradient_eval(self, x: torch.Tensor) -> torch.Tensor:

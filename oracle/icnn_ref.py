@@ -1,7 +1,8 @@
 """CPU restatement (PyTorch f32) of the ICNN transport map, eval and train mode.  Test infrastructure only.
 
 triple_flow/2_icnn_core.py:88-127 (ConvexLayer.forward), :156-179 (SingleCellICNN.forward), :181-211 (gradient: the
-transport map is autograd's d Psi / d x), triple_flow/4_transport_maps.py:113-145 (LN -> T -> LN) and :59-87 (cost).
+transport map is autograd's d Psi / d x), :213-241 (hessian), triple_flow/4_transport_maps.py:113-145 (LN -> T -> LN)
+and :59-87 (cost).
 Weights keyed by the reference's state_dict names.
 """
 from __future__ import annotations
@@ -90,3 +91,24 @@ def single_cell_transport_train(source, target, sd: SD, prefix: str, n_layers: i
         tgt = _ln(target, sd, f"{prefix}.output_norm", 1e-5)
         cost, w2, sp = transport_cost(t, tgt, regularization)
     return t, cost, w2, sp
+
+
+def icnn_hessian(x, sd: SD, prefix: str, n_layers: int, train: bool = False, gradient_clip: float = 1.0,
+                 hessian_reg: float = 1e-4, **kw):
+    """2_icnn_core.py:213-241: H[b, j, i] = d T_i(x_b) / d x_{b,j}, one autograd pass per output coordinate.  Train mode
+    differentiates the norm-clipped T of the training branch and adds hessian_reg * I."""
+    with torch.enable_grad():
+        xr = x.detach().clone().requires_grad_(True)
+        if train:
+            psi = icnn_potential_train(xr, sd, prefix, n_layers, gradient_clip=gradient_clip, **kw)
+        else:
+            psi = icnn_potential(xr, sd, prefix, n_layers, **kw)
+        g, = torch.autograd.grad(psi.sum(), xr, create_graph=True, retain_graph=True)
+        if train:
+            gn = g.norm(dim=-1, keepdim=True)
+            g = torch.where(gn > gradient_clip, g * gradient_clip / gn, g)
+        cols = [torch.autograd.grad(g[..., i].sum(), xr, retain_graph=True)[0] for i in range(g.shape[-1])]
+    h = torch.stack(cols, dim=-1)
+    if train:
+        h = h + hessian_reg * torch.eye(h.shape[-1]).expand_as(h)
+    return h

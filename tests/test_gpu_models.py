@@ -387,6 +387,32 @@ def test_icnn_training_through_transport_map_golden(dev, case):
     assert m(src).shape == (24, 64)
 
 
+def test_icnn_hessian_golden(dev):
+    """SingleCellICNN.hessian (2_icnn_core.py:213-241) vs the reference's, eval and train mode: third-order use of the
+    re-differentiable exact-f32 matrix product (autograd of autograd of the potential, one pass per coordinate)."""
+    from clip_dplm_amd import icnn
+    zf = np.load(os.path.join(G, "icnn_hessian.npz"))
+    sd = {k[2:]: torch.from_numpy(zf[k]) for k in zf.files if k.startswith("w:")}
+    m = icnn.SingleCellICNN(icnn.ICNNConfig(input_dim=16, hidden_dims=[16, 16, 8]))
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    x = torch.from_numpy(zf["x"]).to(dev)
+    for mode in ("eval", "train"):
+        m.train(mode == "train")
+        h = m.hessian(x.clone())
+        ref = torch.from_numpy(zf["hessian_" + mode])
+        assert h.shape == ref.shape and h.requires_grad            # graph kept, as in the reference
+        err = (h.detach().cpu() - ref).abs().max().item()
+        assert err < 2e-4 * max(ref.abs().max().item(), 1.0), (mode, err)
+    # the eval-mode transport map (kernel-only path) is the gradient the Hessian differentiates: finite differences
+    m.eval()
+    eps = 1e-2
+    e0 = torch.zeros_like(x); e0[:, 0] = eps
+    fd = (m.gradient(x + e0) - m.gradient(x - e0)) / (2 * eps)     # d T / d x_0  = H[:, 0, :]
+    h = m.hessian(x.clone()).detach()
+    assert (fd - h[:, 0, :]).abs().max().item() < 5e-2 * max(h.abs().max().item(), 1.0)
+
+
 def test_icnn_training_large_ragged_batch_vs_oracle(dev):
     """Batch 1030 (not a multiple of 4, longer than one contraction chunk of the f32 kernel): the weight-gradient
     products of the double backward are chunked and zero-padded; cost and gradients vs the CPU oracle."""

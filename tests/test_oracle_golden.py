@@ -142,6 +142,17 @@ def test_icnn_training_branch():
                 assert torch.allclose(g, torch.from_numpy(zf[k]), atol=5e-5), k
 
 
+def test_icnn_hessian():
+    """oracle hessian (2_icnn_core.py:213-241) vs the reference's, eval and train mode (tools/make_golden.py)."""
+    from oracle import icnn_ref
+    zf = np.load(os.path.join(G, "icnn_hessian.npz"))
+    sd = {"n." + k[2:]: torch.from_numpy(zf[k]) for k in zf.files if k.startswith("w:")}
+    x = torch.from_numpy(zf["x"])
+    for mode in ("eval", "train"):
+        h = icnn_ref.icnn_hessian(x, sd, "n", 3, train=(mode == "train"))
+        assert torch.allclose(h, torch.from_numpy(zf["hessian_" + mode]), rtol=1e-4, atol=2e-5), mode
+
+
 def test_icnn_transport_maps():
     """triple_flow ICNN transport maps (eval): oracle vs the reference's autograd-of-autograd outputs."""
     from oracle import icnn_ref

@@ -224,8 +224,9 @@ def _load(name, path):
 def gen_icnn():
     from oracle import icnn_ref
     _load("config", REF + "/triple_flow/1_config.py")
-    _load("core", REF + "/triple_flow/2_icnn_core.py")
+    core = _load("core", REF + "/triple_flow/2_icnn_core.py")
     tm = _load("transport_maps", REF + "/triple_flow/4_transport_maps.py")
+    gen_icnn_hessian(core, icnn_ref)
     torch.manual_seed(0)
     model = tm.create_transport_system(64, 64, 64, hidden_dims=[64, 64, 32]).eval()
     with torch.no_grad():                                     # make the positive path matter
@@ -291,6 +292,35 @@ def gen_icnn_train(tm, icnn_ref):
                        for k, v in m.named_parameters()})
         arrays.update({f"{case}:w:" + k: v.detach().numpy() for k, v in m.state_dict().items()})
     save("icnn_train.npz", **arrays)
+
+
+def gen_icnn_hessian(core, icnn_ref):
+    """SingleCellICNN.hessian (2_icnn_core.py:213-241), eval and train mode, on a small potential."""
+    cfgm = sys.modules["config"]
+    cfg = cfgm.ICNNConfig(input_dim=16, hidden_dims=[16, 16, 8])
+    torch.manual_seed(5)
+    m = core.SingleCellICNN(cfg)
+    with torch.no_grad():
+        for mod in m.modules():
+            if hasattr(mod, "pos_weights"):
+                mod.pos_weights.normal_(0, 0.5)
+                mod.scale.fill_(0.3)
+        m.final.weight.mul_(3.0)                             # some rows of T above the clip norm in train mode
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(6, 16, generator=g)
+    sd = {"n." + k: v.detach() for k, v in m.state_dict().items()}
+    arrays = {"x": x.numpy()}
+    for mode in ("eval", "train"):
+        m.train(mode == "train")
+        h = m.hessian(x.clone()).detach()
+        o = icnn_ref.icnn_hessian(x, sd, "n", 3, train=(mode == "train"), hessian_reg=cfg.hessian_reg)
+        check(f"icnn hessian {mode}", o, h, 2e-5)
+        arrays["hessian_" + mode] = h.numpy()
+        if mode == "eval":
+            ev = torch.linalg.eigvalsh(0.5 * (h + h.transpose(-1, -2)))
+            print(f"  hessian fixture: min eigenvalue of sym(H) over the batch {ev.min().item():.3e}")
+    arrays.update({"w:" + k: v.detach().numpy() for k, v in m.state_dict().items()})
+    save("icnn_hessian.npz", **arrays)
 
 
 def gen_esm_projections():
