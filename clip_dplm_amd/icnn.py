@@ -139,8 +139,6 @@ class SingleCellICNN(nn.Module):
 
     def __init__(self, config: ICNNConfig):
         super().__init__()
-        if not config.use_layer_norm:
-            raise NotImplementedError("use_layer_norm=False is not built")
         if any(h != config.input_dim for h in config.hidden_dims[:-1]):
             raise ValueError("the reference only runs when hidden_dims[:-1] == input_dim (SURVEY App. A-11)")
         self.config = config
@@ -187,10 +185,13 @@ class SingleCellICNN(nn.Module):
         return _linear_f32(z, self.final.weight, self.final.bias), inter
 
     def forward(self, x: torch.Tensor, return_intermediates: bool = False):
-        if not self.training:
-            psi, _ = self._forward(x)
-            return psi, None
-        return self._forward_diff(x, return_intermediates)
+        if self.training:
+            return self._forward_diff(x, return_intermediates)
+        if not self.config.use_layer_norm:                # the fused LN + activation kernels do not apply: same
+            with torch.no_grad():                         # products, activation by ATen
+                return self._forward_diff(x)[0], None
+        psi, _ = self._forward(x)
+        return psi, None
 
     def gradient(self, x: torch.Tensor, create_graph: bool = True) -> torch.Tensor:
         """T(x) = dPsi/dx.  Eval: hand-derived on kernels, no graph.  Train: autograd.grad with create_graph (:181-211),
@@ -203,6 +204,11 @@ class SingleCellICNN(nn.Module):
                 grad, = torch.autograd.grad(y.sum(), x, create_graph=create_graph, retain_graph=True)
             gn = grad.norm(dim=-1, keepdim=True)
             return torch.where(gn > self.config.gradient_clip, grad * self.config.gradient_clip / gn, grad)
+        if not self.config.use_layer_norm:                # no hand-derived chain without the fused LN kernels
+            with torch.enable_grad():
+                xr = x.detach().requires_grad_(True)
+                grad, = torch.autograd.grad(self._forward_diff(xr)[0].sum(), xr)
+            return grad.detach()
         return self._gradient_eval(x)
 
     @torch.enable_grad()

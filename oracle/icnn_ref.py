@@ -17,7 +17,8 @@ from .clip_ref import _linear, _ln
 SD = Dict[str, torch.Tensor]
 
 
-def icnn_potential(x, sd: SD, prefix: str, n_layers: int, eps_w: float = 1e-6, activation: str = "celu"):
+def icnn_potential(x, sd: SD, prefix: str, n_layers: int, eps_w: float = 1e-6, activation: str = "celu",
+                   use_layer_norm: bool = True):
     xh = _ln(x, sd, f"{prefix}.input_norm", 1e-5)
     z = None
     for k in range(n_layers):
@@ -26,7 +27,8 @@ def icnn_potential(x, sd: SD, prefix: str, n_layers: int, eps_w: float = 1e-6, a
         if z is not None:
             pos_w = F.softplus(sd[f"{p}.pos_weights"] + eps_w)
             y = y + (z @ pos_w.t()) * sd[f"{p}.scale"]
-        y = _ln(y, sd, f"{p}.norm", 1e-5)
+        if use_layer_norm:                                # 2_icnn_core.py:72: nn.Identity otherwise
+            y = _ln(y, sd, f"{p}.norm", 1e-5)
         z = F.softplus(y) if activation == "softplus" else F.celu(y)
     return _linear(z, sd, f"{prefix}.final")
 

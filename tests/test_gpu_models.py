@@ -413,6 +413,31 @@ def test_icnn_hessian_golden(dev):
     assert (fd - h[:, 0, :]).abs().max().item() < 5e-2 * max(h.abs().max().item(), 1.0)
 
 
+def test_icnn_without_layer_norm_golden(dev):
+    """ICNNConfig(use_layer_norm=False, activation="softplus"): the layers have no LayerNorm (nn.Identity, :72), so the
+    fused LN + activation kernels do not apply; the same exact-f32 products with the activation by ATen.  Potential and
+    transport map vs the reference, eval mode; the train mode of the same module runs and back-propagates."""
+    from clip_dplm_amd import icnn
+    zf = np.load(os.path.join(G, "icnn_noln.npz"))
+    sd = {k[2:]: torch.from_numpy(zf[k]) for k in zf.files if k.startswith("w:")}
+    m = icnn.SingleCellICNN(icnn.ICNNConfig(input_dim=16, hidden_dims=[16, 16, 8], use_layer_norm=False,
+                                            activation="softplus"))
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    x = torch.from_numpy(zf["x"]).to(dev)
+    psi, _ = m(x)
+    assert (psi.cpu() - torch.from_numpy(zf["psi"])).abs().max().item() < 2e-4
+    assert (m.gradient(x).cpu() - torch.from_numpy(zf["gradient"])).abs().max().item() < 2e-4
+    m.train()
+    t = m.gradient(x)
+    t.square().sum().backward()
+    # (without LayerNorm the z contributions are large and the train-time rescale fires: as in fixture case B of the
+    # training test the rescaled path is a constant, so only the last layer's x path and `final` receive gradients)
+    grads = {n: p.grad for n, p in m.named_parameters() if p.grad is not None}
+    assert {"final.weight", "layers.2.linear.weight", "layers.2.linear.bias"} <= set(grads)
+    assert all(torch.isfinite(g).all() for g in grads.values())
+
+
 def test_icnn_training_large_ragged_batch_vs_oracle(dev):
     """Batch 1030 (not a multiple of 4, longer than one contraction chunk of the f32 kernel): the weight-gradient
     products of the double backward are chunked and zero-padded; cost and gradients vs the CPU oracle."""

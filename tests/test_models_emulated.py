@@ -21,6 +21,7 @@ CASES = [
     ("icnn_train_A", T.test_icnn_training_through_transport_map_golden, {"case": "A"}),
     ("icnn_train_B", T.test_icnn_training_through_transport_map_golden, {"case": "B"}),
     ("icnn_hessian", T.test_icnn_hessian_golden, {}),
+    ("icnn_noln", T.test_icnn_without_layer_norm_golden, {}),
     ("icnn_train_ragged", T.test_icnn_training_large_ragged_batch_vs_oracle, {}),
     ("esm_proj", T.test_esm_projections_golden, {}),
 ]

@@ -153,6 +153,17 @@ def test_icnn_hessian():
         assert torch.allclose(h, torch.from_numpy(zf["hessian_" + mode]), rtol=1e-4, atol=2e-5), mode
 
 
+def test_icnn_without_layer_norm():
+    """use_layer_norm = False (ConvexLayer.norm = nn.Identity), softplus activation: potential and transport map."""
+    from oracle import icnn_ref
+    zf = np.load(os.path.join(G, "icnn_noln.npz"))
+    sd = {"n." + k[2:]: torch.from_numpy(zf[k]) for k in zf.files if k.startswith("w:")}
+    x = torch.from_numpy(zf["x"])
+    kw = dict(activation="softplus", use_layer_norm=False)
+    assert torch.allclose(icnn_ref.icnn_potential(x, sd, "n", 3, **kw), torch.from_numpy(zf["psi"]), atol=2e-5)
+    assert torch.allclose(icnn_ref.icnn_gradient(x, sd, "n", 3, **kw), torch.from_numpy(zf["gradient"]), atol=2e-5)
+
+
 def test_icnn_transport_maps():
     """triple_flow ICNN transport maps (eval): oracle vs the reference's autograd-of-autograd outputs."""
     from oracle import icnn_ref

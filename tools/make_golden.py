@@ -321,6 +321,22 @@ def gen_icnn_hessian(core, icnn_ref):
             print(f"  hessian fixture: min eigenvalue of sym(H) over the batch {ev.min().item():.3e}")
     arrays.update({"w:" + k: v.detach().numpy() for k, v in m.state_dict().items()})
     save("icnn_hessian.npz", **arrays)
+    # use_layer_norm = False (ConvexLayer.norm = nn.Identity, :72), softplus activation: potential and transport map
+    cfg2 = cfgm.ICNNConfig(input_dim=16, hidden_dims=[16, 16, 8], use_layer_norm=False, activation="softplus")
+    torch.manual_seed(6)
+    m2 = core.SingleCellICNN(cfg2).eval()
+    with torch.no_grad():
+        for mod in m2.modules():
+            if hasattr(mod, "pos_weights"):
+                mod.pos_weights.normal_(0, 0.5)
+                mod.scale.fill_(0.3)
+    psi = m2(x.clone())[0].detach()
+    tmap = m2.gradient(x.clone()).detach()
+    sd2 = {"n." + k: v.detach() for k, v in m2.state_dict().items()}
+    check("icnn no-LN potential", icnn_ref.icnn_potential(x, sd2, "n", 3, activation="softplus", use_layer_norm=False), psi, 2e-5)
+    check("icnn no-LN gradient", icnn_ref.icnn_gradient(x, sd2, "n", 3, activation="softplus", use_layer_norm=False), tmap, 2e-5)
+    save("icnn_noln.npz", x=x.numpy(), psi=psi.numpy(), gradient=tmap.numpy(),
+         **{"w:" + k: v.detach().numpy() for k, v in m2.state_dict().items()})
 
 
 def gen_esm_projections():
