@@ -1,28 +1,42 @@
 #!/usr/bin/env python3
 """bench.py — seq-pairs/sec of one full contrastive TRAINING step (forward + fused InfoNCE + backward + fused
-AdamW with global-norm clip) of the BASELINE-config-2 dual encoder on MI355X:
+AdamW with global-norm clip) of the BASELINE dual encoder on MI355X.
+
+Default workload = the configuration BASELINE.json's metric is quoted on:
 
     ESM-2-35M protein encoder (12 x 480, 20 heads, hd 24, ffn 1920, RoPE) + 6 x 768 RNA transformer
-    (8 heads, ffn 2048, gelu, post-LN) + ProjectionHeads (P = 512), B = 512 pairs per GPU, L = 256, bf16 MFMA
+    (8 heads, ffn 2048, gelu, post-LN) + ProjectionHeads (P = 512), B = 1024 pairs per GPU, L = 256, bf16 MFMA
     with f32 accumulate / residual stream / master weights, both encoders trained, synthetic data,
     random-init weights N(0, 0.02).
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank/GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = the bf16
-MFMA Linear kernel gemm_nt, timed live with HIP events on the launch stream) and `cpu_baseline` (the CPU
-oracle timed on this box's host cores on a bounded sample; rank 0, N = 1 only).
+N > 1 without a torch.distributed environment: this process starts N fresh ranks itself
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`) BEFORE any HIP call
+and exits with the launcher's return code; under torch.distributed.run it is one rank (RCCL over xGMI).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with
+  * `roofline`: dominant kernel = the bf16 MFMA Linear kernel clipk_gemm_nt, timed live with HIP events on its
+    launch stream; `traffic` = HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same
+    command (profiles/traffic_gemm_nt.json, written by tools/pmc_traffic.py; FETCH_SIZE doubled per
+    MI355X_MICROARCH.md §HBM), null when that file is absent;
+  * `parity`: the step-0 loss of a fixed 32-pair sub-batch on the GPU next to the CPU oracle's on the same weights;
+  * `cpu_baseline`: the CPU oracle (kind "port") timed on this box's host cores on a bounded sample (B = 32).
+
+Other BASELINE configurations (bench lines of their own, not the driver's default):
+    --config c2 --batch 512    config 2 as written (B = 512)
+    --config c4                frozen ESM-2-650M (33 x 1280) at L = 1024, B_local = 256 + trained RNA tower / heads
+    --config c3sim             fused similarity + CE at one rank's config-3 shape (512 x 4096 x 512): achieved GB/s
+    --config c5                ICNN transport system 512 / [512, 256], B = 4096 (eval transport maps)
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -31,9 +45,46 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16 MFMA peak, /opt/skills/guides/
 HBM_PEAK_GBS = 8000.0
 
 
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c2", choices=["c2", "c3sim", "c4", "c5"])
+    ap.add_argument("--batch", type=int, default=None, help="pairs per GPU (default: 1024 for c2, 256 for c4, 4096 for c5)")
+    ap.add_argument("--seq-len", type=int, default=None)
+    ap.add_argument("--esm", default=None)
+    ap.add_argument("--freeze-esm", action="store_true", help="reference behaviour (3_esm_integration.py:83-84)")
+    ap.add_argument("--dual-stream", action="store_true",
+                    help="enqueue the two towers on separate HIP streams (a kernel's HIP-event time then includes "
+                         "waiting for the other tower's kernels)")
+    ap.add_argument("--micro-batches", type=int, default=1, help="with --dual-stream: stream pairs per step")
+    ap.add_argument("--wgrad-stream", action="store_true", help="weight-gradient GEMMs on a side stream per tower")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--all-kernel-timers", action="store_true",
+                    help="HIP events around EVERY kernel launch of the timed region (costs ~1 %% of the step); "
+                         "default: only the dominant kernel, clipk_gemm_nt")
+    return ap.parse_args()
+
+
+def self_launch(args) -> int:
+    """--gpus N > 1 outside torch.distributed.run: start N fresh ranks.  Nothing in this process has touched HIP."""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    print(f"[bench] starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def synth_batch(B, L, rna_dim, device, seed):
     """protein ids uniform over the 20 standard amino-acid ids [4, 24) with <cls>=0 first and <eos>=2
     last, no padding; RNA side N(0,1) features [B, L, rna_dim] (the reference feeds precomputed RNABERT vectors)."""
+    import torch
     g = torch.Generator().manual_seed(seed)
     ids = torch.randint(4, 24, (B, L), generator=g)
     ids[:, 0] = 0
@@ -42,27 +93,36 @@ def synth_batch(B, L, rna_dim, device, seed):
     return rna.to(device), ids.to(device)
 
 
-def cpu_baseline(model_sd, cfg, L, sample_b=8, steps=2):
-    """Time the CPU oracle (kind 'port') on a bounded sample of the same workload: forward + backward + AdamW."""
-    from oracle import model_ref
+def host_threads():
     try:
-        ncores = len(os.sched_getaffinity(0))             # the cores this process may actually use (cgroup share)
+        n = len(os.sched_getaffinity(0))                  # the cores this process may actually use (cgroup share)
     except AttributeError:
-        ncores = os.cpu_count() or 1
-    ncores = max(1, min(ncores, 64))
+        n = os.cpu_count() or 1
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(model_sd, cfg, L, sample_b=32, steps=3, budget_s=75.0):
+    """Time the CPU oracle (kind 'port') on a bounded sample of the same workload: forward + backward + clip + AdamW
+    (B = 32, >= 3 steps).  The first (warm-up) step runs on the initial weights, so its loss is also the
+    oracle side of the `parity` object.  Returns (cpu_baseline dict, step-0 oracle loss)."""
+    import torch
+    from oracle import model_ref
+    ncores = host_threads()
     torch.set_num_threads(ncores)
     sd = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in model_sd.items()}
     params = [v for v in sd.values() if v.requires_grad]
     opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01)
-    rna, ids = synth_batch(sample_b, L, cfg["rna_dim"], "cpu", 1234)
-    times = []
-    budget_s, t_start = 30.0, time.perf_counter()
+    rna, ids = synth_batch(sample_b, L, cfg["rna_dim"], "cpu", 4321)
+    times, loss0 = [], None
+    t_start = time.perf_counter()
     for it in range(steps + 1):
         t0 = time.perf_counter()
         opt.zero_grad()
         loss, _, _ = model_ref.protein_rna_clip_loss(sd, rna, ids, None, None, esm_layers=cfg["esm_layers"],
                                                      esm_heads=cfg["esm_heads"], rna_layers=cfg["rna_layers"],
                                                      rna_heads=cfg["rna_heads"])
+        if it == 0:
+            loss0 = float(loss.item())
         loss.backward()
         torch.nn.utils.clip_grad_norm_(params, 1.0)
         opt.step()
@@ -70,46 +130,49 @@ def cpu_baseline(model_sd, cfg, L, sample_b=8, steps=2):
         print(f"[cpu_baseline] step {it}: {times[-1]:.2f} s on {ncores} threads", file=sys.stderr, flush=True)
         if time.perf_counter() - t_start > budget_s:      # bounded sample: never hold the bench for minutes
             break
-    timed = times[1:] if len(times) > 1 else times         # drop the warm-up step when there is more than one
-    dt = sum(timed) / len(timed)
-    return {"value": round(sample_b / dt, 3), "unit": "seq-pairs/s", "cores": ncores, "kind": "port",
-            "sample": f"{len(timed)} training step(s) (fwd+bwd+clip+AdamW) of the CPU oracle at B={sample_b}, L={L}, "
-                      f"f32, {'after 1 warm-up step' if len(times) > 1 else 'no warm-up (time budget)'}; {dt:.2f} s/step"}
+    timed = sorted(times[1:] if len(times) > 1 else times)   # drop the warm-up step when there is more than one
+    dt = timed[len(timed) // 2]                              # median
+    return ({"value": round(sample_b / dt, 3), "unit": "seq-pairs/s", "cores": ncores, "kind": "port",
+             "sample": f"median of {len(timed)} training step(s) (fwd+bwd+clip+AdamW) of the CPU oracle at B={sample_b}, "
+                       f"L={L}, f32, {'after 1 warm-up step' if len(times) > 1 else 'no warm-up (time budget)'}; "
+                       f"{dt:.2f} s/step"}, loss0)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="pairs per GPU")
-    ap.add_argument("--seq-len", type=int, default=256)
-    ap.add_argument("--esm", default="esm2_t12_35M_UR50D")
-    ap.add_argument("--freeze-esm", action="store_true", help="reference behaviour (3_esm_integration.py:83-84)")
-    ap.add_argument("--dual-stream", action="store_true",
-                    help="enqueue the two towers on separate HIP streams (+1.5 %% pairs/s; a kernel's HIP-event time "
-                         "then includes waiting for the other tower's kernels, so the per-kernel numbers are not "
-                         "the kernels' own durations any more)")
-    ap.add_argument("--single-stream", action="store_true", help="(default; kept for older command lines)")
-    ap.add_argument("--micro-batches", type=int, default=1, help="stream pairs per step (batch split over them)")
-    ap.add_argument("--wgrad-stream", action="store_true", help="weight-gradient GEMMs on a side stream per tower")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-timers", action="store_true")
-    ap.add_argument("--all-kernel-timers", action="store_true",
-                    help="HIP events around EVERY kernel launch of the timed region (costs ~1 %% of the step); "
-                         "default: only the dominant kernel, clipk_gemm_nt")
-    args = ap.parse_args()
+def load_traffic(workload_key):
+    """HBM-side bytes per clipk_gemm_nt launch from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py)."""
+    path = os.path.join(ROOT, "profiles", "traffic_gemm_nt.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None
+    e = t.get(workload_key)
+    return e
+
+
+# ====================================================================================================== c2 / c4
+def bench_clip(args):
+    import torch
+    import torch.distributed as dist
 
     import clip_dplm_amd as K
     from clip_dplm_amd import ops
     from clip_dplm_amd.distributed import init_distributed
     from clip_dplm_amd.encoders import ESM2_SHAPES
+    import clip_dplm_amd.encoders as _enc
+
+    c4 = args.config == "c4"
+    esm = args.esm or ("esm2_t33_650M_UR50D" if c4 else "esm2_t12_35M_UR50D")
+    B = args.batch or (256 if c4 else 1024)
+    Lp = args.seq_len or (1024 if c4 else 256)
+    Lr = 256 if c4 else Lp
+    freeze = args.freeze_esm or c4
 
     rank, world, device = init_distributed()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     force_dist = bool(os.environ.get("CLIPK_FORCE_DIST"))     # rehearse the RCCL code path with a 1-rank group
     if force_dist and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -118,18 +181,32 @@ def main():
     group = dist.group.WORLD if (world > 1 or force_dist) else None
 
     torch.manual_seed(0)                                  # identical weights on every rank
-    model = K.ProteinRNACLIP(esm=args.esm, freeze_protein_encoder=args.freeze_esm).to(device).train()
+    model = K.ProteinRNACLIP(esm=esm, freeze_protein_encoder=freeze).to(device).train()
     for m in model.modules():                             # training-step timing with dropout p = 0
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
-    model.dual_stream = bool(args.dual_stream) and not args.single_stream
+    model.dual_stream = bool(args.dual_stream)
     model.micro_batches = args.micro_batches
-    import clip_dplm_amd.encoders as _enc
     _enc.WGRAD_SIDE_STREAM = args.wgrad_stream
-    sd_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if rank == 0 else None
+    nl, d, h, f = ESM2_SHAPES[esm]
+    want_cpu = rank == 0 and world == 1 and not c4 and not (args.no_cpu_baseline and args.no_parity)
+    sd_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if want_cpu else None
+
+    # ---- parity object, GPU side: step-0 loss of a fixed 32-pair sub-batch on the initial weights (eval mode == train
+    # mode here: dropout p = 0).  The oracle side comes from cpu_baseline()'s first step on the same batch.
+    parity = None
+    if want_cpu and not args.no_parity:
+        rna_s, ids_s = synth_batch(32, Lp, 768, device, 4321)
+        with torch.no_grad():
+            parity = {"sub_batch": 32, "loss_gpu": float(model.loss(rna_s, ids_s).item())}
+        del rna_s, ids_s
+
     opt = K.FusedAdamW(model, lr=1e-4, weight_decay=0.01, max_grad_norm=1.0, group=group)
-    B, L = args.batch, args.seq_len
-    rna, ids = synth_batch(B, L, 768, device, 1234 + rank)
+    g = torch.Generator().manual_seed(1234 + rank)
+    ids = torch.randint(4, 24, (B, Lp), generator=g)
+    ids[:, 0], ids[:, -1] = 0, 2
+    rna = torch.randn(B, Lr, 768, generator=g).to(device)
+    ids = ids.to(device)
 
     def step():
         opt.zero_grad()
@@ -161,15 +238,13 @@ def main():
     dt = time.perf_counter() - t0
     ops.set_kernel_timer(None)
     # Two more steps OUTSIDE the timed region, one HIP stream, HIP events around every launch: the per-class breakdown
-    # (`kernels`) without taxing the timed region (~1 % when every launch is timed), and with --dual-stream also the
-    # dominant kernel's own rate (`roofline.one_stream`): with two streams a kernel's event time includes waiting
-    # for the other tower's kernels.
+    # (`kernels`) without taxing the timed region (~1 % when every launch is timed).
     timer_alone = None
     was_dual = model.dual_stream
     if timer is not None and rank == 0 and world == 1 and (was_dual or not args.all_kernel_timers):
         model.dual_stream = False
         step(); torch.cuda.synchronize()
-        timer_alone = ops.KernelTimer()            # outside the timed region: every kernel class
+        timer_alone = ops.KernelTimer()
         ops.set_kernel_timer(timer_alone)
         for _ in range(2):
             step()
@@ -187,40 +262,49 @@ def main():
             dist.destroy_process_group()
         return
 
-    nl, d, h, f = ESM2_SHAPES[args.esm]
+    if c4:
+        workload = (f"BASELINE config 4 (one rank's share): frozen {esm} protein encoder (33 x 1280, hd 64) at L={Lp}, "
+                    f"B={B} sequences/GPU + trained 6x768 RNA transformer (L={Lr}) and projection heads, full training "
+                    f"step (fwd + fused InfoNCE + bwd of the trained parts + fused AdamW/clip)")
+        metric = "seq-pairs/sec/node, contrastive training step, frozen ESM-2-650M dual encoder (config 4)"
+    else:
+        workload = (f"BASELINE metric config: {esm} protein encoder + 6x768 RNA transformer, B={B} pairs/GPU, L={Lp}, "
+                    f"full training step (fwd + fused InfoNCE + bwd + fused AdamW/clip), "
+                    + ("ESM frozen" if freeze else "both encoders trained"))
+        metric = "seq-pairs/sec/node, contrastive training step, ESM-2-35M dual encoder"
     out = {
-        "metric": "seq-pairs/sec/node, contrastive training step, ESM-2-35M dual encoder",
+        "metric": metric,
         "value": round(B * world * args.steps / dt, 2),
         "unit": "seq-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"BASELINE config 2: {args.esm} protein encoder + 6x768 RNA transformer, "
-                               f"B={B} pairs/GPU, L={L}, full training step (fwd + fused InfoNCE + bwd + fused AdamW/clip), "
-                               + ("ESM frozen" if args.freeze_esm else "both encoders trained"),
-                   "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}",
+        "config": {"workload": workload, "global_batch": B * world, "seq_len": Lp, "parallelism": f"dp{world}",
                    "projection_dim": 512, "hip_streams": 2 if model.dual_stream else 1},
         "loss": round(float(loss.item()), 5),
     }
+    # algorithmic FLOP of one step (8d^2 + 4Ld + 4df per token.layer forward; x3 trained, x1 frozen)
+    fl_esm = (8 * d * d + 4 * Lp * d + 4 * d * f) * nl * Lp * (1 if freeze else 3)
+    fl_rna = (8 * 768 * 768 + 4 * Lr * 768 + 4 * 768 * 2048) * 6 * Lr * 3
+    step_tflop = B * (fl_esm + fl_rna) / 1e12
+    out["step_mfu"] = {"algorithmic_tflop_per_step": round(step_tflop, 2),
+                       "achieved_tflops": round(step_tflop / (dt / args.steps), 1),
+                       "frac_of_bf16_peak": round(step_tflop / (dt / args.steps) / MFMA_BF16_PEAK_TFLOPS, 4)}
     if timer is not None:
         summ = timer.summary()
-        g = summ.get("gemm_nt")
-        if g:
-            achieved = g["work"] / (g["total_ms"] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "clipk_gemm_nt = gemm_nt_v3_kernel / gemm_nt_v2_kernel (bf16 16x16x32 MFMA Linear fwd/dgrad)",
+        gm = summ.get("gemm_nt")
+        if gm:
+            achieved = gm["work"] / (gm["total_ms"] * 1e-3) / 1e12
+            traffic = load_traffic(f"{args.config}_B{B}")
+            out["roofline"] = {"bound": "mfma",
+                               "kernel": "clipk_gemm_nt = gemm_nt_v3_kernel / gemm_nt_v2_kernel (bf16 16x16x32 MFMA Linear fwd/dgrad)",
                                "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                               "avg_launch_us": round(g["avg_us"], 2), "launches": g["launches"],
-                               "share_of_step": round(g["total_ms"] / (1e3 * dt), 4)}
-            if timer_alone is not None and was_dual:
-                ga = timer_alone.summary().get("gemm_nt")
-                if ga:
-                    ach = ga["work"] / (ga["total_ms"] * 1e-3) / 1e12
-                    out["roofline"]["one_stream"] = {"achieved": round(ach, 2), "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                                                     "avg_launch_us": round(ga["avg_us"], 2), "launches": ga["launches"],
-                                                     "note": "same kernels, 2 extra steps outside the timed region "
-                                                             "with both towers on one HIP stream"}
-        # per-class breakdown: from the timed region with --all-kernel-timers, else from the two extra one-stream steps
+                               "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
+                               "traffic": traffic["bytes_per_launch"] if traffic else None,
+                               "avg_launch_us": round(gm["avg_us"], 2), "launches": gm["launches"],
+                               "share_of_step": round(gm["total_ms"] / (1e3 * dt), 4)}
+            if traffic:
+                out["roofline"]["traffic_detail"] = {k: traffic[k] for k in traffic if k != "bytes_per_launch"}
         src, steps_src, tag = (summ, args.steps, "timed region") if (args.all_kernel_timers or timer_alone is None) \
             else (timer_alone.summary(), 2, "2 extra steps, one HIP stream, outside the timed region")
         out["kernels"] = {k: {"launches_per_step": v["launches"] // steps_src, "avg_us": round(v["avg_us"], 2),
@@ -229,12 +313,137 @@ def main():
                               "rate_unit": "TFLOP/s" if ("gemm" in k or "attn" in k) else "TB/s"}
                           for k, v in src.items()}
         out["kernels"]["_source"] = tag
-    if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(sd_cpu, {"rna_dim": 768, "esm_layers": nl, "esm_heads": h, "rna_layers": 6,
-                                                    "rna_heads": 8}, L)
+    if want_cpu:
+        del opt, model, rna, ids
+        torch.cuda.empty_cache()
+        cb, loss0 = cpu_baseline(sd_cpu, {"rna_dim": 768, "esm_layers": nl, "esm_heads": h, "rna_layers": 6,
+                                          "rna_heads": 8}, Lp)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cb
+        if parity is not None:
+            parity["loss_oracle"] = loss0
+            parity["loss_abs_err"] = abs(parity["loss_gpu"] - loss0)
+            parity["bar"] = 1e-3
+            parity["note"] = "step-0 loss, initial weights, 32 pairs (seed 4321), full depth; oracle = CPU f32 restatement"
+            out["parity"] = parity
     print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+# ====================================================================================================== c3sim
+def bench_c3sim(args):
+    """Fused similarity + symmetric CE at one rank's share of config 3: B_l = 512 local pairs against B_g = 4096
+    gathered keys, P = 512 (f32 embeddings, exact-f32 MFMA).  A 'step' = forward (row + column LSE) + backward (dA, dB,
+    d scale) for this rank; the logits never reach HBM.  HBM-bound by the survey's accounting: algorithmic bytes per
+    launch = keys read once (B_g * P * 4) + local rows (B_l * P * 4) (+ B_l * P * 4 written by the gradient kernel)."""
+    import torch
+    import torch.nn.functional as F
+    from clip_dplm_amd import ops
+    dev = torch.device("cuda:0")
+    Bl, W, P = args.batch or 512, 8, 512
+    Bg = Bl * W
+    g = torch.Generator().manual_seed(3)
+    a = F.normalize(torch.randn(Bg, P, generator=g), dim=-1).to(dev)
+    b = F.normalize(torch.randn(Bg, P, generator=g), dim=-1).to(dev)
+    sc = torch.tensor([14.2849], device=dev)
+    al, bl = a[:Bl].contiguous(), b[:Bl].contiguous()
+
+    def step():
+        lr_, pr_ = ops.simce_lse(al, b, sc, label_offset=0)
+        lc_, pc_ = ops.simce_lse(bl, a, sc, label_offset=0)
+        lrg = lr_.repeat(W)                                   # stand-in for the all-gathered LSE vectors
+        lcg = lc_.repeat(W)
+        da, _ = ops.simce_grad(al, b, sc, lr_, lcg, 0.5, 0.5, 1.0 / Bg, label_offset=0)
+        db, _ = ops.simce_grad(bl, a, sc, lc_, lrg, 0.5, 0.5, 1.0 / Bg, label_offset=0)
+        return da, db
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
+    tl, tg = 0.0, 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ev[0][0].record(); l1 = ops.simce_lse(al, b, sc); ev[0][1].record()
+        ev[1][0].record(); l2 = ops.simce_lse(bl, a, sc); ev[1][1].record()
+        lrg, lcg = l1[0].repeat(W), l2[0].repeat(W)
+        ev[2][0].record(); ops.simce_grad(al, b, sc, l1[0], lcg, 0.5, 0.5, 1.0 / Bg); ev[2][1].record()
+        ev[3][0].record(); ops.simce_grad(bl, a, sc, l2[0], lrg, 0.5, 0.5, 1.0 / Bg); ev[3][1].record()
+        torch.cuda.synchronize()
+        tl += ev[0][0].elapsed_time(ev[0][1]) + ev[1][0].elapsed_time(ev[1][1])
+        tg += ev[2][0].elapsed_time(ev[2][1]) + ev[3][0].elapsed_time(ev[3][1])
+    dt = time.perf_counter() - t0
+    n = 2 * args.steps
+    lse_us, grad_us = 1e3 * tl / n, 1e3 * tg / n
+    bytes_lse = (Bg + Bl) * P * 4 + 2 * Bl * 4
+    bytes_grad = (Bg + Bl) * P * 4 + Bl * P * 4 + (Bl + Bg) * 4
+    flop_lse = 2.0 * Bl * Bg * P
+    out = {"metric": "seq-pairs/sec/rank, fused similarity + symmetric CE fwd+bwd at the config-3 shape",
+           "value": round(Bl * args.steps / dt, 1), "unit": "seq-pairs/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"BASELINE config 3, one rank's loss block: {Bl} local pairs x {Bg} gathered keys, P={P}, "
+                                  "simce_lse x2 + simce_grad x2 (host-synchronised per step)"},
+           "roofline": {"bound": "hbm", "kernel": "simce_kernel<LSE> (exact-f32 MFMA similarity + online LSE)",
+                        "achieved": round(bytes_lse / (lse_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(bytes_lse / (lse_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                        "avg_launch_us": round(lse_us, 2), "algorithmic_bytes_per_launch": bytes_lse,
+                        "f32_mfma_tflops": round(flop_lse / (lse_us * 1e-6) / 1e12, 1),
+                        "f32_mfma_frac_of_157": round(flop_lse / (lse_us * 1e-6) / 1e12 / 157.3, 3)},
+           "kernels": {"simce_lse": {"avg_us": round(lse_us, 2), "GBps": round(bytes_lse / (lse_us * 1e-6) / 1e9, 1)},
+                       "simce_grad": {"avg_us": round(grad_us, 2), "GBps": round(bytes_grad / (grad_us * 1e-6) / 1e9, 1),
+                                      "f32_mfma_tflops": round(2 * flop_lse / (grad_us * 1e-6) / 1e12, 1)}}}
+    print(json.dumps(out), flush=True)
+
+
+# ====================================================================================================== c5
+def bench_c5(args):
+    """ICNN transport system at its factory dims (512 / [512, 256]): eval-mode transport maps T(x) = dPsi/dx of the three
+    maps for B samples.  HBM accounting: 4 KiB per sample and map (x in, T out, f32) + 3.2 MB of weights."""
+    import torch
+    from clip_dplm_amd import icnn
+    dev = torch.device("cuda:0")
+    B = args.batch or 4096
+    torch.manual_seed(0)
+    model = icnn.create_transport_system(512, 512, 512).to(dev).eval()
+    g = torch.Generator().manual_seed(0)
+    cell, pert, prot = (torch.randn(B, 512, generator=g).to(dev) for _ in range(3))
+    for _ in range(args.warmup):
+        model(cell, pert, prot)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out_ = model(cell, pert, prot)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    per_map_bytes = B * 512 * 4 * 2 + 0.79e6 * 4
+    ach = 3 * per_map_bytes * args.steps / dt / 1e9
+    out = {"metric": "samples/sec, ICNN triple transport maps (eval)", "value": round(B * args.steps / dt, 1),
+           "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"BASELINE config 5: create_transport_system(512, 512, 512), hidden [512, 256], B={B}, "
+                                  "three eval-mode transport maps per step"},
+           "roofline": {"bound": "hbm", "kernel": "ICNN transport map (whole op: all launches of the three maps)",
+                        "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                        "algorithmic_bytes_per_step": int(3 * per_map_bytes)}}
+    print(json.dumps(out), flush=True)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if args.config not in ("c2", "c4"):
+            raise SystemExit(f"--config {args.config} is a one-GPU kernel bench")
+        sys.exit(self_launch(args))
+    if args.config in ("c2", "c4"):
+        bench_clip(args)
+    elif args.config == "c3sim":
+        bench_c3sim(args)
+    else:
+        bench_c5(args)
 
 
 if __name__ == "__main__":

@@ -44,6 +44,9 @@ SIGNATURES = {
     "clipk_version": (_i, []),
     "clipk_arch": (C.c_char_p, []),
     "clipk_status_string": (C.c_char_p, [_i]),
+    "clipk_set_option": (_i, [C.c_char_p, _i]),
+    "clipk_get_option": (_i, [C.c_char_p, C.POINTER(_i)]),
+    "clipk_reset_options": (_i, []),
     "clipk_gemm_nt": (_i, [C.POINTER(GemmArgs), _vp]),
     "clipk_gemm_wgrad_workspace": (_sz, [_i, _i, _i]),
     "clipk_gemm_wgrad": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
@@ -51,6 +54,9 @@ SIGNATURES = {
     "clipk_simce_lse": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "clipk_simce_grad": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _sz, _vp]),
     "clipk_sim_logits": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i64, _vp]),
+    "clipk_ce_logits_lse": (_i, [_vp, _i64, _i, _i, _vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
+    "clipk_ce_logits_bwd": (_i, [_vp, _i64, _i, _i, _vp, _i64, _i, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "clipk_transpose_scale_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "clipk_gemm_f32_nt": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "clipk_layernorm_fwd": (_i, [_vp, _i, _i64, _vp, _vp, _f, _i, _vp, _vp, _i64, _vp, _vp, _i, _i, _vp]),
     "clipk_layernorm_bwd_workspace": (_sz, [_i, _i]),

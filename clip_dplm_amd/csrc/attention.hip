@@ -1403,14 +1403,13 @@ void launch_fwd_whole(const AP& p, hipStream_t st) {
   hipLaunchKernelGGL((attn_fwd_whole32_kernel<D, ROT>), dim3(p.H * p.B), dim3(256), lds, st, p);
 }
 inline bool whole_fwd_applies(int L, int D) {
-  const char* fe = getenv("CLIPK_ATTN_WHOLE_FWD");          // read per call: the tests flip it
-  return !(fe && atoi(fe) == 0) && L > 128 && L <= FUSED_LMAX && (D == 16 || D == 24 || D == 32);
+  return clipk_opt_get(OPT_ATTN_WHOLE_FWD) != 0 && L > 128 && L <= FUSED_LMAX && (D == 16 || D == 24 || D == 32);
 }
 
 template <int DP, int DR, int DX>
 int launch_fwd(const AP& p, hipStream_t st) {
   if constexpr (DP == 32 && DR == 0) {
-    // short heads whose rows need no rotation: whole-head kernel (CLIPK_ATTN_WHOLE_FWD=0: the general one)
+    // short heads whose rows need no rotation: whole-head kernel (option attn_whole_fwd = 0: the general one)
     if (whole_fwd_applies(p.L, p.D)) {
       switch (p.D) {
         case 16: launch_fwd_whole<16, false>(p, st); break;
@@ -1432,33 +1431,30 @@ int launch_fwd(const AP& p, hipStream_t st) {
 template <bool ROPE, int D, int NW>
 void launch_fused_nw(const AP& p, hipStream_t st) {
   constexpr size_t lds = lds_fused(D);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_set{0};
+  clipk_once_per_device(attr_set, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused32_kernel<ROPE, D, NW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  });
   int nwg = (NW == 4 ? 2 : 1) * attn_cu_count();          // persistent: the resident workgroups walk the heads
   if (nwg > p.H * p.B) nwg = p.H * p.B;
   hipLaunchKernelGGL((attn_bwd_fused32_kernel<ROPE, D, NW>), dim3(nwg), dim3(64 * NW), lds, st, p);
 }
 template <bool ROPE, int D>
 void launch_fused(const AP& p, hipStream_t st) {
-  // 4 waves (default) or 8 (CLIPK_ATTN_FUSED_WAVES=8).  Measured, ESM-2-35M shape, warm, interleaved rounds: 435 us
+  // 4 waves (default) or 8 (option attn_fused_waves = 8).  Measured, ESM-2-35M shape, warm, interleaved rounds: 435 us
   // with 4 waves, 585 us with 8 - the gather does run under the sweep, but with ONE workgroup per CU every barrier
   // (eight per head in the sweep, six around it) stalls the whole CU and the steps are half as long.
-  const char* e = getenv("CLIPK_ATTN_FUSED_WAVES");
-  if (e && atoi(e) == 8) launch_fused_nw<ROPE, D, 8>(p, st);
+  if (clipk_opt_get(OPT_ATTN_FUSED_WAVES) == 8) launch_fused_nw<ROPE, D, 8>(p, st);
   else launch_fused_nw<ROPE, D, 4>(p, st);
 }
 
 template <int DP, int DR, int DX>
 int launch_bwd(const AP& p, hipStream_t st) {
   if constexpr (DP == 32) {
-    // whole-head kernel for the short-head encoders (ESM-2 8M / 35M / 150M at L <= 256); CLIPK_ATTN_FUSED_BWD=0
+    // whole-head kernel for the short-head encoders (ESM-2 8M / 35M / 150M at L <= 256); option attn_fused_bwd = 0
     // keeps the two-kernel path (tests compare the two)
-    const char* fe = getenv("CLIPK_ATTN_FUSED_BWD");       // read per call: the tests flip it
-    const bool fused_on = !(fe && atoi(fe) == 0);
+    const bool fused_on = clipk_opt_get(OPT_ATTN_FUSED_BWD) != 0;
     // q / k must arrive rotated (clipk_rope_qk) or unrotated-by-design: the chunk-per-lane staging cannot rotate
     if (fused_on && p.L > 128 && p.L <= FUSED_LMAX && p.D >= 16 && (DR == 0 || p.pre_rot)) {
       switch (p.D) {

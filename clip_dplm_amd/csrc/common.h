@@ -5,8 +5,28 @@
 #include <stdint.h>
 #include "../../include/clipk.h"
 
-#define CLIPK_ABI_VERSION 1
+#define CLIPK_ABI_VERSION 2
 #define WAVE 64
+
+// Kernel-selection options (core.hip): set explicitly through clipk_set_option(), never read from the environment.
+// Every value of every option computes the same results; they choose between kernels / schedules that tests and
+// tools/ want to compare.  Result-changing ablation switches exist only in builds with -DCLIPK_EXPERIMENTS.
+enum clipk_opt {
+  OPT_GEMM_KERNEL = 0,     // -1 auto, 1 generic kernel (gemm_nt.hip), 2 128x128 (v2), 3 persistent 256x256 (v3)
+  OPT_GEMM_EPI_GENERIC,    // 1: run-time epilogue instead of the specialised modes
+  OPT_GEMM_BM,             // v2: 256 = 256-row tile variant
+  OPT_GEMM_STAGES,         // v2: 2 = two-stage LDS pipeline
+  OPT_GEMM_NWG,            // v3: persistent grid size (multiple of 8), 0 = one workgroup per CU
+  OPT_GEMM_STAGGER,        // start-up stagger of workgroups (0 = off)
+  OPT_EPI_NT,              // 1: non-temporal epilogue stores
+  OPT_WGRAD_KERNEL,        // -1 auto, 2 128x128 kernel, 3 256x256 phase-interleaved kernel
+  OPT_ATTN_WHOLE_FWD,      // -1 auto, 0 off, 1 on: whole-head forward for short heads
+  OPT_ATTN_FUSED_BWD,      // -1 auto, 0 off, 1 on: whole-head backward for short heads
+  OPT_ATTN_FUSED_WAVES,    // 4 (default) or 8 waves per workgroup in the whole-head backward
+  OPT_GEMM_ABL,            // CLIPK_EXPERIMENTS builds only: timing ablations that change results
+  OPT_COUNT
+};
+int clipk_opt_get(int which);      // core.hip
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;     // 8 bf16 = one MFMA A/B fragment (4 VGPRs)
 typedef __attribute__((ext_vector_type(4))) short bf16x4;     // 4 bf16 = one ds_read_b64_tr_b16 result
@@ -126,5 +146,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 static inline int clipk_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? CLIPK_OK : CLIPK_ERR_LAUNCH;
+}
+// hipFuncSetAttribute is a per-device setting: remember which devices have it (idempotent work, so a race between two
+// host threads at most repeats it).
+#include <atomic>
+template <typename F>
+static inline void clipk_once_per_device(std::atomic<uint64_t>& mask, F&& f) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(mask.load(std::memory_order_acquire) & bit)) {
+    f();
+    mask.fetch_or(bit, std::memory_order_release);
+  }
 }
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }

@@ -535,10 +535,12 @@ extern "C" int clipk_adamw_step(float* w, const float* g, float* m, float* v, vo
                                 float beta1, float beta2, float eps, float weight_decay, int step,
                                 const float* grad_norm_sq, float max_norm, float grad_scale, void* stream) {
   if (!w || !g || !m || !v || n <= 0 || step < 1) return CLIPK_ERR_BAD_ARG;
-  const float bc1 = 1.0f - powf(beta1, (float)step);
-  const float bc2 = 1.0f - powf(beta2, (float)step);
+  // bias corrections in double on the host, as torch.optim.AdamW computes them (f32 powf is ~6e-5 off in 1 - beta2^t
+  // at small t)
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   hipLaunchKernelGGL(adamw_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, w, g, m, v,
-                     (unsigned short*)w_bf16, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2),
+                     (unsigned short*)w_bf16, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s,
                      grad_norm_sq, max_norm, grad_scale);
   return clipk_check_launch();
 }

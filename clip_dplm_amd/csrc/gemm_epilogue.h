@@ -268,10 +268,10 @@ static inline EpiArgs epi_args_from(const clipk_gemm_args* a) {
   e.dact_aux = (const unsigned short*)a->dact_aux; e.ldd = a->ldd; e.dact = a->dact;
   e.residual = a->residual; e.ldr = a->ldr; e.r_f32 = (a->r_dtype == CLIPK_F32);
   e.alpha = a->alpha;
-  // Streaming (non-temporal) output stores, CLIPK_EPI_NT=1.  In the kernel microbenchmark they are worth 7 % on the
+  // Streaming (non-temporal) output stores, option epi_nt = 1.  In the kernel microbenchmark they are worth 7 % on the
   // hot shapes (the output stream stops evicting operand panels from L2: esm qkv 256 -> 192 us; f32 residual outputs
   // get slower), in the training step nothing (96.8 vs 96.6 ms): there the consumer of the output runs next and finds
   // less of it in the Infinity Cache.  Off by default.
-  { const char* nt = getenv("CLIPK_EPI_NT"); e.nt = nt ? atoi(nt) : 0; }
+  e.nt = clipk_opt_get(OPT_EPI_NT);
   return e;
 }

@@ -18,7 +18,6 @@
 
 extern "C" int clipk_gemm_nt_v2_launch(const clipk_gemm_args* a, void* stream);
 extern "C" int clipk_gemm_nt_v3_launch(const clipk_gemm_args* a, void* stream);
-extern "C" int clipk_gemm_nt_v4_launch(const clipk_gemm_args* a, void* stream);
 
 namespace {
 
@@ -226,17 +225,13 @@ extern "C" int clipk_gemm_nt(const clipk_gemm_args* a, void* stream) {
   // fast paths, both LDS-DMA staged and needing whole 32-deep K steps:
   //   gemm_nt_v3.hip  persistent 256 x 256 tiles, phase-interleaved: problems with at least ~3/4 of a tile per CU
   //   gemm_nt_v2.hip  128 x 128 tiles, 4 workgroups per CU: everything else
-  // CLIPK_GEMM_V3 = 0 / 1 forces the choice (tools/bench_kernels.py, tests), CLIPK_GEMM_V1 the generic kernel.
-  const bool force_v1 = getenv("CLIPK_GEMM_V1") != nullptr;
-  const char* v3 = getenv("CLIPK_GEMM_V3");
-  const int v3mode = v3 ? atoi(v3) : -1;
+  // option gemm_kernel = 2 / 3 forces the choice (tools/bench_kernels.py, tests), 1 the generic kernel.
+  const int kmode = clipk_opt_get(OPT_GEMM_KERNEL);
+  const bool force_v1 = kmode == 1;
+  const int v3mode = kmode == 3 ? 1 : kmode == 2 ? 0 : -1;
   const long tiles256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
   const bool v3_ok = (a->K & 31) == 0 && a->K >= 160 && (long)a->M * a->lda * 2 < (1L << 32) &&
                      (long)a->N * a->ldb * 2 < (1L << 32);     // 32-bit buffer offsets
-  const char* v4 = getenv("CLIPK_GEMM_V4");                 // experimental 256 x 128, two workgroups per CU
-  if (!force_v1 && v4 && atoi(v4) == 1 && (a->K & 31) == 0 && a->K >= 96 && a->M >= 1024 &&
-      (long)a->M * a->lda * 2 < (1L << 32) && (long)a->N * a->ldb * 2 < (1L << 32))
-    return clipk_gemm_nt_v4_launch(a, stream);
   if (!force_v1 && v3_ok && ((v3mode == 1 && a->M >= 2048) || (v3mode < 0 && tiles256 >= 192)))
     return clipk_gemm_nt_v3_launch(a, stream);
   if (!force_v1 && (a->K & 31) == 0) return clipk_gemm_nt_v2_launch(a, stream);
@@ -252,12 +247,11 @@ extern "C" int clipk_gemm_nt(const clipk_gemm_args* a, void* stream) {
   p.alpha = a->alpha;
   const int ntm = (a->M + BM - 1) / BM, ntn = (a->N + BN - 1) / BN;
   p.ntn = ntn;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_set{0};
+  clipk_once_per_device(attr_set, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel),
                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_set = true;
-  }
+  });
   hipLaunchKernelGGL(gemm_nt_kernel, dim3(ntm * ntn), dim3(NTHREADS), LDS_BYTES, (hipStream_t)stream, p);
   return clipk_check_launch();
 }

@@ -170,19 +170,15 @@ extern "C" int clipk_gemm_nt_v2_launch(const clipk_gemm_args* a, void* stream) {
   p.e = epi_args_from(a);
   const int ntn = (a->N + BN - 1) / BN;
   p.ntn = ntn;
-  { const char* sg = getenv("CLIPK_GEMM_STAGGER"); p.stagger = sg ? atoi(sg) : 0; }
-  const char* force = getenv("CLIPK_GEMM_BM");             // A/B switch for tools/bench_kernels.py
-  const bool big = force ? (atoi(force) == 256) : false;
-  const char* fs = getenv("CLIPK_GEMM_STAGES");
-  const int stages = fs ? atoi(fs) : 1;
-  const char* ge = getenv("CLIPK_GEMM_EPI_GENERIC");       // A/B switch: force the run-time epilogue
-  const int mode = (ge && atoi(ge) == 1) ? EPI_GENERIC : epi_mode_for(a);
-  static bool attr_set = false;
-  if (!attr_set) {
+  p.stagger = clipk_opt_get(OPT_GEMM_STAGGER);
+  const bool big = clipk_opt_get(OPT_GEMM_BM) == 256;      // A/B switches for tools/bench_kernels.py
+  const int stages = clipk_opt_get(OPT_GEMM_STAGES);
+  const int mode = clipk_opt_get(OPT_GEMM_EPI_GENERIC) == 1 ? EPI_GENERIC : epi_mode_for(a);
+  static std::atomic<uint64_t> attr_set{0};
+  clipk_once_per_device(attr_set, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_v2_kernel<256, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 * BK * 2 + B_TILE_BYTES));
-    attr_set = true;
-  }
+  });
   hipStream_t st = (hipStream_t)stream;
   if (big) {
     const int ntm = (a->M + 255) / 256;

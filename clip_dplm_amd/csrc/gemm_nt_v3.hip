@@ -1,5 +1,5 @@
 // gemm_nt_v3.hip — persistent 256 x 256-tile, 8-wave, phase-interleaved kernel for clipk_gemm_nt
-// (K % 32 == 0, K >= 192).  Same contract and epilogue as gemm_nt_v2.hip; selected by CLIPK_GEMM_V3 (gemm_nt.hip).
+// (K % 32 == 0, K >= 192).  Same contract and epilogue as gemm_nt_v2.hip; selected by gemm_nt.hip (option gemm_kernel).
 //
 // Why a second structure: the 128 x 128 kernel tops out where the CU's L2 -> LDS path saturates.
 // A 256 x 256 tile halves the operand bytes per FLOP, but only pays with ~1 workgroup per CU if the loads stay in
@@ -264,6 +264,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v3_kernel(const Params p) {
     }
     // ---- epilogue (gemm_epilogue.h): issues its stores and moves on; they drain under the next main loop
     float* eb = reinterpret_cast<float*>(smem + 2 * BUF_BYTES) + wid * (SLAB_BYTES / 4);
+#ifdef CLIPK_EXPERIMENTS
     if (p.abl & 1) {
       float sacc = bv[0];
 #pragma unroll
@@ -272,21 +273,26 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v3_kernel(const Params p) {
         for (int j = 0; j < 8; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
       if (sacc == 1.2345e-30f) reinterpret_cast<float*>(p.e.C)[0] = sacc;
     } else
+#endif
     gemm_epilogue<MODE, 8, true>(p.e, acc, eb, lane_e, cm0 + wm * 128, gn_e, bv);
     if (!more) break;
-    if (MODE == EPI_GENERIC || (p.abl & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // store count unknown: drain
-    first = (MODE == EPI_GENERIC) || (p.abl & 1);
+#ifdef CLIPK_EXPERIMENTS
+    const bool drain = MODE == EPI_GENERIC || (p.abl & 1);
+#else
+    constexpr bool drain = MODE == EPI_GENERIC;
+#endif
+    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // store count unknown: drain
+    first = drain;
   }
 }
 
 template <int MODE>
 void launch_v3(const Params& p, dim3 grid, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_set{0};
+  clipk_once_per_device(attr_set, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_v3_kernel<MODE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_set = true;
-  }
+  });
   hipLaunchKernelGGL((gemm_nt_v3_kernel<MODE>), grid, dim3(512), LDS_BYTES, st, p);
 }
 
@@ -316,15 +322,18 @@ extern "C" int clipk_gemm_nt_v3_launch(const clipk_gemm_args* a, void* stream) {
   // one persistent workgroup per CU; a multiple of 8 keeps "workgroup b runs on XCD b % 8" true for every tile
   // it walks, so the XCD-contiguous tile order (xcd_remap) still holds
   int nwg = cu_count() & ~7;
-  { const char* e = getenv("CLIPK_GEMM_NWG"); if (e && atoi(e) >= 8) nwg = atoi(e) & ~7; }   // experiments only
+  { const int e = clipk_opt_get(OPT_GEMM_NWG); if (e >= 8) nwg = e & ~7; }                   // experiments only
   if (nwg > p.ntiles) nwg = p.ntiles;
   const dim3 grid(nwg);
-  { const char* e = getenv("CLIPK_GEMM_ABL"); p.abl = e ? atoi(e) : 0; }
-  { const char* e = getenv("CLIPK_GEMM_STAGGER"); p.stagger = e ? atoi(e) : 0; }
+#ifdef CLIPK_EXPERIMENTS
+  p.abl = clipk_opt_get(OPT_GEMM_ABL);                      // timing-only ablations: experiment builds only
   if (p.abl & 4) p.e.N = 0;                                 // every store out of range: same instructions, no traffic
+#else
+  p.abl = 0;
+#endif
+  p.stagger = clipk_opt_get(OPT_GEMM_STAGGER);
   hipStream_t st = (hipStream_t)stream;
-  const char* ge = getenv("CLIPK_GEMM_EPI_GENERIC");
-  const int mode = (ge && atoi(ge) == 1) ? EPI_GENERIC : epi_mode_for(a);
+  const int mode = clipk_opt_get(OPT_GEMM_EPI_GENERIC) == 1 ? EPI_GENERIC : epi_mode_for(a);
   if (mode == EPI_PLAIN) launch_v3<EPI_PLAIN>(p, grid, st);
   else if (mode == EPI_RES32) launch_v3<EPI_RES32>(p, grid, st);
   else if (mode == EPI_GELU_PRE) launch_v3<EPI_GELU_PRE>(p, grid, st);

@@ -235,12 +235,11 @@ Plan make_plan(int M, int N, int K) {
   return pl;
 }
 
-// large problems go to the 256 x 256 phase-interleaved kernel; CLIPK_WGRAD_V3 = 0 / 1 forces the choice
+// large problems go to the 256 x 256 phase-interleaved kernel; option wgrad_kernel = 2 / 3 forces the choice
 bool use_v3(int M, int N, int K) {
-  const char* e = getenv("CLIPK_WGRAD_V3");
-  const int mode = e ? atoi(e) : -1;
-  if (mode == 0) return false;
-  if (mode == 1) return M >= 1024;
+  const int mode = clipk_opt_get(OPT_WGRAD_KERNEL);
+  if (mode == 2) return false;
+  if (mode == 3) return M >= 1024;
   return M >= 16384 && N >= 128 && K >= 128;
 }
 

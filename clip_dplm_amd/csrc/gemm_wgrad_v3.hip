@@ -302,12 +302,11 @@ extern "C" void clipk_wgrad_v3_plan(int M, int N, int K, int* ntn, int* ntk, int
 }
 
 extern "C" int clipk_wgrad_v3_launch(const clipk_wgrad_v3_args* a, void* stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_set{0};
+  clipk_once_per_device(attr_set, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_v3_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_set = true;
-  }
+  });
   hipLaunchKernelGGL(wgrad_v3_kernel, dim3(a->ntn * a->ntk * a->splits), dim3(512), LDS_BYTES, (hipStream_t)stream, *a);
   return clipk_check_launch();
 }

@@ -121,10 +121,10 @@ class _Lin:
     """Kernel-side view of one Linear: f32 master params + cached bf16 W / W^T.  gw / gb: explicit gradient buffers
     (fused views of several parameters' .grad), used instead of w.grad / b.grad by the direct-accumulation path."""
 
-    def __init__(self, w, b, cache: KF.WeightCache, gw=None, gb=None):
+    def __init__(self, w, b, cache: KF.WeightCache, gw=None, gb=None, version_fn=None):
         self.w, self.b = w, b
         self.gw, self.gb = gw, gb
-        self.wb, self.wtb = cache.get(w)
+        self.wb, self.wtb = cache.get(w, version_fn)
 
 
 # =================================================================================================
@@ -196,7 +196,9 @@ class EsmStackFn(torch.autograd.Function):
             t = flat[3 + 12 * i: 3 + 12 * (i + 1)]
             caches = module.layer_caches[i]
             gw, gb = module._qkv_grads[i] if len(getattr(module, "_qkv_grads", ())) == nl else (None, None)
-            p = {"ln1_w": t[0], "ln1_b": t[1], "qkv": _Lin(t[2], t[3], caches[0], gw, gb), "out": _Lin(t[4], t[5], caches[1]),
+            # the fused qkv view's own _version never moves: its bf16 copy is keyed on the three source Parameters
+            p = {"ln1_w": t[0], "ln1_b": t[1], "qkv": _Lin(t[2], t[3], caches[0], gw, gb, module.qkv_version_fn(i)),
+                 "out": _Lin(t[4], t[5], caches[1]),
                  "ln2_w": t[6], "ln2_b": t[7], "fc1": _Lin(t[8], t[9], caches[2]), "fc2": _Lin(t[10], t[11], caches[3])}
             x, s = _esm_layer_fwd(x, p, meta)
             layers.append(p)
@@ -324,6 +326,10 @@ class ESM2Encoder(nn.Module):
         if key not in self._rope:
             self._rope[key] = _rope_tables(L, self.hidden_size // self.num_heads, device)
         return self._rope[key]
+
+    def qkv_version_fn(self, i):
+        s = self.encoder.layer[i].attention.self
+        return lambda: s.query.weight._version + s.key.weight._version + s.value.weight._version
 
     def flat_param_groups(self):
         """Parameters FusedAdamW's flat buffer should store back to back: q/k/v weights, q/k/v biases per layer."""
@@ -491,9 +497,13 @@ class TransformerSeqEncoder(nn.Module):
     """
 
     def __init__(self, embed_dim=768, num_layers=6, nhead=8, dim_feedforward=2048, activation="gelu",
-                 layer_norm_eps=1e-12, final_eps=None):
+                 layer_norm_eps=1e-12, final_eps=None, dropout: float = 0.0):
         super().__init__()
         self.embed_dim, self.num_layers, self.nhead = embed_dim, num_layers, nhead
+        # nn.TransformerEncoderLayer's dropout (attention probabilities, both residual branches, FFN activation;
+        # rna_clip_codes.ipynb:1915 uses 0.1).  The kernel stack has no dropout: training with p > 0 raises instead of
+        # silently training unregularised; eval mode (and p = 0, the parity / benchmark setting) is exact.
+        self.dropout = float(dropout)
         self.activation, self.eps = activation, layer_norm_eps
         self.final_eps = layer_norm_eps if final_eps is None else final_eps
         self.layers = nn.ModuleList([_PostLayerParams(embed_dim, dim_feedforward, layer_norm_eps)
@@ -528,6 +538,12 @@ class TransformerSeqEncoder(nn.Module):
 
     def forward(self, x, src_key_padding_mask=None):
         B, L, E = x.shape
+        if self.training and self.dropout > 0.0 and torch.is_grad_enabled():
+            raise NotImplementedError(
+                f"TransformerSeqEncoder: training-mode dropout p={self.dropout} is not implemented in the HIP layer "
+                "stack (INTEGRATION.md §dropout).  Set `encoder.dropout = 0.0` (or construct with dropout=0.0) to train "
+                "without it, or call .eval(); the reference's nn.TransformerEncoderLayer(dropout=0.1) would drop "
+                "attention probabilities, both residual branches and the FFN activation here.")
         mask_u8 = None
         if src_key_padding_mask is not None:
             mask_u8 = (~src_key_padding_mask.bool()).to(torch.uint8).contiguous()      # kernels take 1 = valid

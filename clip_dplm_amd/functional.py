@@ -22,19 +22,28 @@ def mark_weights_dirty() -> None:
     _WEIGHT_EPOCH += 1
 
 
+def _cache_key(w: torch.Tensor, version=None):
+    """Identity + version of a master weight.  For a fused zero-copy view of several Parameters (ESM's qkv:
+    torch.as_strided of the flat buffer, whose own _version never moves) the caller passes the sum of the source
+    Parameters' versions, so load_state_dict / re-initialisation / another optimiser invalidate the copy too."""
+    return (w.data_ptr(), w._version if version is None else ("src", version), _WEIGHT_EPOCH, tuple(w.shape))
+
+
 class WeightCache:
     """bf16 W [N,K] and W^T [K,N] of an f32 master weight, refreshed lazily (or all at once, refresh_weight_caches)."""
 
-    __slots__ = ("wb", "wtb", "key", "src", "__weakref__")
+    __slots__ = ("wb", "wtb", "key", "src", "src_version", "__weakref__")
 
     def __init__(self):
         self.wb = self.wtb = None
         self.key = None
         self.src = None                      # the master weight this cache was last built from
+        self.src_version = None              # callable -> version token of a fused view's source Parameters (or None)
         _CACHES.add(self)
 
-    def get(self, w: torch.Tensor):
-        key = (w.data_ptr(), w._version, _WEIGHT_EPOCH, tuple(w.shape))
+    def get(self, w: torch.Tensor, version_fn=None):
+        self.src_version = version_fn
+        key = _cache_key(w, None if version_fn is None else version_fn())
         if key != self.key:
             src = w.detach()
             if not src.is_contiguous():
@@ -61,7 +70,7 @@ def refresh_weight_caches() -> int:
             continue
         if w.dim() != 2 or c.wb.shape != w.shape:
             continue
-        key = (w.data_ptr(), w._version, _WEIGHT_EPOCH, tuple(w.shape))
+        key = _cache_key(w, None if c.src_version is None else c.src_version())
         if key != c.key:
             todo.append((c, w, key))
     if not todo:
@@ -207,22 +216,70 @@ class SkipScaleFn(torch.autograd.Function):
 
 class SimLogitsFn(torch.autograd.Function):
     """logits = scale * A B^T, materialised for the reference's module API (old/clip.py:66-67).
-    Forward is the exact-f32 MFMA kernel.  The backward of this cold, API-compatibility path uses
-    torch.matmul (rocBLAS): training should call clip_loss(), which never materialises the logits."""
+    Forward and backward are exact-f32 MFMA products (clipk_sim_logits / clipk_gemm_f32_nt on transposed operands
+    prepared by clipk_transpose_scale_f32): dA = scale * dS B, dB = scale * dS^T A, dscale = <dA, A> / scale."""
 
     @staticmethod
     def forward(ctx, a, b, scale):
         a, b = a.contiguous(), b.contiguous()
-        ctx.save_for_backward(a, b, scale)
-        return ops.sim_logits(a, b, scale.reshape(1))
+        sc = scale.reshape(1).contiguous()
+        ctx.save_for_backward(a, b, sc)
+        ctx.scale_shape = scale.shape
+        return ops.sim_logits(a, b, sc)
 
     @staticmethod
     def backward(ctx, ds):
-        a, b, scale = ctx.saved_tensors
-        da = (ds @ b) * scale
-        db = (ds.t() @ a) * scale
-        dscale = (ds * (a @ b.t())).sum().reshape(scale.shape)
+        a, b, sc = ctx.saved_tensors
+        ds = ds.contiguous()
+        da = db = dscale = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+            da = ops.matmul_f32_nt(ds, ops.transpose_scale_f32(b, sc))             # scale * dS @ B       [M, P]
+        if ctx.needs_input_grad[1]:
+            db = ops.matmul_f32_nt(ops.transpose_scale_f32(ds), ops.transpose_scale_f32(a, sc))   # scale dS^T A
+        if ctx.needs_input_grad[2]:
+            dscale = ((da * a).sum() / sc[0]).reshape(ctx.scale_shape)             # sum dS o (A B^T): scalar plumbing
         return da, db, dscale
+
+
+class CEDiagFn(torch.autograd.Function):
+    """w_row * CE(rows of [S | S_cache], diag) + w_col * CE(columns of S, diag) on MATERIALISED logits — the loss calls
+    of old/ablation.py:16 (1, 0), rna_clip_codes.ipynb:1952-1953 (.5, .5) and old/clip_opt.py:130-151 (.5, .5 + cache)
+    on the clipk_ce_logits kernels."""
+
+    @staticmethod
+    def forward(ctx, S, S2, w_row, w_col):
+        S = S if S.stride(-1) == 1 else S.contiguous()
+        if S2 is not None and (S2.shape[1] == 0):
+            S2 = None
+        if S2 is not None and S2.stride(-1) != 1:
+            S2 = S2.contiguous()
+        M, N = S.shape
+        lse_r, pos_r = ops.ce_logits_lse(S, S2, columns=False)
+        loss = w_row * (lse_r - pos_r).sum() / M
+        lse_c = None
+        if w_col != 0.0:
+            lse_c, pos_c = ops.ce_logits_lse(S, None, columns=True)
+            loss = loss + w_col * (lse_c - pos_c).sum() / N
+        ctx.meta = (w_row / M, w_col / N)
+        ctx.has_s2 = S2 is not None
+        ctx.save_for_backward(S, S2, lse_r, lse_c)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        S, S2, lse_r, lse_c = ctx.saved_tensors
+        wr, wc = ctx.meta
+        dS, dS2 = ops.ce_logits_bwd(S, S2, lse_r, lse_c, wr, wc, g.reshape(1).contiguous().float())
+        return dS, dS2, None, None
+
+
+def cross_entropy_diag(logits, cache_logits=None, symmetric=True):
+    """F.cross_entropy(logits, arange) [+ the column direction] on the HIP kernels, for callers of the module API that
+    hold materialised logits (square `logits`; `cache_logits` = extra negative columns of the row direction)."""
+    if logits.shape[0] != logits.shape[1]:
+        raise ValueError("cross_entropy_diag expects square logits [B, B]")
+    w = (0.5, 0.5) if symmetric else (1.0, 0.0)
+    return CEDiagFn.apply(logits.float(), None if cache_logits is None else cache_logits.float(), *w)
 
 
 def sim_logits(a, b, scale):

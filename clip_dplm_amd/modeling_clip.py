@@ -265,10 +265,9 @@ class OptimizedCLIPModule(nn.Module):
 
 
 def optimized_clip_loss(outputs, temperature=0.07):
-    """old/clip_opt.py:130-151 on materialised logits (API compatibility; plain torch reductions).
+    """old/clip_opt.py:130-151 on the materialised logits the module returns (API compatibility), computed by the
+    clipk_ce_logits kernels (row LSE over [S | S_cache], column LSE over S, fused backward) — no ATen softmax.
     `temperature` is accepted and unused, exactly like the reference; the label-smoothing tensor the reference
     builds and discards is not built (App. A-6)."""
-    sim_d_p = outputs["logits_per_diffmap_protein"]
-    combined = torch.cat([sim_d_p, outputs["logits_per_diffmap_cache"]], dim=1)
-    labels = torch.arange(sim_d_p.size(0), device=sim_d_p.device)
-    return (F.cross_entropy(combined, labels) + F.cross_entropy(sim_d_p.t(), labels)) / 2
+    return KF.cross_entropy_diag(outputs["logits_per_diffmap_protein"], outputs["logits_per_diffmap_cache"],
+                                 symmetric=True)

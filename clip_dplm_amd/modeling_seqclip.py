@@ -36,18 +36,20 @@ class RNARBPCLIPProjectionHead(OptimizedProjectionHead):
 class RNARBPCLIPEncoder(TransformerSeqEncoder):
     """rna_clip_codes.ipynb:1911-1923: 3 x nn.TransformerEncoderLayer(d, nhead=8, ffn=4d) + LayerNorm."""
 
-    def __init__(self, embed_dim, num_layers=3):
+    def __init__(self, embed_dim, num_layers=3, dropout: float = 0.1):
         super().__init__(embed_dim=embed_dim, num_layers=num_layers, nhead=8, dim_feedforward=embed_dim * 4,
-                         activation="relu", layer_norm_eps=1e-5, final_eps=1e-5)
+                         activation="relu", layer_norm_eps=1e-5, final_eps=1e-5, dropout=dropout)
 
 
 class RNARBPCLIPModel(nn.Module):
     """rna_clip_codes.ipynb:1925-1954."""
 
-    def __init__(self, rna_dim=120, rbp_dim=1280, projection_dim=512):
+    def __init__(self, rna_dim=120, rbp_dim=1280, projection_dim=512, dropout: float = 0.1):
         super().__init__()
-        self.rna_encoder = RNARBPCLIPEncoder(rna_dim)
-        self.rbp_encoder = RNARBPCLIPEncoder(rbp_dim)
+        # `dropout` is the notebook's nn.TransformerEncoderLayer default (0.1); the encoder stacks raise in training
+        # mode while it is > 0 (see TransformerSeqEncoder): pass dropout=0.0 to train on the HIP path.
+        self.rna_encoder = RNARBPCLIPEncoder(rna_dim, dropout=dropout)
+        self.rbp_encoder = RNARBPCLIPEncoder(rbp_dim, dropout=dropout)
         self.rna_projection = RNARBPCLIPProjectionHead(rna_dim, projection_dim)
         self.rbp_projection = RNARBPCLIPProjectionHead(rbp_dim, projection_dim)
         self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))

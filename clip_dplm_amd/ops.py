@@ -61,6 +61,21 @@ def _lib():
     return _ffi.load()
 
 
+def set_option(name: str, value: int) -> None:
+    """Kernel-selection option of libclipk (include/clipk.h: clipk_set_option).  Results never depend on options."""
+    check(_lib().clipk_set_option(name.encode(), int(value)), f"clipk_set_option({name})")
+
+
+def get_option(name: str) -> int:
+    v = C.c_int(0)
+    check(_lib().clipk_get_option(name.encode(), C.byref(v)), f"clipk_get_option({name})")
+    return v.value
+
+
+def reset_options() -> None:
+    check(_lib().clipk_reset_options(), "clipk_reset_options")
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -188,6 +203,65 @@ def sim_logits(x, y, scale):
     check(_lib().clipk_sim_logits(x.data_ptr(), Mx, y.data_ptr(), Ny, P, scale.data_ptr(), s.data_ptr(), s.stride(0),
                                   _stream()), "clipk_sim_logits")
     return s
+
+
+def ce_logits_lse(S, S2=None, columns=False, label_offset=0):
+    """LSE over the rows (optionally of [S | S2]) or the columns of materialised f32 logits + the diagonal logit."""
+    _need_cuda(S, S2)
+    assert S.dtype == torch.float32 and S.dim() == 2 and S.stride(1) == 1
+    M, N = S.shape
+    N2 = 0 if S2 is None else S2.shape[1]
+    if N2:
+        assert S2.dtype == torch.float32 and S2.stride(1) == 1 and S2.shape[0] == M
+    n = N if columns else M
+    lse = torch.empty(n, dtype=torch.float32, device=S.device)
+    pos = torch.empty(n, dtype=torch.float32, device=S.device)
+    check(_lib().clipk_ce_logits_lse(S.data_ptr(), S.stride(0), M, N, ptr(S2) if N2 else None, S2.stride(0) if N2 else 0,
+                                     N2, int(bool(columns)), label_offset, lse.data_ptr(), pos.data_ptr(), _stream()),
+          "clipk_ce_logits_lse")
+    return lse, pos
+
+
+def ce_logits_bwd(S, S2, lse_row, lse_col, w_row, w_col, g, off_row=0, off_col=0):
+    _need_cuda(S, S2, lse_row, lse_col, g)
+    M, N = S.shape
+    N2 = 0 if S2 is None else S2.shape[1]
+    dS = torch.empty((M, N), dtype=torch.float32, device=S.device)
+    dS2 = torch.empty((M, N2), dtype=torch.float32, device=S.device) if N2 else None
+    check(_lib().clipk_ce_logits_bwd(S.data_ptr(), S.stride(0), M, N, ptr(S2) if N2 else None, S2.stride(0) if N2 else 0,
+                                     N2, ptr(lse_row), ptr(lse_col), float(w_row), float(w_col), off_row, off_col,
+                                     g.data_ptr(), dS.data_ptr(), dS.stride(0), ptr(dS2), dS2.stride(0) if N2 else 0,
+                                     _stream()), "clipk_ce_logits_bwd")
+    return dS, dS2
+
+
+def transpose_scale_f32(x, scale=None):
+    """scale[0] * x^T for a contiguous f32 [R, C] matrix (scale: device scalar tensor or None)."""
+    _need_cuda(x, scale)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
+    R, Cc = x.shape
+    out = torch.empty((Cc, R), dtype=torch.float32, device=x.device)
+    check(_lib().clipk_transpose_scale_f32(x.data_ptr(), R, Cc, ptr(scale), out.data_ptr(), _stream()),
+          "clipk_transpose_scale_f32")
+    return out
+
+
+F32_KMAX = 512       # clipk_gemm_f32_nt keeps one operand row block in LDS: contraction <= 768, a multiple of 4
+
+
+def matmul_f32_nt(a, b):
+    """a[M, K] @ b[N, K]^T in exact f32 for any K: contraction chunks of F32_KMAX chained through the addend."""
+    K = a.shape[1]
+    if K <= F32_KMAX and K % 4 == 0 and a.is_contiguous() and b.is_contiguous():
+        return gemm_f32_nt(a, b)
+    out = None
+    for k0 in range(0, K, F32_KMAX):
+        ak, bk = a[:, k0:k0 + F32_KMAX], b[:, k0:k0 + F32_KMAX]
+        if ak.shape[1] % 4:
+            pad = 4 - ak.shape[1] % 4
+            ak, bk = torch.nn.functional.pad(ak, (0, pad)), torch.nn.functional.pad(bk, (0, pad))
+        out = gemm_f32_nt(ak.contiguous(), bk.contiguous(), addend=out)
+    return out
 
 
 def gemm_f32_nt(x, w, bias=None, addend=None, addend_scale=None):

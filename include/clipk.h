@@ -41,6 +41,16 @@ int clipk_version(void);          /* ABI version, bumped on any signature change
 const char* clipk_arch(void);     /* "gfx950" */
 const char* clipk_status_string(int status);
 
+/* Kernel-selection options (process-wide, explicit; the library never reads environment variables).  Every value
+ * of every option computes the same results: they pick between kernels / schedules that tests and tools/ compare.
+ * Names: gemm_kernel (-1 auto, 1 generic, 2 128x128, 3 persistent 256x256), gemm_epi_generic, gemm_bm, gemm_stages,
+ * gemm_nwg, gemm_stagger, epi_nt, wgrad_kernel (-1 auto, 2, 3), attn_whole_fwd, attn_fused_bwd (-1 auto, 0, 1),
+ * attn_fused_waves (4, 8).  Unknown name -> CLIPK_ERR_BAD_ARG.  (The reference has no counterpart: its kernels are
+ * ATen's.) */
+int clipk_set_option(const char* name, int value);
+int clipk_get_option(const char* name, int* value);
+int clipk_reset_options(void);
+
 /* ------------------------------------------------------------------------------------------------
  * Linear (GEMM + fused epilogue), bf16 MFMA, f32 accumulate.
  *   C[M,N] = epilogue( A[M,K] · B[N,K]^T )
@@ -115,6 +125,28 @@ int clipk_simce_grad(const float* X, int Mx, const float* Y, int Ny, const float
  *   S[Mx,Ny] = scale * X·Y^T, exact f32. */
 int clipk_sim_logits(const float* X, int Mx, const float* Y, int Ny, int P, const float* scale,
                      float* S, int64_t lds, void* stream);
+
+/* Cross-entropy on MATERIALISED logits — the reference's loss call sites take the logits tensor its modules return:
+ * F.cross_entropy(logits, arange(B)) at old/ablation.py:16 / run1/full.py:133, the symmetric pair at
+ * current/rna_clip_codes.ipynb:1952-1953, and (F.cross_entropy(cat([S, S_cache], 1)) + F.cross_entropy(S^T)) / 2
+ * at old/clip_opt.py:130-151.  (Training should use clipk_simce_*: there the logits never reach HBM.)
+ *   lse:  columns == 0: lse[i] = logsumexp_j [S | S2][i, j], pos[i] = S[i, i + label_offset]          (i < M)
+ *         columns == 1: lse[j] = logsumexp_i S[i, j],        pos[j] = S[j + label_offset, j]          (j < N; N2 == 0)
+ *   bwd:  dS[i,j]  = g * ( w_row (exp(S_ij - lse_row[i]) - [j == i + off_row])
+ *                        + w_col (exp(S_ij - lse_col[j]) - [i == j + off_col]) ),
+ *         dS2[i,j] = g * w_row exp(S2_ij - lse_row[i]);   lse_row / lse_col may be NULL (direction unused);
+ *         w_row / w_col carry the 1 / batch factors; g = device scalar (upstream gradient). */
+int clipk_ce_logits_lse(const float* S, int64_t ld, int M, int N, const float* S2, int64_t ld2, int N2,
+                        int columns, int label_offset, float* lse, float* pos, void* stream);
+int clipk_ce_logits_bwd(const float* S, int64_t ld, int M, int N, const float* S2, int64_t ld2, int N2,
+                        const float* lse_row, const float* lse_col, float w_row, float w_col,
+                        int label_offset_row, int label_offset_col, const float* gscale,
+                        float* dS, int64_t ldd, float* dS2, int64_t ldd2, void* stream);
+
+/* out[cols, rows] = scale_dev[0] * in[rows, cols]^T (f32; scale_dev NULL = 1).  Operand preparation of the exact-f32
+ * products that differentiate the materialised logits (d/dA = scale * dS · B, d/dB = scale * dS^T · A of
+ * old/clip.py:67) and of the ICNN's transposed weights (triple_flow/2_icnn_core.py:181-211). */
+int clipk_transpose_scale_f32(const float* in, int rows, int cols, const float* scale_dev, float* out, void* stream);
 
 /* Exact-f32 Linear for the ICNN transport maps (the reference forces f32 there: triple_flow/2_icnn_core.py:195):
  *   out[M,N] = X[M,K] · W[N,K]^T (+ bias[N]) (+ addend_scale[0] * addend[M,N])

@@ -39,3 +39,15 @@ def pytest_collection_modifyitems(config, items):
 def dev():
     import torch
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def kopt():
+    """Set libclipk kernel-selection options for one test (include/clipk.h: clipk_set_option); everything is reset
+    to the defaults afterwards.  Options never change results, only which kernel / schedule computes them."""
+    from clip_dplm_amd import ops
+
+    def _set(name, value):
+        ops.set_option(name, value)
+    yield _set
+    ops.reset_options()

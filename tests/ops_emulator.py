@@ -110,6 +110,34 @@ def sim_logits(x, y, scale):
     return (x @ y.t()) * scale
 
 
+def matmul_f32_nt(a, b):
+    return a @ b.t()
+
+
+def transpose_scale_f32(x, scale=None):
+    return (x.t() * (scale if scale is not None else 1.0)).contiguous()
+
+
+def ce_logits_lse(S, S2=None, columns=False, label_offset=0):
+    if columns:
+        return torch.logsumexp(S, 0), torch.diagonal(S, -label_offset).clone()
+    full = S if S2 is None else torch.cat([S, S2], 1)
+    return torch.logsumexp(full, 1), torch.diagonal(S, label_offset).clone()
+
+
+def ce_logits_bwd(S, S2, lse_row, lse_col, w_row, w_col, g, off_row=0, off_col=0):
+    eye = torch.eye(S.shape[0], S.shape[1], dtype=S.dtype)
+    d = torch.zeros_like(S)
+    d2 = None
+    if lse_row is not None:
+        d = d + w_row * (torch.exp(S - lse_row[:, None]) - eye)
+        if S2 is not None:
+            d2 = g * w_row * torch.exp(S2 - lse_row[:, None])
+    if lse_col is not None:
+        d = d + w_col * (torch.exp(S - lse_col[None, :]) - eye)
+    return g * d, d2
+
+
 def layernorm_fwd(x, gamma, beta, eps, act=None, want_f32=True, want_bf16=False, want_stats=True):
     xf = x.float()
     mean = xf.mean(-1)

@@ -51,13 +51,12 @@ def test_gemm_nt_plain(dev, M, N, K):
     assert torch.allclose(c16.float(), ref, rtol=1e-2, atol=1e-2)
 
 
-@pytest.mark.parametrize("kernel,M", [("v2", 384), ("v3", 2304), ("v4", 2304)])
+@pytest.mark.parametrize("kernel,M", [("v2", 384), ("v3", 2304)])
 @pytest.mark.parametrize("act", [None, "relu", "gelu"])
-def test_gemm_nt_epilogue(dev, monkeypatch, act, kernel, M):
+def test_gemm_nt_epilogue(dev, kopt, act, kernel, M):
     """run-time (generic) epilogue combinations — f32 out + residual + pre-activation, bf16 residual, act' — through
     all three tile structures"""
-    monkeypatch.setenv("CLIPK_GEMM_V3", "1" if kernel == "v3" else "0")
-    monkeypatch.setenv("CLIPK_GEMM_V4", "1" if kernel == "v4" else "0")
+    kopt("gemm_kernel", 3 if kernel == "v3" else 2)
     ops = _ops()
     N, K = 256, 192
     a = _rand((M, K), dev, 3, dtype=torch.bfloat16)
@@ -87,19 +86,18 @@ def test_gemm_nt_epilogue(dev, monkeypatch, act, kernel, M):
     assert torch.allclose(outd, (a.float() @ b.float().t()) * gref, rtol=1e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize("kernel", ["v2", "v3", "v4", "v2generic", "v3generic", "v4generic"])
+@pytest.mark.parametrize("kernel", ["v2", "v3", "v2generic", "v3generic"])
 @pytest.mark.parametrize("M,N,K", [(2048, 256, 128), (2500, 360, 160), (4096, 1440, 480), (2304, 480, 1920),
                                    (3000, 776, 192), (66000, 520, 480), (40000, 1000, 224)])
-def test_gemm_nt_specialised_epilogues(dev, monkeypatch, kernel, M, N, K):
+def test_gemm_nt_specialised_epilogues(dev, kopt, kernel, M, N, K):
     """The four compile-time epilogue modes (gemm_epilogue.h) of the 128x128 kernel and of the persistent 256x256
-    phase-interleaved kernel (CLIPK_GEMM_V3), ragged M / N edges and the K % 64 == 32 tail, against torch f32.  The
+    phase-interleaved kernel (option gemm_kernel = 3), ragged M / N edges and the K % 64 == 32 tail, against torch f32.  The
     two largest shapes have 774 / 628 output tiles, i.e. every persistent workgroup walks 2-4 tiles: that covers the
     next-tile prefetch under the epilogue and the store-tolerant vmcnt bookkeeping."""
     ops = _ops()
-    monkeypatch.setenv("CLIPK_GEMM_V3", "1" if kernel.startswith("v3") else "0")
-    monkeypatch.setenv("CLIPK_GEMM_V4", "1" if kernel.startswith("v4") else "0")
+    kopt("gemm_kernel", 3 if kernel.startswith("v3") else 2)
     if kernel.endswith("generic"):
-        monkeypatch.setenv("CLIPK_GEMM_EPI_GENERIC", "1")
+        kopt("gemm_epi_generic", 1)
     a = _rand((M, K), dev, 11, dtype=torch.bfloat16)
     b = _rand((N, K), dev, 12, 0.05, dtype=torch.bfloat16)
     bias = _rand((N,), dev, 13)
@@ -132,10 +130,10 @@ def test_gemm_nt_specialised_epilogues(dev, monkeypatch, kernel, M, N, K):
 @pytest.mark.parametrize("kernel", ["v2", "v3"])
 @pytest.mark.parametrize("M,N,K", [(512, 128, 128), (4096, 1440, 480), (1000, 360, 120), (8192, 480, 1920),
                                    (300, 8, 16), (16384, 768, 768), (20000, 1440, 480), (1100, 264, 520)])
-def test_gemm_wgrad(dev, monkeypatch, kernel, M, N, K):
-    """128x128 kernel and the 256x256 phase-interleaved kernel (CLIPK_WGRAD_V3 = 1 takes every M >= 1024): ragged
+def test_gemm_wgrad(dev, kopt, kernel, M, N, K):
+    """128x128 kernel and the 256x256 phase-interleaved kernel (option wgrad_kernel = 3 takes every M >= 1024): ragged
     N / K edges, a ragged last 64-row step (M = 20000, 1100), one- and two-step splits."""
-    monkeypatch.setenv("CLIPK_WGRAD_V3", "1" if kernel == "v3" else "0")
+    kopt("wgrad_kernel", 3 if kernel == "v3" else 2)
     ops = _ops()
     dy = _rand((M, N), dev, 8, 0.1, dtype=torch.bfloat16)
     x = _rand((M, K), dev, 9, dtype=torch.bfloat16)
@@ -190,11 +188,11 @@ def test_weight_cache_batched_refresh(dev):
 
 
 @pytest.mark.parametrize("B,L,H,D", [(3, 100, 4, 24), (2, 256, 20, 24), (2, 130, 2, 64)])
-def test_rope_prerotation_equals_rotation_at_staging(dev, B, L, H, D, monkeypatch):
+def test_rope_prerotation_equals_rotation_at_staging(dev, B, L, H, D, kopt):
     """clipk_rope_qk (in place, once) + attention without forward rotation == attention that rotates q / k while
     staging them: identical bf16 values reach the MFMAs, so outputs, LSE and dqkv (same kernels) are bit-identical."""
     ops = _ops()
-    monkeypatch.setenv("CLIPK_ATTN_FUSED_BWD", "0")
+    kopt("attn_fused_bwd", 0)
     qkv = _rand((B * L, 3 * H * D), dev, 60, dtype=torch.bfloat16)
     dout = _rand((B * L, H * D), dev, 61, dtype=torch.bfloat16)
     inv = 1.0 / (10000 ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
@@ -212,7 +210,7 @@ def test_rope_prerotation_equals_rotation_at_staging(dev, B, L, H, D, monkeypatc
     assert torch.equal(g1, g2)
     # default dispatch: short heads at 128 < L <= 256 take the whole-head backward when q / k arrive rotated; it sums
     # in another order, so agreement there is to bf16 rounding
-    monkeypatch.delenv("CLIPK_ATTN_FUSED_BWD")
+    kopt("attn_fused_bwd", -1)
     g3 = ops.attn_bwd(rot, o2, dout, lse2, B, L, H, D, key_mask=mask, rope=rope, q_scale=D ** -0.5, prerotated=True)
     m3 = mask.view(B * L, 1).float()
     assert ((g3.float() - g1.float()) * m3).abs().max().item() < 8e-3 * (g1.float() * m3).abs().max().item()
@@ -430,7 +428,7 @@ def test_attention_fwd_bwd(dev, B, L, H, D, use_rope, use_mask):
 @pytest.mark.parametrize("B,L,H,D,use_rope", [(8, 256, 20, 24, True), (3, 190, 4, 32, False), (2, 256, 3, 16, True),
                                                  (2, 129, 2, 24, True), (5, 255, 3, 32, True), (1, 256, 1, 24, False)])
 @pytest.mark.parametrize("waves", ["4", "8"])
-def test_attention_bwd_whole_head_vs_two_kernel(dev, B, L, H, D, use_rope, waves, monkeypatch):
+def test_attention_bwd_whole_head_vs_two_kernel(dev, B, L, H, D, use_rope, waves, kopt):
     """The whole-head backward (one workgroup per head, 5 products) against the dQ + dK/dV kernel pair (7 products)
     on the same inputs: same arithmetic up to the f32 summation order over query / key blocks, so they agree to bf16 rounding."""
     ops = _ops()
@@ -445,10 +443,10 @@ def test_attention_bwd_whole_head_vs_two_kernel(dev, B, L, H, D, use_rope, waves
         qkv = ops.rope_qk_(qkv, B, L, H, D, rope)               # the whole-head kernel wants q / k rotated already
     out, lse = ops.attn_fwd(qkv, B, L, H, D, key_mask=mask, rope=None, q_scale=scale)
     kw = dict(key_mask=mask, rope=rope, q_scale=scale, prerotated=use_rope)
-    monkeypatch.setenv("CLIPK_ATTN_FUSED_BWD", "0")
+    kopt("attn_fused_bwd", 0)
     g2 = ops.attn_bwd(qkv, out, dout, lse, B, L, H, D, **kw).float()
-    monkeypatch.setenv("CLIPK_ATTN_FUSED_BWD", "1")
-    monkeypatch.setenv("CLIPK_ATTN_FUSED_WAVES", waves)      # 4 (default): two 256-thread workgroups per CU; 8: one of 512
+    kopt("attn_fused_bwd", 1)
+    kopt("attn_fused_waves", int(waves))      # 4 (default): two 256-thread workgroups per CU; 8: one of 512
     g1 = ops.attn_bwd(qkv, out, dout, lse, B, L, H, D, **kw).float()
     assert torch.equal(g1, ops.attn_bwd(qkv, out, dout, lse, B, L, H, D, **kw).float())      # reproducible
     m3 = mask.view(B * L, 1).float()
@@ -459,7 +457,7 @@ def test_attention_bwd_whole_head_vs_two_kernel(dev, B, L, H, D, use_rope, waves
 
 
 @pytest.mark.parametrize("B,L,H,D", [(8, 256, 20, 24), (3, 190, 4, 32), (2, 129, 3, 16), (5, 255, 2, 24)])
-def test_attention_fwd_whole_head_equals_general(dev, B, L, H, D, monkeypatch):
+def test_attention_fwd_whole_head_equals_general(dev, B, L, H, D, kopt):
     """Short heads whose rows need no rotation take the whole-head forward (K / V staged once per head); it keeps the
     general kernel's tiles, sub-block order and arithmetic, so outputs and LSE are bit-identical."""
     ops = _ops()
@@ -467,9 +465,9 @@ def test_attention_fwd_whole_head_equals_general(dev, B, L, H, D, monkeypatch):
     lens = torch.tensor([L] + [max(1, L - 29 * (i + 1)) for i in range(B - 1)])
     mask = (torch.arange(L)[None] < lens[:, None]).to(torch.uint8).contiguous().to(dev)
     for m in (None, mask):
-        monkeypatch.setenv("CLIPK_ATTN_WHOLE_FWD", "0")
+        kopt("attn_whole_fwd", 0)
         o0, l0 = ops.attn_fwd(qkv, B, L, H, D, key_mask=m, rope=None, q_scale=D ** -0.5)
-        monkeypatch.setenv("CLIPK_ATTN_WHOLE_FWD", "1")
+        kopt("attn_whole_fwd", 1)
         o1, l1 = ops.attn_fwd(qkv, B, L, H, D, key_mask=m, rope=None, q_scale=D ** -0.5)
         assert torch.equal(o0, o1) and torch.equal(l0, l1)
 
@@ -552,3 +550,73 @@ def test_adamw_clip(dev):
         assert abs(nsq.item() - (g.double() ** 2).sum().item()) / (g.double() ** 2).sum().item() < 1e-5
         ops.adamw_step(wk, g, m, v, 1e-3, 0.9, 0.999, 1e-8, 0.01, step, grad_norm_sq=nsq, max_norm=1.0)
         assert torch.allclose(wk, p.detach(), rtol=1e-5, atol=1e-6), (wk - p).abs().max()
+
+
+# ------------------------------------------------------------------------------------------------ materialised logits
+@pytest.mark.parametrize("B,Nc", [(256, 0), (128, 200), (1000, 37), (1536, 0)])
+def test_ce_logits_kernels_vs_torch(dev, B, Nc):
+    """clipk_ce_logits_{lse,bwd} (F.cross_entropy on the logits the module API returns: old/ablation.py:16,
+    rna_clip_codes.ipynb:1952-1953, old/clip_opt.py:130-151 with cache columns) against f64 torch autograd."""
+    from clip_dplm_amd import functional as KF
+    g = torch.Generator().manual_seed(B + Nc)
+    S = (torch.randn(B, B, generator=g) * 4).to(dev).requires_grad_(True)
+    S2 = (torch.randn(B, Nc, generator=g) * 4).to(dev).requires_grad_(True) if Nc else None
+    lab = torch.arange(B, device=dev)
+    for symmetric in (True, False):
+        Sd = S.detach().double().requires_grad_(True)
+        S2d = S2.detach().double().requires_grad_(True) if Nc else None
+        rows = Sd if not Nc else torch.cat([Sd, S2d], 1)
+        ref = F.cross_entropy(rows, lab)
+        if symmetric:
+            ref = 0.5 * (ref + F.cross_entropy(Sd.t(), lab))
+        (ref * 1.7).backward()
+        S.grad = None
+        if Nc:
+            S2.grad = None
+        loss = KF.cross_entropy_diag(S, S2, symmetric=symmetric)
+        assert abs(loss.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
+        (loss * 1.7).backward()
+        assert torch.allclose(S.grad.double(), Sd.grad, rtol=1e-4, atol=1e-8), (S.grad.double() - Sd.grad).abs().max()
+        if Nc:
+            assert torch.allclose(S2.grad.double(), S2d.grad, rtol=1e-4, atol=1e-8)
+
+
+@pytest.mark.parametrize("M,N,P", [(256, 256, 128), (100, 300, 64), (1100, 1100, 512)])
+def test_sim_logits_backward_on_kernels(dev, M, N, P):
+    """SimLogitsFn: forward clipk_sim_logits, backward exact-f32 MFMA products on transposed operands (no rocBLAS):
+    gradients of sum(logits * G) w.r.t. a, b and the scale against f64 autograd; contraction lengths > 512 take the
+    chunked path (M = N = 1100 is not a multiple of 4 either)."""
+    from clip_dplm_amd import functional as KF
+    a = _unit((M, P), dev, 21).requires_grad_(True)
+    b = _unit((N, P), dev, 22).requires_grad_(True)
+    sc = torch.tensor(14.2849, device=dev, requires_grad=True)
+    G = _rand((M, N), dev, 23)
+    (KF.sim_logits(a, b, sc) * G).sum().backward()
+    ad, bd = a.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    sd = sc.detach().double().requires_grad_(True)
+    ((ad @ bd.t()) * sd * G.double()).sum().backward()
+    assert torch.allclose(a.grad.double(), ad.grad, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(b.grad.double(), bd.grad, rtol=1e-4, atol=1e-4)
+    assert abs(sc.grad.item() - sd.grad.item()) < 1e-4 * max(1.0, abs(sd.grad.item()))
+
+
+def test_transpose_scale_f32(dev):
+    from clip_dplm_amd import ops
+    x = _rand((333, 130), dev, 24)
+    s = torch.tensor([2.5], device=dev)
+    assert torch.equal(ops.transpose_scale_f32(x), x.t().contiguous())
+    assert torch.allclose(ops.transpose_scale_f32(x, s), x.t() * 2.5, rtol=1e-6, atol=0)
+
+
+def test_options_api(dev):
+    """clipk_set_option / get / reset: explicit kernel selection, unknown names and result-changing ablations refused."""
+    from clip_dplm_amd import _ffi, ops
+    assert ops.get_option("gemm_kernel") == -1
+    ops.set_option("gemm_kernel", 2)
+    assert ops.get_option("gemm_kernel") == 2
+    ops.reset_options()
+    assert ops.get_option("gemm_kernel") == -1
+    with pytest.raises(_ffi.ClipkError):
+        ops.set_option("no_such_option", 1)
+    with pytest.raises(_ffi.ClipkError):
+        ops.set_option("gemm_abl", 1)                       # timing ablations change results: experiment builds only

@@ -257,7 +257,7 @@ def test_training_step_is_bitwise_reproducible(dev, dual_stream):
     assert out[0][1].abs().sum().item() > 0
 
 
-def test_large_tile_kernels_agree_with_small_tile_kernels_in_the_model(dev, monkeypatch):
+def test_large_tile_kernels_agree_with_small_tile_kernels_in_the_model(dev, kopt):
     """The persistent 256x256 Linear kernel and the 256x256 weight-gradient kernel (picked automatically at
     benchmark scale) against the 128x128 kernels, which the golden-vector tests above pin to the reference: same
     model, same inputs, loss within 2e-4 and every parameter gradient with cosine > 0.9999 (both accumulate exact
@@ -273,9 +273,9 @@ def test_large_tile_kernels_agree_with_small_tile_kernels_in_the_model(dev, monk
     ids = torch.randint(4, 24, (B, L), generator=g).to(dev)
     rna = torch.randn(B, L, 768, generator=g).to(dev)
     res = {}
-    for tag, v in (("small", "0"), ("large", "1")):
-        monkeypatch.setenv("CLIPK_GEMM_V3", v)
-        monkeypatch.setenv("CLIPK_WGRAD_V3", v)
+    for tag, v in (("small", 2), ("large", 3)):
+        kopt("gemm_kernel", v)
+        kopt("wgrad_kernel", v)
         m.zero_grad(set_to_none=True)
         loss = m.loss(rna, ids)
         loss.backward()
@@ -480,3 +480,39 @@ def test_esm_projections_golden(dev):
         y.sum().backward()
     ids, mask = E.tokenize(["MKV", "ACDEFGHIK"])
     assert ids.tolist()[0] == [0, 20, 15, 7, 2, 1, 1, 1, 1, 1, 1] and mask.sum().item() == 5 + 11
+
+
+def test_load_state_dict_after_forward_refreshes_fused_qkv_copies(dev):
+    """the ESM fused qkv weight is a zero-copy as_strided view whose own _version never moves; its bf16
+    copies are keyed on the three source Parameters' versions.  FusedAdamW model, one step, then load_state_dict of
+    other weights: the next grad-enabled forward must equal a fresh model holding those weights (bitwise: same
+    kernels, same inputs)."""
+    import clip_dplm_amd as K
+    from clip_dplm_amd.encoders import ESM2_SHAPES
+    ESM2_SHAPES["test_stale"] = (2, 96, 4, 384)
+    kw = dict(esm="test_stale", rna_dim=64, rna_layers=1, rna_heads=8, rna_ffn=128, projection_dim=64)
+    torch.manual_seed(0)
+    m = K.ProteinRNACLIP(**kw).to(dev).train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    torch.manual_seed(1)
+    other = {k: v.detach().clone() for k, v in K.ProteinRNACLIP(**kw).state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(4, 24, (16, 32), generator=g).to(dev)
+    rna = torch.randn(16, 32, 64, generator=g).to(dev)
+    opt = K.FusedAdamW(m, lr=1e-3)
+    opt.zero_grad(); m.loss(rna, ids).backward(); opt.step()
+    m.load_state_dict(other)                               # in place, bypasses the optimiser's dirty marking
+    opt.zero_grad()
+    l1 = m.loss(rna, ids)
+    fresh = K.ProteinRNACLIP(**kw)
+    fresh.load_state_dict(other)
+    fresh = fresh.to(dev).train()
+    for mod in fresh.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    opt2 = K.FusedAdamW(fresh, lr=1e-3)
+    opt2.zero_grad()
+    l2 = fresh.loss(rna, ids)
+    assert torch.equal(l1, l2), (l1.item(), l2.item())

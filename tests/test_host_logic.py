@@ -175,3 +175,38 @@ def test_flat_buffer_groups_qkv_for_zero_copy_fusion(monkeypatch):
     assert enc.encoder.layer[1].attention.self.value.weight.grad.abs().max() > 0
     opt.step()
     assert not torch.equal(before, enc.encoder.layer[1].attention.self.value.weight.detach())
+
+
+def test_dropout_in_training_mode_is_refused_not_ignored(monkeypatch):
+    """The kernel stack has no dropout: a module built with the notebook's p = 0.1 raises in training mode instead of
+    silently training unregularised; p = 0 trains, eval mode runs."""
+    ops_emulator.install(monkeypatch)
+    import clip_dplm_amd as K
+    m = K.RNARBPCLIPModel(rna_dim=24, rbp_dim=64, projection_dim=32)            # dropout = 0.1 like the notebook
+    g = torch.Generator().manual_seed(0)
+    rna, rbp = torch.randn(4, 6, 24, generator=g), torch.randn(4, 5, 64, generator=g)
+    m.train()
+    with pytest.raises(NotImplementedError, match="dropout"):
+        m(rna, rbp)
+    m.eval()
+    assert torch.isfinite(m(rna, rbp)[2])
+    m2 = K.RNARBPCLIPModel(rna_dim=24, rbp_dim=64, projection_dim=32, dropout=0.0).train()
+    for mod in m2.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    assert torch.isfinite(m2(rna, rbp)[2])
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` outside torch.distributed.run starts two fresh ranks itself (before any HIP call) and
+    returns the launcher's exit code.  Here there is no GPU, so each rank stops at the 'needs an MI355X' check: the
+    test asserts the launch happened (both ranks reported) and that the failure propagated."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0
+    assert "starting 2 ranks" in r.stderr
+    assert r.stderr.count("needs an MI355X") >= 2, r.stderr[-2000:]

@@ -50,22 +50,19 @@ GEMM_SHAPES = [  # (name, M, N, K, epilogue)
 
 
 def bench_gemm():
-    """three arms, interleaved in one process: 128^2 kernel with the run-time epilogue (round-1 baseline), 128^2 with
-    the specialised straight-line epilogue, 256^2 phase-interleaved kernel (CLIPK_GEMM_V3)"""
-    arms = [("v2gen", {"CLIPK_GEMM_EPI_GENERIC": "1", "CLIPK_GEMM_V3": "0"}), ("v2", {"CLIPK_GEMM_V3": "0"}),
-            ("v3", {"CLIPK_GEMM_V3": "1"})]
+    """arms interleaved in one process: 128^2 kernel with the run-time epilogue (round-1 baseline), 128^2 with the
+    specialised straight-line epilogue, 256^2 phase-interleaved kernel (option gemm_kernel = 3).  Arms are dicts of
+    libclipk options (ops.set_option); BENCH_NT / BENCH_NWG / BENCH_STAGGER / BENCH_ABL (the last needs a
+    -DCLIPK_EXPERIMENTS build) add arms."""
+    arms = [("v2gen", {"gemm_epi_generic": 1, "gemm_kernel": 2}), ("v2", {"gemm_kernel": 2}), ("v3", {"gemm_kernel": 3})]
     if os.environ.get("BENCH_NT"):
-        arms.append(("v3nt0", {"CLIPK_GEMM_V3": "1", "CLIPK_EPI_NT": "0"}))
-        arms.append(("v3nt1", {"CLIPK_GEMM_V3": "1", "CLIPK_EPI_NT": "1"}))
-    if os.environ.get("BENCH_V4"):
-        arms.append(("v4", {"CLIPK_GEMM_V4": "1"}))
+        arms.append(("v3nt1", {"gemm_kernel": 3, "epi_nt": 1}))
     for ab in os.environ.get("BENCH_ABL", "").split():
-        arms.append(("v3a" + ab, {"CLIPK_GEMM_V3": "1", "CLIPK_GEMM_ABL": ab}))
+        arms.append(("v3a" + ab, {"gemm_kernel": 3, "gemm_abl": int(ab)}))
     for nw in os.environ.get("BENCH_NWG", "").split():
-        arms.append(("v3w" + nw, {"CLIPK_GEMM_V3": "1", "CLIPK_GEMM_NWG": nw}))
-        arms.append(("w%sa1" % nw, {"CLIPK_GEMM_V3": "1", "CLIPK_GEMM_NWG": nw, "CLIPK_GEMM_ABL": "1"}))
+        arms.append(("v3w" + nw, {"gemm_kernel": 3, "gemm_nwg": int(nw)}))
     for st in os.environ.get("BENCH_STAGGER", "").split():
-        arms.append(("v3s" + st, {"CLIPK_GEMM_V3": "1", "CLIPK_GEMM_STAGGER": st}))
+        arms.append(("v3s" + st, {"gemm_kernel": 3, "gemm_stagger": int(st)}))
     print(f"{'shape':12s} {'M':>7s} {'N':>5s} {'K':>5s} {'epi':9s} | " + " | ".join(f"{n:>5s} us  TF/s" for n, _ in arms)
           + " | v2/v2gen v3/v2")
     tot = {n: 0.0 for n, _ in arms}
@@ -80,40 +77,38 @@ def bench_gemm():
         elif epi == "dact":
             kw = {"dact_aux": rnd((M, N)), "dact": "gelu"}
         out = {}
-        for n, env in arms:
-            for k in ("CLIPK_GEMM_EPI_GENERIC", "CLIPK_GEMM_V3", "CLIPK_GEMM_V4", "CLIPK_EPI_NT", "CLIPK_GEMM_STAGGER", "CLIPK_GEMM_ABL", "CLIPK_GEMM_NWG"):
-                os.environ.pop(k, None)
-            os.environ.update(env)
+        for n, opts in arms:
+            ops.reset_options()
+            for k, v in opts.items():
+                ops.set_option(k, v)
             med, mn = timeit(lambda: ops.gemm_nt(a, b, **kw))
             out[n] = med
             tot[n] += med
         fl = 2.0 * M * N * K
         print(f"{name:12s} {M:7d} {N:5d} {K:5d} {epi:9s} | "
               + " | ".join(f"{out[n] * 1e3:7.1f} {fl / out[n] / 1e9:5.0f}" for n, _ in arms)
-              + f" | {out['v2gen'] / out['v2']:.2f}x {out['v2'] / out['v3']:.2f}x"
-              + (f" v3/v4 {out['v3'] / out['v4']:.2f}x" if "v4" in out else ""), flush=True)
+              + f" | {out['v2gen'] / out['v2']:.2f}x {out['v2'] / out['v3']:.2f}x", flush=True)
         del a, b, kw
-    for k in ("CLIPK_GEMM_EPI_GENERIC", "CLIPK_GEMM_V3", "CLIPK_GEMM_V4", "CLIPK_EPI_NT", "CLIPK_GEMM_STAGGER", "CLIPK_GEMM_ABL", "CLIPK_GEMM_NWG"):
-        os.environ.pop(k, None)
+    ops.reset_options()
     print("sum: " + ", ".join(f"{n} {tot[n]:.2f} ms" for n, _ in arms))
 
 
 def bench_wgrad():
     print(f"{'shape':12s} {'M':>7s} {'N':>5s} {'K':>5s} |   v2 us  TF/s |   v3 us  TF/s | v3/v2")
-    tot = {"0": 0.0, "1": 0.0}
+    tot = {2: 0.0, 3: 0.0}
     for name, M, N, K, _ in GEMM_SHAPES[:8]:
         dy, x = rnd((M, N), scale=0.1), rnd((M, K))
         out = {}
-        for ver in ("0", "1"):
-            os.environ["CLIPK_WGRAD_V3"] = ver
+        for ver in (2, 3):
+            ops.set_option("wgrad_kernel", ver)
             med, mn = timeit(lambda: ops.gemm_wgrad(dy, x, want_bias=True))
             out[ver] = med
             tot[ver] += med
         fl = 2.0 * M * N * K
-        print(f"{name:12s} {M:7d} {N:5d} {K:5d} | {out['0'] * 1e3:7.1f} {fl / out['0'] / 1e9:5.0f} | "
-              f"{out['1'] * 1e3:7.1f} {fl / out['1'] / 1e9:5.0f} | {out['0'] / out['1']:.2f}x", flush=True)
-    os.environ.pop("CLIPK_WGRAD_V3", None)
-    print(f"sum: v2 {tot['0']:.2f} ms, v3 {tot['1']:.2f} ms")
+        print(f"{name:12s} {M:7d} {N:5d} {K:5d} | {out[2] * 1e3:7.1f} {fl / out[2] / 1e9:5.0f} | "
+              f"{out[3] * 1e3:7.1f} {fl / out[3] / 1e9:5.0f} | {out[2] / out[3]:.2f}x", flush=True)
+    ops.reset_options()
+    print(f"sum: v2 {tot[2]:.2f} ms, v3 {tot[3]:.2f} ms")
 
 
 def bench_attn():

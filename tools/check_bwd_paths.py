@@ -7,6 +7,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import clip_dplm_amd as K  # noqa: E402
+from clip_dplm_amd import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -19,7 +20,7 @@ ids = torch.randint(4, 24, (256, 256), generator=g).to(dev)
 rna = torch.randn(256, 256, 768, generator=g).to(dev)
 grads = {}
 for mode in ("1", "0"):
-    os.environ["CLIPK_ATTN_FUSED_BWD"] = mode
+    ops.set_option("attn_fused_bwd", int(mode))
     for p in m.parameters():
         p.grad = None
     loss = m.loss(rna, ids)

@@ -48,15 +48,15 @@ torch.cuda.synchronize()
 res = collections.defaultdict(list)
 for rnd in range(4):
     for mode, waves, name in (("1", "8", "whole-head, 8 waves"), ("1", "4", "whole-head, 4 waves"), ("0", "8", "dQ + dK/dV pair")):
-        os.environ["CLIPK_ATTN_FUSED_BWD"] = mode
-        os.environ["CLIPK_ATTN_FUSED_WAVES"] = waves
+        ops.set_option("attn_fused_bwd", int(mode))
+        ops.set_option("attn_fused_waves", int(waves))
         res[name].append(timeit(bwd))
 for k, v in res.items():
     print(f"{k:20s}", " ".join(f"{x:7.1f}" for x in v), "us")
-os.environ["CLIPK_ATTN_FUSED_BWD"] = "1"
-os.environ["CLIPK_ATTN_FUSED_WAVES"] = "4"
+ops.set_option("attn_fused_bwd", 1)
+ops.set_option("attn_fused_waves", 4)
 g1 = bwd().float()
-os.environ["CLIPK_ATTN_FUSED_BWD"] = "0"
+ops.set_option("attn_fused_bwd", 0)
 g0 = bwd().float()
 print(f"max rel diff {(g1 - g0).abs().max().item() / g0.abs().max().item():.2e}")
 
@@ -72,9 +72,9 @@ print("hd 96 forward     ", " ".join(f"{x:7.1f}" for x in t), "us")
 fw = collections.defaultdict(list)
 for rnd in range(3):
     for mode, name in (("1", "hd 24 forward, whole-head"), ("0", "hd 24 forward, general")):
-        os.environ["CLIPK_ATTN_WHOLE_FWD"] = mode
+        ops.set_option("attn_whole_fwd", int(mode))
         fw[name].append(timeit(lambda: ops.attn_fwd(rot, B, L, H, D, rope=None, q_scale=D ** -0.5)))
-    os.environ["CLIPK_ATTN_WHOLE_FWD"] = "1"
+    ops.set_option("attn_whole_fwd", 1)
     scratch = qkv.clone()
     fw["hd 24 rope_qk_ + forward (two launches)"].append(timeit(
         lambda: ops.attn_fwd(ops.rope_qk_(scratch, B, L, H, D, r), B, L, H, D, rope=None, q_scale=D ** -0.5)))
