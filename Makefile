@@ -18,7 +18,9 @@ $(LIB): $(OBJ)
 	@mkdir -p clip_dplm_amd/lib
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ)
 
-probes: tools/probes/probe_layouts tools/probes/probe_gather tools/probes/probe_store_shapes
+probes: tools/probes/probe_layouts tools/probes/probe_gather tools/probes/probe_store_shapes tools/probes/probe_store_vs_dma
+tools/probes/probe_store_vs_dma: tools/probes/probe_store_vs_dma.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-value -o $@ $<
 tools/probes/probe_layouts: tools/probes/probe_layouts.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -Wno-unused-value -o $@ $<
 tools/probes/probe_gather: tools/probes/probe_gather.hip
@@ -27,6 +29,6 @@ tools/probes/probe_store_shapes: tools/probes/probe_store_shapes.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-value -o $@ $<
 
 clean:
-	rm -rf build $(LIB) tools/probes/probe_layouts tools/probes/probe_gather tools/probes/probe_store_shapes
+	rm -rf build $(LIB) tools/probes/probe_layouts tools/probes/probe_gather tools/probes/probe_store_shapes tools/probes/probe_store_vs_dma
 
 .PHONY: all clean probes

@@ -302,7 +302,8 @@ def bench_clip(args):
                                "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
                                "traffic": traffic["bytes_per_launch"] if traffic else None,
                                "avg_launch_us": round(gm["avg_us"], 2), "launches": gm["launches"],
-                               "share_of_step": round(gm["total_ms"] / (1e3 * dt), 4)}
+                               "share_of_step": round(gm["total_ms"] / (1e3 * dt), 4),
+                               "algorithmic_bytes_per_launch": round(gm["bytes"] / max(gm["launches"], 1))}
             if traffic:
                 out["roofline"]["traffic_detail"] = {k: traffic[k] for k in traffic if k != "bytes_per_launch"}
         src, steps_src, tag = (summ, args.steps, "timed region") if (args.all_kernel_timers or timer_alone is None) \

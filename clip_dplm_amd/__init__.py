@@ -11,13 +11,17 @@ from .modeling_clip import (CLIPEncoder, DiffMapProteinCLIP, DiffMapProteinCLIPM
                             optimized_clip_loss)
 from .modeling_seqclip import (ProteinRNACLIP, RNARBPCLIPEncoder, RNARBPCLIPModel, RNARBPCLIPProjectionHead,
                                create_padding_mask)
+from .modeling_trimodal import CellStateEncoder, ContrastiveModel, PerturbationEncoder, TransformerEncoder
 from .optim import FlatParams, FusedAdamW, cosine_annealing_lr
+from .training import CosineAnnealingLR, EarlyStopping, evaluate_model, load_checkpoint, save_checkpoint, train_epoch
 
 __all__ = [
     "HybridCLIPConfig", "ModelArchitectureConfig", "TrainingConfig", "SubConfig",
     "CLIPEncoder", "ProjectionHead", "RNAProteinCLIPModule", "DiffMapProteinCLIPModule", "RNAProteinCLIP",
     "DiffMapProteinCLIP", "OptimizedProjectionHead", "OptimizedCLIPModule", "optimized_clip_loss",
     "RNARBPCLIPProjectionHead", "RNARBPCLIPEncoder", "RNARBPCLIPModel", "create_padding_mask", "ProteinRNACLIP",
+    "ContrastiveModel", "CellStateEncoder", "PerturbationEncoder", "TransformerEncoder",
     "ESM2Encoder", "ESM2_SHAPES", "TransformerSeqEncoder", "pool", "clip_loss", "FlatParams", "FusedAdamW",
-    "cosine_annealing_lr",
+    "cosine_annealing_lr", "CosineAnnealingLR", "EarlyStopping", "train_epoch", "evaluate_model", "save_checkpoint",
+    "load_checkpoint",
 ]

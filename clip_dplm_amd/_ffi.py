@@ -53,6 +53,10 @@ SIGNATURES = {
     "clipk_simce_workspace": (_sz, [_i, _i, _i]),
     "clipk_simce_lse": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "clipk_simce_grad": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _sz, _vp]),
+    "clipk_simce_pairs_workspace": (_sz, [_i, _i, _i]),
+    "clipk_simce_lse_pairs": (_i, [_vp, _i, _i, _i, C.POINTER(_i), _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "clipk_simce_grad_pairs": (_i, [_vp, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _i, _vp, _vp, _f, _f, _f, _vp, _vp,
+                                    _vp, _sz, _vp]),
     "clipk_sim_logits": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i64, _vp]),
     "clipk_ce_logits_lse": (_i, [_vp, _i64, _i, _i, _vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
     "clipk_ce_logits_bwd": (_i, [_vp, _i64, _i, _i, _vp, _i64, _i, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _i64, _vp, _i64, _vp]),

@@ -26,6 +26,7 @@ constexpr int QB = 32;          // queries per workgroup
 constexpr int KT = 32;          // keys per tile
 constexpr int PWMAX = 128;      // contraction slice per wave
 constexpr int MAXW = 8;         // P <= 1024
+constexpr int MAXZ = 6;         // problems per batched launch
 
 enum { MODE_LSE = 0, MODE_GRAD = 1, MODE_LOGITS = 2 };
 
@@ -48,6 +49,11 @@ struct SP {
   float* S; long lds_out;
   const float* ep_bias; const float* ep_add; const float* ep_add_scale;
   int ksplit, tiles_per_split, ntiles;
+  // batched launch (blockIdx.z = problem): several same-shape (X, Y) problems in one grid — the three pairwise blocks
+  // of the tri-modal loss in both directions.  nz == 0: the single problem described above.
+  int nz;
+  const float* Xz[MAXZ]; const float* Yz[MAXZ]; const float* lse_xz[MAXZ]; const float* lse_yz[MAXZ];
+  long z_part, z_pos, z_slab, z_dsc;     // per-problem strides (floats) of part_ml / pos / slab / dsc_part
 };
 
 __device__ __forceinline__ int keyrow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -61,6 +67,16 @@ __global__ __launch_bounds__(512) void simce_kernel(const SP p) {
   const int q = lane & 31, h = lane >> 5;
   const int q0 = blockIdx.x * QB, ks = blockIdx.y;
   const int Nkeys = p.Ny + p.Nc;
+  const int z = blockIdx.z;
+  const float* Xb = p.nz ? p.Xz[z] : p.X;
+  const float* Yb = p.nz ? p.Yz[z] : p.Y;
+  const float* Ycb = p.nz ? Yb : p.Yc;
+  const float* lse_xb = p.nz ? p.lse_xz[z] : p.lse_x;
+  const float* lse_yb = p.nz ? p.lse_yz[z] : p.lse_y;
+  float* part_ml = p.part_ml + (p.nz ? z * p.z_part : 0);
+  float* posb = p.pos + (p.nz ? z * p.z_pos : 0);
+  float* slabb = p.slab + (p.nz ? z * p.z_slab : 0);
+  float* dsc_partb = p.dsc_part + (p.nz ? z * p.z_dsc : 0);
   float* ylds = reinterpret_cast<float*>(smem) + w * KT * YLD;
   float* red = reinterpret_cast<float*>(smem) + NW * KT * YLD;     // [NW][16*64]
   const int pbeg = w * Pw;
@@ -70,7 +86,7 @@ __global__ __launch_bounds__(512) void simce_kernel(const SP p) {
   f32x4 xf[PWMAX / 8];
   {
     int qi = q0 + q; qi = qi < p.Mx ? qi : p.Mx - 1;
-    const float* xr = p.X + (long)qi * P;
+    const float* xr = Xb + (long)qi * P;
 #pragma unroll
     for (int t = 0; t < PWMAX / 8; ++t) {
       xf[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -88,7 +104,7 @@ __global__ __launch_bounds__(512) void simce_kernel(const SP p) {
   float lse_xi = 0.f, dsc = 0.f;
   f32x16 dx[PWMAX / 32];
   if (MODE == MODE_GRAD) {
-    lse_xi = p.lse_x[qg < p.Mx ? qg : p.Mx - 1];
+    lse_xi = lse_xb[qg < p.Mx ? qg : p.Mx - 1];
 #pragma unroll
     for (int t = 0; t < PWMAX / 32; ++t)
 #pragma unroll
@@ -108,7 +124,7 @@ __global__ __launch_bounds__(512) void simce_kernel(const SP p) {
       const int idx = lane + 64 * it;
       const int row = idx / c4_per_row, c4 = idx - row * c4_per_row;
       int j = j0 + row; j = j < Nkeys ? j : Nkeys - 1;
-      const float* yr = (j < p.Ny) ? p.Y + (long)j * P : p.Yc + (long)(j - p.Ny) * P;
+      const float* yr = (j < p.Ny) ? Yb + (long)j * P : Ycb + (long)(j - p.Ny) * P;
       const int pp = pbeg + c4 * 4;
       f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
       if (pp < P) v = *reinterpret_cast<const f32x4*>(yr + pp);
@@ -169,7 +185,7 @@ __global__ __launch_bounds__(512) void simce_kernel(const SP p) {
         if (key < Nkeys) {
           gv = p.w_row * expf(sv - lse_xi);
           if (key < p.Ny) {
-            gv += p.w_col * expf(sv - p.lse_y[key]);
+            gv += p.w_col * expf(sv - lse_yb[key]);
             if (key == label) gv -= (p.w_row + p.w_col);
           }
           gv *= p.inv_bg;
@@ -213,10 +229,10 @@ __global__ __launch_bounds__(512) void simce_kernel(const SP p) {
       if (m_n > -INFINITY) l_n = l_run * expf(m_run - m_n) + l_o * expf(m_o - m_n);
       if (qg < p.Mx) {
         if (h == 0) {
-          float* o = p.part_ml + ((long)ks * p.Mx + qg) * 2;
+          float* o = part_ml + ((long)ks * p.Mx + qg) * 2;
           o[0] = m_n; o[1] = l_n;
         }
-        if (pos_hit) p.pos[qg] = pos_v;
+        if (pos_hit) posb[qg] = pos_v;
       }
     }
   } else if (MODE == MODE_GRAD) {
@@ -233,19 +249,21 @@ __global__ __launch_bounds__(512) void simce_kernel(const SP p) {
       const int pp = pbeg + c4 * 4;
       if (q0 + row < p.Mx && pp < P) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(ylds + row * YLD + c4 * 4);
-        *reinterpret_cast<f32x4*>(p.slab + ((long)ks * p.Mx + q0 + row) * P + pp) = v;
+        *reinterpret_cast<f32x4*>(slabb + ((long)ks * p.Mx + q0 + row) * P + pp) = v;
       }
     }
     if (w == 0) {
       const float d = dsc + __shfl_xor(dsc, 32, 64);
-      if (h == 0 && qg < p.Mx) p.dsc_part[(long)ks * p.Mx + qg] = d;
+      if (h == 0 && qg < p.Mx) dsc_partb[(long)ks * p.Mx + qg] = d;
     }
   }
 }
 
-__global__ void simce_lse_finalize(const float* part_ml, int ksplit, int Mx, float* lse) {
+__global__ void simce_lse_finalize(const float* part_ml, int ksplit, int Mx, float* lse, long z_part) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Mx) return;
+  part_ml += blockIdx.y * z_part;                 // batched launch: blockIdx.y = problem
+  lse += (long)blockIdx.y * Mx;
   float m = -INFINITY;
   for (int s = 0; s < ksplit; ++s) m = fmaxf(m, part_ml[((long)s * Mx + i) * 2]);
   float l = 0.f;
@@ -257,9 +275,14 @@ __global__ void simce_lse_finalize(const float* part_ml, int ksplit, int Mx, flo
 }
 
 __global__ void simce_grad_finalize(const float* slab, const float* dsc_part, int ksplit, int Mx, int P,
-                                    const float* scale, float* dX, float* dscale_partial) {
+                                    const float* scale, float* dX, float* dscale_partial, long z_slab,
+                                    long z_dsc) {
   const long n4 = (long)Mx * P / 4;
   const float sc = scale[0];
+  slab += blockIdx.y * z_slab;                    // batched launch: blockIdx.y = problem
+  dsc_part += blockIdx.y * z_dsc;
+  dX += (long)blockIdx.y * Mx * P;
+  if (dscale_partial) dscale_partial += (long)blockIdx.y * Mx;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < ksplit; ++s) a += reinterpret_cast<const f32x4*>(slab + (long)s * Mx * P)[i];
@@ -298,7 +321,7 @@ template <int MODE>
 int launch(const SP& sp, const Plan& pl, hipStream_t st) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(simce_kernel<MODE>),
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
-  hipLaunchKernelGGL(simce_kernel<MODE>, dim3(pl.nqb, pl.ksplit), dim3(pl.NW * 64), pl.lds, st, sp);
+  hipLaunchKernelGGL(simce_kernel<MODE>, dim3(pl.nqb, pl.ksplit, sp.nz > 0 ? sp.nz : 1), dim3(pl.NW * 64), pl.lds, st, sp);
   return clipk_check_launch();
 }
 
@@ -326,7 +349,7 @@ extern "C" int clipk_simce_lse(const float* X, int Mx, const float* Y, int Ny, c
   int rc = launch<MODE_LSE>(sp, pl, (hipStream_t)stream);
   if (rc) return rc;
   hipLaunchKernelGGL(simce_lse_finalize, dim3((Mx + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)workspace, pl.ksplit, Mx, lse);
+                     (const float*)workspace, pl.ksplit, Mx, lse, 0L);
   return clipk_check_launch();
 }
 
@@ -355,7 +378,80 @@ extern "C" int clipk_simce_grad(const float* X, int Mx, const float* Y, int Ny, 
   int blocks = (int)((n4 + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(simce_grad_finalize, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                      (const float*)sp.slab, (const float*)sp.dsc_part, pl.ksplit, Mx, P, scale, dX,
-                     dscale_partial);
+                     dscale_partial, 0L, 0L);
+  return clipk_check_launch();
+}
+
+// ---- batched form: npairs same-shape problems (X = E[pairs[2i]], Y = E[pairs[2i+1]]) in ONE launch each for the LSE
+// pass and the gradient pass (blockIdx.z = problem).  The tri-modal ContrastiveModel of current/tf_clip_codes (1).ipynb
+// :13150-13163 is three pairwise symmetric losses on one logit_scale = six directed problems.
+extern "C" size_t clipk_simce_pairs_workspace(int npairs, int B, int P) {
+  Plan pl;
+  if (npairs <= 0 || npairs > MAXZ || !make_plan(B, B, P, &pl)) return 0;
+  return (size_t)npairs * pl.ksplit * B * ((size_t)P + 2) * sizeof(float);
+}
+
+extern "C" int clipk_simce_lse_pairs(const float* E, int nmod, int B, int P, const int* pairs, int npairs,
+                                     const float* scale, float* lse, float* pos, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  if (!E || !pairs || !scale || !lse || !pos || !workspace || npairs <= 0 || npairs > MAXZ || nmod <= 0)
+    return CLIPK_ERR_BAD_ARG;
+  Plan pl;
+  if (!make_plan(B, B, P, &pl)) return CLIPK_ERR_UNSUPPORTED;
+  if (!aligned16(E) || (((size_t)B * P * 4) & 15)) return CLIPK_ERR_BAD_ARG;
+  const long z_part = (long)pl.ksplit * B * 2;
+  if (workspace_bytes < (size_t)npairs * z_part * sizeof(float)) return CLIPK_ERR_BAD_ARG;
+  SP sp{};
+  sp.Mx = B; sp.Ny = B; sp.Nc = 0;
+  sp.P = P; sp.Pw = pl.Pw; sp.NW = pl.NW; sp.scale = scale; sp.label_offset = 0;
+  sp.part_ml = (float*)workspace; sp.pos = pos;
+  sp.ksplit = pl.ksplit; sp.tiles_per_split = pl.tps; sp.ntiles = pl.ntiles;
+  sp.nz = npairs; sp.z_part = z_part; sp.z_pos = B;
+  for (int i = 0; i < npairs; ++i) {
+    const int a = pairs[2 * i], b = pairs[2 * i + 1];
+    if (a < 0 || a >= nmod || b < 0 || b >= nmod) return CLIPK_ERR_BAD_ARG;
+    sp.Xz[i] = E + (size_t)a * B * P; sp.Yz[i] = E + (size_t)b * B * P;
+  }
+  int rc = launch<MODE_LSE>(sp, pl, (hipStream_t)stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(simce_lse_finalize, dim3((B + 255) / 256, npairs), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)workspace, pl.ksplit, B, lse, z_part);
+  return clipk_check_launch();
+}
+
+extern "C" int clipk_simce_grad_pairs(const float* E, int nmod, int B, int P, const int* pairs, const int* reverse,
+                                      int npairs, const float* scale, const float* lse /*[npairs][B]*/, float w_row,
+                                      float w_col, float inv_bg, float* dX /*[npairs][B][P]*/,
+                                      float* dscale_partial /*[npairs][B]*/, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+  if (!E || !pairs || !reverse || !scale || !lse || !dX || !workspace || npairs <= 0 || npairs > MAXZ || nmod <= 0)
+    return CLIPK_ERR_BAD_ARG;
+  Plan pl;
+  if (!make_plan(B, B, P, &pl)) return CLIPK_ERR_UNSUPPORTED;
+  if (!aligned16(E) || !aligned16(dX) || !aligned16(workspace) || (((size_t)B * P * 4) & 15)) return CLIPK_ERR_BAD_ARG;
+  const long z_slab = (long)pl.ksplit * B * P, z_dsc = (long)pl.ksplit * B;
+  if (workspace_bytes < (size_t)npairs * (z_slab + z_dsc) * sizeof(float)) return CLIPK_ERR_BAD_ARG;
+  SP sp{};
+  sp.Mx = B; sp.Ny = B; sp.Nc = 0;
+  sp.P = P; sp.Pw = pl.Pw; sp.NW = pl.NW; sp.scale = scale; sp.label_offset = 0;
+  sp.w_row = w_row; sp.w_col = w_col; sp.inv_bg = inv_bg;
+  sp.slab = (float*)workspace; sp.dsc_part = (float*)workspace + (size_t)npairs * z_slab;
+  sp.ksplit = pl.ksplit; sp.tiles_per_split = pl.tps; sp.ntiles = pl.ntiles;
+  sp.nz = npairs; sp.z_slab = z_slab; sp.z_dsc = z_dsc;
+  for (int i = 0; i < npairs; ++i) {
+    const int a = pairs[2 * i], b = pairs[2 * i + 1], r = reverse[i];
+    if (a < 0 || a >= nmod || b < 0 || b >= nmod || r < 0 || r >= npairs) return CLIPK_ERR_BAD_ARG;
+    sp.Xz[i] = E + (size_t)a * B * P; sp.Yz[i] = E + (size_t)b * B * P;
+    sp.lse_xz[i] = lse + (size_t)i * B;            // rows of X over the keys Y
+    sp.lse_yz[i] = lse + (size_t)r * B;            // each key of Y over the queries X = the reverse problem's LSE
+  }
+  int rc = launch<MODE_GRAD>(sp, pl, (hipStream_t)stream);
+  if (rc) return rc;
+  long n4 = (long)B * P / 4;
+  int blocks = (int)((n4 + 255) / 256); if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(simce_grad_finalize, dim3(blocks, npairs), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)sp.slab, (const float*)sp.dsc_part, pl.ksplit, B, P, scale, dX, dscale_partial,
+                     z_slab, z_dsc);
   return clipk_check_launch();
 }
 

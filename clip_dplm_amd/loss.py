@@ -97,12 +97,51 @@ def clip_loss(a_embeds: torch.Tensor, b_embeds: torch.Tensor, logit_scale_exp: t
     return ClipLossFn.apply(a_embeds, b_embeds, logit_scale_exp, float(w_row), float(w_col), cache, group)
 
 
+_TRI_PAIRS = ((0, 1), (1, 0), (0, 2), (2, 0), (1, 2), (2, 1))      # (cell,pert) (pert,cell) (cell,prot) ...
+
+
+class TriModalLossFn(torch.autograd.Function):
+    """The three pairwise symmetric InfoNCE losses of current/tf_clip_codes (1).ipynb:13150-13163 on ONE logit scale:
+    six directed similarity + LSE problems in one launch (clipk_simce_lse_pairs), six gradient problems in one more
+    (clipk_simce_grad_pairs).  Returns (cell_pert, cell_protein, pert_protein) losses; any combination of upstream
+    gradients is honoured."""
+
+    @staticmethod
+    def forward(ctx, cell, pert, prot, scale):
+        E = torch.stack([cell, pert, prot]).contiguous()                # [3, B, P]
+        sc = scale.reshape(1).contiguous()
+        lse, pos = _kernels.simce_lse_pairs(E, _TRI_PAIRS, sc)
+        per = (lse - pos).mean(1)                                       # six one-directional CE values
+        ctx.save_for_backward(E, sc, lse)
+        ctx.scale_shape = scale.shape
+        return 0.5 * (per[0] + per[1]), 0.5 * (per[2] + per[3]), 0.5 * (per[4] + per[5])
+
+    @staticmethod
+    def backward(ctx, g_cp, g_ce, g_pe):
+        E, sc, lse = ctx.saved_tensors
+        B = E.shape[1]
+        dX, dsc = _kernels.simce_grad_pairs(E, _TRI_PAIRS, sc, lse, 0.5, 0.5, 1.0 / B)
+        # problem (a, b) holds d L_ab / d E_a complete (both directions): combine per modality — [B, P] adds: plumbing
+        dcell = g_cp * dX[0] + g_ce * dX[2]
+        dpert = g_cp * dX[1] + g_pe * dX[4]
+        dprot = g_ce * dX[3] + g_pe * dX[5]
+        dscale = (g_cp * dsc[0].sum() + g_ce * dsc[2].sum() + g_pe * dsc[4].sum()).reshape(ctx.scale_shape)
+        return dcell, dpert, dprot, dscale
+
+
 def tri_modal_loss(cell_embed: torch.Tensor, pert_embed: torch.Tensor, protein_embed: torch.Tensor,
                    logit_scale_exp: torch.Tensor, group=None):
     """Tri-modal contrastive objective of current/tf_clip_codes (1).ipynb:13150-13176: three pairwise symmetric
-    InfoNCE losses sharing one logit_scale, each on the fused similarity + CE kernels (no B x B logits).
-    Returns the dict of the reference's ContrastiveModel.forward (loss terms only)."""
-    cp = clip_loss(cell_embed, pert_embed, logit_scale_exp, symmetric=True, group=group)
-    ce = clip_loss(cell_embed, protein_embed, logit_scale_exp, symmetric=True, group=group)
-    pe = clip_loss(pert_embed, protein_embed, logit_scale_exp, symmetric=True, group=group)
+    InfoNCE losses sharing one logit_scale on the fused similarity + CE kernels (no B x B logits).  Single process:
+    one batched launch per pass for all three pairs (TriModalLossFn); with a process group: three global-batch
+    clip_loss calls.  Returns the loss entries of the reference's ContrastiveModel.forward dict."""
+    if group is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        group = dist.group.WORLD
+    if group is not None and dist.get_world_size(group) > 1:
+        cp = clip_loss(cell_embed, pert_embed, logit_scale_exp, symmetric=True, group=group)
+        ce = clip_loss(cell_embed, protein_embed, logit_scale_exp, symmetric=True, group=group)
+        pe = clip_loss(pert_embed, protein_embed, logit_scale_exp, symmetric=True, group=group)
+    else:
+        cp, ce, pe = TriModalLossFn.apply(cell_embed.contiguous(), pert_embed.contiguous(), protein_embed.contiguous(),
+                                          logit_scale_exp)
     return {"loss": cp + ce + pe, "cell_pert_loss": cp, "cell_protein_loss": ce, "pert_protein_loss": pe}

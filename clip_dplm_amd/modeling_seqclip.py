@@ -115,7 +115,18 @@ class ProteinRNACLIP(nn.Module):
         kernels of one tower (LayerNorm, attention, GEMM epilogues) overlap the MFMA-bound phases of the other, in the
         forward and — because autograd replays each node on its forward stream — in the backward."""
         if not (self.dual_stream and rna_values.is_cuda):
-            return self._embed_rna(rna_values, rna_mask), self._embed_protein(protein_ids, protein_mask)
+            nmb = max(1, int(self.micro_batches))
+            if nmb == 1:
+                return self._embed_rna(rna_values, rna_mask), self._embed_protein(protein_ids, protein_mask)
+            # samples are independent up to the loss: encode them in `micro_batches` chunks, so that a layer's
+            # activations (755 MB of qkv per ESM layer at B = 1024) fit the 256 MiB Infinity Cache between the
+            # kernel that writes them and the kernel that reads them
+            B = rna_values.shape[0]
+            cuts = [(i * B) // nmb for i in range(nmb + 1)]
+            sl = lambda t, i: None if t is None else t[cuts[i]:cuts[i + 1]]
+            er = torch.cat([self._embed_rna(sl(rna_values, i), sl(rna_mask, i)) for i in range(nmb)], 0)
+            ep = torch.cat([self._embed_protein(sl(protein_ids, i), sl(protein_mask, i)) for i in range(nmb)], 0)
+            return er, ep
         main = torch.cuda.current_stream()
         nmb = max(1, int(self.micro_batches))
         if self._streams is None or len(self._streams) != 2 * nmb:

@@ -25,16 +25,16 @@ class KernelTimer:
         self.only = None if only is None else set(only)    # restrict to these kernel names (two events per launch cost
                                                            # ~1 % of a training step when every launch is timed)
 
-    def add(self, name, s, e, work):
-        self.records.setdefault(name, []).append((s, e, work))
+    def add(self, name, s, e, work, nbytes=0.0):
+        self.records.setdefault(name, []).append((s, e, work, nbytes))
 
     def summary(self):
         """name -> dict(launches, total_ms, avg_us, work) — call after torch.cuda.synchronize()."""
         out = {}
         for name, recs in self.records.items():
-            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            ms = sum(r[0].elapsed_time(r[1]) for r in recs)
             out[name] = {"launches": len(recs), "total_ms": ms, "avg_us": 1e3 * ms / max(len(recs), 1),
-                         "work": float(sum(w for _, _, w in recs))}
+                         "work": float(sum(r[2] for r in recs)), "bytes": float(sum(r[3] for r in recs))}
         return out
 
 
@@ -46,14 +46,14 @@ def set_kernel_timer(t: Optional[KernelTimer]) -> None:
     _TIMER = t
 
 
-def _timed(name: str, work: float, fn):
+def _timed(name: str, work: float, fn, nbytes: float = 0.0):
     if _TIMER is None or (_TIMER.only is not None and name not in _TIMER.only):
         return fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     r = fn()
     e.record()
-    _TIMER.add(name, s, e, work)
+    _TIMER.add(name, s, e, work, nbytes)
     return r
 
 
@@ -133,7 +133,10 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
     else:
         args.residual, args.ldr, args.r_dtype = None, 0, 0
     args.alpha = alpha
-    check(_timed("gemm_nt", 2.0 * M * N * K, lambda: _lib().clipk_gemm_nt(C.byref(args), _stream())), "clipk_gemm_nt")
+    # algorithmic bytes: both operands once, every output / epilogue operand once
+    nb = 2.0 * (M * K + N * K) + M * N * (c.element_size() + (2 if out_preact else 0) + (2 if dact_aux is not None else 0)
+                                          + (residual.element_size() if residual is not None else 0))
+    check(_timed("gemm_nt", 2.0 * M * N * K, lambda: _lib().clipk_gemm_nt(C.byref(args), _stream()), nb), "clipk_gemm_nt")
     return (c, pre) if out_preact else c
 
 
@@ -193,6 +196,47 @@ def simce_grad(x, y, scale, lse_x, lse_y, w_row, w_col, inv_bg, label_offset=0, 
                                lse_x.data_ptr(), lse_y.data_ptr(), float(w_row), float(w_col), float(inv_bg),
                                dx.data_ptr(), dsc.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "clipk_simce_grad")
     return dx, dsc
+
+
+def _pairs_arrays(pairs):
+    flat = [int(v) for pr in pairs for v in pr]
+    rev = [pairs.index((b, a)) if (b, a) in pairs else i for i, (a, b) in enumerate(pairs)]
+    return (C.c_int * len(flat))(*flat), (C.c_int * len(rev))(*rev)
+
+
+def simce_lse_pairs(E, pairs, scale):
+    """E f32 [nmod, B, P]; pairs = [(x_mod, y_mod), ...] (<= 6).  One launch: lse, pos each [npairs, B]."""
+    _need_cuda(E, scale)
+    assert E.dtype == torch.float32 and E.dim() == 3 and E.is_contiguous()
+    nmod, B, P = E.shape
+    n = len(pairs)
+    pa, _ = _pairs_arrays(list(pairs))
+    lse = torch.empty((n, B), dtype=torch.float32, device=E.device)
+    pos = torch.zeros((n, B), dtype=torch.float32, device=E.device)
+    lib = _lib()
+    nbytes = lib.clipk_simce_pairs_workspace(n, B, P)
+    if nbytes == 0:
+        raise _ffi.ClipkError(f"simce pairs: unsupported shape npairs={n} B={B} P={P}")
+    ws = workspace(nbytes, E.device, "simce")
+    check(lib.clipk_simce_lse_pairs(E.data_ptr(), nmod, B, P, pa, n, scale.data_ptr(), lse.data_ptr(), pos.data_ptr(),
+                                    ws.data_ptr(), ws.numel(), _stream()), "clipk_simce_lse_pairs")
+    return lse, pos
+
+
+def simce_grad_pairs(E, pairs, scale, lse, w_row, w_col, inv_bg):
+    """Gradients of every directed problem w.r.t. its X rows: dX [npairs, B, P], dscale partials [npairs, B]."""
+    _need_cuda(E, scale, lse)
+    nmod, B, P = E.shape
+    n = len(pairs)
+    pa, ra = _pairs_arrays(list(pairs))
+    dX = torch.empty((n, B, P), dtype=torch.float32, device=E.device)
+    dsc = torch.empty((n, B), dtype=torch.float32, device=E.device)
+    lib = _lib()
+    ws = workspace(lib.clipk_simce_pairs_workspace(n, B, P), E.device, "simce")
+    check(lib.clipk_simce_grad_pairs(E.data_ptr(), nmod, B, P, pa, ra, n, scale.data_ptr(), lse.data_ptr(), float(w_row),
+                                     float(w_col), float(inv_bg), dX.data_ptr(), dsc.data_ptr(), ws.data_ptr(),
+                                     ws.numel(), _stream()), "clipk_simce_grad_pairs")
+    return dX, dsc
 
 
 def sim_logits(x, y, scale):

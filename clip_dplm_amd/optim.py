@@ -92,6 +92,9 @@ class FusedAdamW:
         self.group = group
         self.world = dist.get_world_size(group) if group is not None else 1
         self.rank = dist.get_rank(group) if group is not None else 0
+        # parameter order of module.parameters() (what torch.optim.AdamW(model.parameters()) would index): the flat
+        # buffer may store them in another order (fused qkv groups)
+        self.param_order = [p for p in module.parameters() if p.requires_grad]
         self.flat = FlatParams(module, self.world)
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
@@ -138,14 +141,89 @@ class FusedAdamW:
             KF.refresh_weight_caches()       # ... rebuild them in one launch (what is left is refreshed lazily)
         return self.norm_sq
 
+    # ---- checkpoint format: torch.optim.AdamW's, so optimizer_state of the reference's checkpoints
+    # (triple_flow/5_training.py:335-358: torch.save({'model_state', 'optimizer_state', ...})) is interchangeable in
+    # both directions.  Parameter indices follow module.parameters() order (what the reference hands its optimiser).
+    def _gathered_moments(self):
+        """Full-length (m, v) on every rank: the moments are sharded 1/W per rank (ZeRO-1)."""
+        if self.group is None or self.world == 1:
+            return self.m, self.v
+        if dist.get_backend(self.group) == "gloo":
+            full = [torch.zeros(self.flat.numel, dtype=torch.float32, device=self.m.device) for _ in range(2)]
+            lo = self.rank * self.shard
+            full[0][lo:lo + self.shard].copy_(self.m)
+            full[1][lo:lo + self.shard].copy_(self.v)
+            dist.all_reduce(full[0], group=self.group)
+            dist.all_reduce(full[1], group=self.group)
+            return full[0], full[1]
+        m = torch.empty(self.flat.numel, dtype=torch.float32, device=self.m.device)
+        v = torch.empty_like(m)
+        dist.all_gather_into_tensor(m, self.m, group=self.group)
+        dist.all_gather_into_tensor(v, self.v, group=self.group)
+        return m, v
+
     def state_dict(self):
-        return {"step": self.step_count, "m": self.m, "v": self.v, "lr": self.lr}
+        """torch.optim.AdamW.state_dict() layout: {'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [..]}
+        with cloned, full (un-sharded) per-parameter tensors — loadable by torch.optim.AdamW and by FusedAdamW at any
+        world size.  Collective when sharded: call on every rank."""
+        m, v = self._gathered_moments()
+        off = {id(p): o for p, o in zip(self.flat.params, self.flat.offsets)}
+        state = {}
+        for i, p in enumerate(self.param_order):
+            o = off[id(p)]
+            st = {}
+            if self.step_count > 0:                      # torch creates per-parameter state lazily at the first step
+                st = {"step": torch.tensor(float(self.step_count)),
+                      "exp_avg": m[o:o + p.numel()].view(p.shape).clone(),
+                      "exp_avg_sq": v[o:o + p.numel()].view(p.shape).clone()}
+            if st:
+                state[i] = st
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": True, "params": list(range(len(self.param_order)))}
+        if self.max_grad_norm is not None:
+            group["max_grad_norm"] = self.max_grad_norm  # extra key (the clip is folded into the step); torch ignores it
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd["step"])
-        self.m.copy_(sd["m"])
-        self.v.copy_(sd["v"])
-        self.lr = sd.get("lr", self.lr)
+        """Accepts torch.optim.AdamW.state_dict() (and what state_dict() above returns); the legacy
+        {'step', 'm', 'v'} flat format of round 1 is still read when world size matches."""
+        if "param_groups" not in sd:                     # legacy private format
+            self.step_count = int(sd["step"])
+            self.m.copy_(sd["m"])
+            self.v.copy_(sd["v"])
+            self.lr = sd.get("lr", self.lr)
+            return
+        g = sd["param_groups"][0]
+        if len(sd["param_groups"]) != 1 or len(g["params"]) != len(self.param_order):
+            raise ValueError(f"optimizer state has {len(g['params'])} parameters in {len(sd['param_groups'])} group(s); "
+                             f"this model has {len(self.param_order)} in one group")
+        if g.get("amsgrad") or g.get("maximize"):
+            raise ValueError("amsgrad / maximize states are not supported by the fused AdamW step")
+        self.lr = float(g["lr"])
+        self.betas = tuple(g["betas"])
+        self.eps = float(g["eps"])
+        self.wd = float(g["weight_decay"])
+        off = {id(p): o for p, o in zip(self.flat.params, self.flat.offsets)}
+        lo, hi = self.rank * self.shard, (self.rank + 1) * self.shard
+        steps = set()
+        self.m.zero_()
+        self.v.zero_()
+        for i, p in enumerate(self.param_order):
+            st = sd["state"].get(g["params"][i])
+            if not st:
+                continue
+            steps.add(int(round(float(st["step"]))))
+            o, n = off[id(p)], p.numel()
+            a, b = max(o, lo), min(o + n, hi)            # the part of this parameter that lives in this rank's shard
+            if a >= b:
+                continue
+            for dst, key in ((self.m, "exp_avg"), (self.v, "exp_avg_sq")):
+                src = st[key].reshape(-1).to(device=dst.device, dtype=torch.float32)
+                dst[a - lo:b - lo].copy_(src[a - o:b - o])
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): the fused step keeps one counter")
+        self.step_count = steps.pop() if steps else 0
 
 
 def cosine_annealing_lr(base_lr: float, epoch: int, t_max: int = 20, eta_min: float = 0.0) -> float:

@@ -121,6 +121,22 @@ int clipk_simce_grad(const float* X, int Mx, const float* Y, int Ny, const float
                      float* dX /*[Mx,P]*/, float* dscale_partial /*[Mx]*/,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* Batched form for several same-shape contrastive problems on one logit scale — the tri-modal ContrastiveModel of
+ * current/tf_clip_codes (1).ipynb:13150-13163 (cell x pert, cell x protein, pert x protein, each symmetric) is six
+ * directed problems (X = E[pairs[2i]], Y = E[pairs[2i+1]]), computed by ONE launch per pass (grid z = problem):
+ *   lse_pairs : lse[i][b] = LSE_j scale <X_b, Y_j>, pos[i][b] = scale <X_b, Y_b>
+ *   grad_pairs: dX[i] = complete gradient of (w_row CE_rows + w_col CE_cols)(X, Y) * inv_bg w.r.t. the rows of X,
+ *               using lse[i] for the rows and lse[reverse[i]] (the problem with X and Y exchanged) for the keys.
+ * E: f32 [nmod][B][P] contiguous; pairs / reverse: HOST int arrays; npairs <= 6. */
+size_t clipk_simce_pairs_workspace(int npairs, int B, int P);
+int clipk_simce_lse_pairs(const float* E, int nmod, int B, int P, const int* pairs, int npairs, const float* scale,
+                          float* lse /*[npairs][B]*/, float* pos /*[npairs][B]*/, void* workspace,
+                          size_t workspace_bytes, void* stream);
+int clipk_simce_grad_pairs(const float* E, int nmod, int B, int P, const int* pairs, const int* reverse, int npairs,
+                           const float* scale, const float* lse /*[npairs][B]*/, float w_row, float w_col,
+                           float inv_bg, float* dX /*[npairs][B][P]*/, float* dscale_partial /*[npairs][B]*/,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* Materialised logits for the drop-in module API (old/clip.py:67 returns them):
  *   S[Mx,Ny] = scale * X·Y^T, exact f32. */
 int clipk_sim_logits(const float* X, int Mx, const float* Y, int Ny, int P, const float* scale,

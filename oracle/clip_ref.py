@@ -100,3 +100,12 @@ def optimized_clip_loss(outputs):
     s = outputs["logits_per_diffmap_protein"]
     comb = torch.cat([s, outputs["logits_per_diffmap_cache"]], dim=1) if "logits_per_diffmap_cache" in outputs else s
     return 0.5 * (ce_diag(comb) + ce_diag(s.t()))
+
+
+def tri_modal_losses(cell_embed, pert_embed, protein_embed, logit_scale):
+    """current/tf_clip_codes (1).ipynb:13143-13165: three pairwise symmetric CE losses on one logit_scale."""
+    s = logit_scale.exp()
+    cp = clip_loss_symmetric((cell_embed @ pert_embed.t()) * s)
+    ce = clip_loss_symmetric((cell_embed @ protein_embed.t()) * s)
+    pe = clip_loss_symmetric((pert_embed @ protein_embed.t()) * s)
+    return cp + ce + pe, cp, ce, pe

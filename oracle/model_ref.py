@@ -28,3 +28,28 @@ def protein_rna_clip_loss(sd: SD, rna_values, protein_ids, rna_mask, protein_mas
     logits = (er @ ep.t()) * sd["logit_scale"].exp()
     loss = clip_ref.clip_loss_symmetric(logits) if symmetric else clip_ref.ce_diag(logits)
     return loss, er, ep
+
+
+def contrastive_model_forward(sd: SD, cell_state, connectivity, gene_esm_embeddings, gene_values, protein_emb):
+    """ContrastiveModel.forward of current/tf_clip_codes (1).ipynb:13113-13176 with the state_dict keys of that class.
+    Encoders: CellStateEncoder :13074-13089 (MLP, then the post-LN stack over the B cells as ONE unbatched sequence with
+    isolated cells masked as keys), PerturbationEncoder :13091-13111 (esm_projection + value_encoder, then the stack with
+    attention over the batch axis per gene position, App. A-8), TransformerEncoder on the 2-D protein embeddings.
+    `[:, 0]` is applied to 3-D encoder outputs only: on the 2-D ones it is the upstream defect A-19 (never executed)."""
+    h = cell_state @ sd["cell_encoder.encoder.0.weight"].t() + sd["cell_encoder.encoder.0.bias"]
+    h = clip_ref._gelu(clip_ref._ln(h, sd, "cell_encoder.encoder.1", 1e-5))
+    h = clip_ref._linear(h, sd, "cell_encoder.encoder.3")
+    keys_ok = ~(connectivity.sum(-1) == 0)                                            # [B]
+    cell_enc = encoder_ref.post_ln_encoder(h[None], sd, "cell_encoder.graph_encoder", 3, 8, keys_ok[None], "relu",
+                                           1e-5, 1e-5)[0]
+    x = clip_ref._linear(gene_esm_embeddings, sd, "pert_encoder.esm_projection") + \
+        clip_ref._linear(gene_values.unsqueeze(-1), sd, "pert_encoder.value_encoder")
+    pert_enc = encoder_ref.post_ln_encoder(x.transpose(0, 1), sd, "pert_encoder.transformer", 3, 8, None, "relu",
+                                           1e-5, 1e-5).transpose(0, 1)[:, 0]
+    prot_enc = encoder_ref.post_ln_encoder(protein_emb[None], sd, "protein_encoder", 3, 8, None, "relu", 1e-5, 1e-5)[0]
+    ce = clip_ref.l2_normalize(clip_ref.optimized_projection_head(cell_enc, sd, "cell_projection"))
+    pe = clip_ref.l2_normalize(clip_ref.optimized_projection_head(pert_enc, sd, "pert_projection"))
+    pr = clip_ref.l2_normalize(clip_ref.optimized_projection_head(prot_enc, sd, "protein_projection"))
+    total, cp, cpr, ppr = clip_ref.tri_modal_losses(ce, pe, pr, sd["logit_scale"])
+    return {"cell_embed": ce, "pert_embed": pe, "protein_embed": pr, "loss": total, "cell_pert_loss": cp,
+            "cell_protein_loss": cpr, "pert_protein_loss": ppr}

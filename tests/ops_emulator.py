@@ -97,6 +97,20 @@ def simce_grad(x, y, scale, lse_x, lse_y, w_row, w_col, inv_bg, label_offset=0, 
     return dx.float(), dsc.float()
 
 
+def simce_lse_pairs(E, pairs, scale):
+    out = [simce_lse(E[a], E[b], scale) for a, b in pairs]
+    return torch.stack([o[0] for o in out]), torch.stack([o[1] for o in out])
+
+
+def simce_grad_pairs(E, pairs, scale, lse, w_row, w_col, inv_bg):
+    pairs = list(pairs)
+    out = []
+    for i, (a, b) in enumerate(pairs):
+        r = pairs.index((b, a))
+        out.append(simce_grad(E[a], E[b], scale, lse[i], lse[r], w_row, w_col, inv_bg))
+    return torch.stack([o[0] for o in out]), torch.stack([o[1] for o in out])
+
+
 def gemm_f32_nt(x, w, bias=None, addend=None, addend_scale=None):
     out = x @ w.t()
     if bias is not None:

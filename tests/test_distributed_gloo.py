@@ -75,6 +75,7 @@ def _worker(rank, world, initfile, results):
             opt.step()
         out["params"] = {n: p.detach().clone() for n, p in m.named_parameters()}
         out["train_loss"] = l.item()
+        out["opt_state"] = opt.state_dict()                    # collective: gathers the sharded moments
         # ---- (4) the benchmark model in small: ESM stack (zero-copy fused qkv views of the sharded flat buffer,
         # pre-rotated q / k, weight gradients written straight into .grad) + post-LN stack, two sharded steps
         from clip_dplm_amd.encoders import ESM2_SHAPES
@@ -145,10 +146,18 @@ def test_world2_matches_single_process():
         l = m.loss(xa, xb, symmetric=True)
         l.backward()
         opt.step()
+    ref_state = opt.state_dict()
     for r in range(world):
         assert abs(res[r]["train_loss"] - l.item()) < 1e-5
         for n, p in m.named_parameters():
             assert torch.allclose(res[r]["params"][n], p, rtol=1e-4, atol=1e-6), (r, n)
+        # the sharded optimiser's checkpoint holds the FULL moments on every rank, in torch.optim.AdamW's layout
+        st = res[r]["opt_state"]
+        assert st["param_groups"][0]["params"] == ref_state["param_groups"][0]["params"]
+        for i, ent in ref_state["state"].items():
+            assert float(st["state"][i]["step"]) == float(ent["step"]) == 2.0
+            assert torch.allclose(st["state"][i]["exp_avg"], ent["exp_avg"], rtol=1e-4, atol=1e-7), (r, i)
+            assert torch.allclose(st["state"][i]["exp_avg_sq"], ent["exp_avg_sq"], rtol=1e-4, atol=1e-9), (r, i)
     # (4) ProteinRNACLIP, sharded vs single process on the concatenated batch
     from clip_dplm_amd.encoders import ESM2_SHAPES
     ESM2_SHAPES["test_tiny"] = (2, 96, 4, 384)

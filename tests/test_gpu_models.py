@@ -516,3 +516,57 @@ def test_load_state_dict_after_forward_refreshes_fused_qkv_copies(dev):
     opt2.zero_grad()
     l2 = fresh.loss(rna, ids)
     assert torch.equal(l1, l2), (l1.item(), l2.item())
+
+
+def test_trimodal_contrastive_model_golden(dev):
+    """ContrastiveModel (current/tf_clip_codes (1).ipynb:13113-13176) with the reference's state_dict,
+    against the fixture built from the reference's own sub-modules and loss expressions (tools/make_golden.py
+    gen_trimodal; `[:, 0]` on the 2-D encoder outputs is upstream defect A-19).  Embeddings at bf16-GEMM level, the
+    three pairwise losses and their sum at the loss bar; the batched loss kernels' gradients reach every parameter."""
+    import clip_dplm_amd as K
+    z, sd = load("trimodal_model.npz")
+    m = K.ContrastiveModel(21, 64, projection_dim=64, esm_dim=40)
+    m.load_state_dict(sd)                                  # reference keys load as they are
+    m = m.to(dev).eval()
+    out = m(t(z, "cell_state", dev), t(z, "connectivity", dev), t(z, "gene_esm", dev), t(z, "gene_values", dev),
+            t(z, "protein_emb", dev))
+    assert set(out) == {"cell_embed", "pert_embed", "protein_embed", "loss", "cell_pert_loss", "cell_protein_loss",
+                        "pert_protein_loss"}
+    for k in ("cell_embed", "pert_embed", "protein_embed"):
+        err = (out[k].cpu() - t(z, k)).abs().max().item()
+        assert err < 0.03, (k, err)
+    for k in ("cell_pert_loss", "cell_protein_loss", "pert_protein_loss", "loss"):
+        assert abs(out[k].item() - float(z[k])) < 2e-2, (k, out[k].item(), float(z[k]))   # B = 16: one row = 1/16 of the mean
+    out["loss"].backward()
+    missing = [n for n, p in m.named_parameters() if p.grad is None]
+    assert not missing, missing
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_trimodal_loss_pairs_kernels_vs_f64(dev):
+    """loss.tri_modal_loss (six directed problems in one launch per pass) against f64 torch: the three losses, and
+    the gradients w.r.t. the three embedding matrices and the scale under unequal upstream weights."""
+    from clip_dplm_amd.loss import tri_modal_loss
+    B, P = 192, 128
+    g = torch.Generator().manual_seed(2)
+    E = [torch.nn.functional.normalize(torch.randn(B, P, generator=g), dim=-1).to(dev).requires_grad_(True)
+         for _ in range(3)]
+    ls = torch.tensor(2.6592, device=dev, requires_grad=True)
+    out = tri_modal_loss(E[0], E[1], E[2], ls.exp())
+    w = (1.0, 0.3, 2.0)
+    (w[0] * out["cell_pert_loss"] + w[1] * out["cell_protein_loss"] + w[2] * out["pert_protein_loss"]).backward()
+    Ed = [e.detach().double().requires_grad_(True) for e in E]
+    lsd = ls.detach().double().requires_grad_(True)
+    lab = torch.arange(B, device=dev)
+
+    def sym(a, b):
+        S = (a @ b.t()) * lsd.exp()
+        return 0.5 * (torch.nn.functional.cross_entropy(S, lab) + torch.nn.functional.cross_entropy(S.t(), lab))
+    ref = (sym(Ed[0], Ed[1]), sym(Ed[0], Ed[2]), sym(Ed[1], Ed[2]))
+    (w[0] * ref[0] + w[1] * ref[1] + w[2] * ref[2]).backward()
+    for k, r in zip(("cell_pert_loss", "cell_protein_loss", "pert_protein_loss"), ref):
+        assert abs(out[k].item() - r.item()) < 1e-5
+    assert abs(out["loss"].item() - sum(r.item() for r in ref)) < 2e-5
+    for e, ed in zip(E, Ed):
+        assert torch.allclose(e.grad.double(), ed.grad, rtol=1e-4, atol=1e-7), (e.grad.double() - ed.grad).abs().max()
+    assert abs(ls.grad.item() - lsd.grad.item()) < 1e-5 * max(1.0, abs(lsd.grad.item()))

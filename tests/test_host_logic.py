@@ -210,3 +210,97 @@ def test_bench_launches_its_own_ranks():
     assert r.returncode != 0
     assert "starting 2 ranks" in r.stderr
     assert r.stderr.count("needs an MI355X") >= 2, r.stderr[-2000:]
+
+
+def _small_clip(K):
+    cfg = NS(rna_config=sub(32), protein_config=sub(32), diffmap_config=sub(32), projection_dim=16,
+             logit_scale_init_value=2.6592)
+    m = K.RNAProteinCLIPModule(cfg)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    return m
+
+
+def test_fused_adamw_state_dict_is_torch_adamw_state_dict(monkeypatch, tmp_path):
+    """SURVEY §8f-2 / ADVICE r01: FusedAdamW.state_dict() is torch.optim.AdamW's format — the `optimizer_state` of the
+    reference's checkpoints (triple_flow/5_training.py:335-358) — in BOTH directions, and the reference's checkpoint
+    dict round-trips through torch.save / torch.load(weights_only=True)."""
+    ops_emulator.install(monkeypatch)
+    import clip_dplm_amd as K
+    torch.manual_seed(0)
+    m, ref = _small_clip(K), _small_clip(K)
+    ref.load_state_dict(m.state_dict())
+    opt = K.FusedAdamW(m, lr=1e-3, weight_decay=0.01, max_grad_norm=1.0)
+    topt = torch.optim.AdamW(ref.parameters(), lr=1e-3, weight_decay=0.01)
+    g = torch.Generator().manual_seed(1)
+    a, b = torch.randn(16, 32, generator=g), torch.randn(16, 32, generator=g)
+
+    def fstep(mm, oo):
+        oo.zero_grad(); mm.loss(a, b, symmetric=True).backward(); oo.step()
+
+    def tstep(mm, oo):
+        oo.zero_grad(); mm.loss(a, b, symmetric=True).backward()
+        torch.nn.utils.clip_grad_norm_(mm.parameters(), 1.0); oo.step()
+    for _ in range(3):
+        fstep(m, opt); tstep(ref, topt)
+    fs, ts = opt.state_dict(), topt.state_dict()
+    assert set(fs) == {"state", "param_groups"} and fs["param_groups"][0]["params"] == ts["param_groups"][0]["params"]
+    for i, ent in ts["state"].items():
+        assert float(fs["state"][i]["step"]) == float(ent["step"])
+        assert fs["state"][i]["exp_avg"].shape == ent["exp_avg"].shape
+        assert torch.allclose(fs["state"][i]["exp_avg"], ent["exp_avg"], rtol=1e-4, atol=1e-7), i
+        assert torch.allclose(fs["state"][i]["exp_avg_sq"], ent["exp_avg_sq"], rtol=1e-4, atol=1e-9), i
+    # torch -> fused: a NEW fused optimiser resumes from torch's state and stays on torch's trajectory
+    m2 = _small_clip(K)
+    m2.load_state_dict(ref.state_dict())
+    opt2 = K.FusedAdamW(m2, lr=5e-4, weight_decay=0.0, max_grad_norm=1.0)
+    opt2.load_state_dict(ts)
+    assert opt2.step_count == 3 and opt2.lr == 1e-3 and opt2.wd == 0.01
+    fstep(m2, opt2); tstep(ref, topt)
+    for (n, p), (_, q) in zip(m2.named_parameters(), ref.named_parameters()):
+        assert torch.allclose(p, q, rtol=1e-4, atol=1e-5), n
+    # fused -> torch: torch.optim.AdamW accepts the fused optimiser's state
+    ref2 = _small_clip(K)
+    ref2.load_state_dict(m.state_dict())
+    topt2 = torch.optim.AdamW(ref2.parameters(), lr=1e-3, weight_decay=0.01)
+    topt2.load_state_dict(fs)
+    fstep(m, opt); tstep(ref2, topt2)
+    for (n, p), (_, q) in zip(m.named_parameters(), ref2.named_parameters()):
+        assert torch.allclose(p, q, rtol=1e-4, atol=1e-5), n
+    # the reference's checkpoint dict, through torch.save / weights_only load
+    sched = K.CosineAnnealingLR(opt, T_max=20)
+    sched.step()
+    path = tmp_path / "ckpt.pt"
+    K.save_checkpoint(path, m, opt, sched, training_state={"epoch": 2, "step": 4, "best_val_loss": 1.5},
+                      config={"learning_rate": 1e-3})
+    raw = torch.load(path, weights_only=True)
+    assert set(raw) == {"model_state", "optimizer_state", "scheduler_state", "training_state", "config"}
+    m3 = _small_clip(K)
+    opt3 = K.FusedAdamW(m3, lr=1.0)
+    sched3 = K.CosineAnnealingLR(opt3, T_max=5)
+    ck = K.load_checkpoint(path, m3, opt3, sched3)
+    assert ck["training_state"]["epoch"] == 2 and opt3.step_count == opt.step_count
+    assert sched3.last_epoch == sched.last_epoch and abs(opt3.lr - opt.lr) < 1e-12
+    for (n, p), (_, q) in zip(m3.named_parameters(), m.named_parameters()):
+        assert torch.equal(p, q), n
+
+
+def test_cosine_schedule_and_early_stopping_match_the_reference_loop():
+    """CosineAnnealingLR == torch.optim.lr_scheduler.CosineAnnealingLR(T_max=20) (rna_clip_codes.ipynb:2034);
+    EarlyStopping follows rna_clip_codes.ipynb:2002-2027 call by call."""
+    import clip_dplm_amd as K
+    p = torch.nn.Parameter(torch.zeros(3))
+    topt = torch.optim.AdamW([p], lr=1e-4)
+    tsch = torch.optim.lr_scheduler.CosineAnnealingLR(topt, T_max=20)
+    holder = NS(lr=1e-4)
+    sch = K.CosineAnnealingLR(holder, T_max=20)
+    for _ in range(45):                                      # past T_max: the cosine keeps going, as torch's does
+        assert abs(sch.get_last_lr()[0] - tsch.get_last_lr()[0]) < 1e-12
+        assert abs(holder.lr - topt.param_groups[0]["lr"]) < 1e-12
+        topt.step(); tsch.step(); sch.step()
+    es = K.EarlyStopping(patience=2, min_delta=0.0)
+    seq = [(1.0, False, False), (0.9, True, False), (0.95, False, False), (0.91, False, True)]
+    for loss, ret, stop in seq:
+        assert es(loss) is ret and es.early_stop is stop
+    assert es.best_loss == 0.9 and es.counter == 2

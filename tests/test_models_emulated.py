@@ -24,6 +24,8 @@ CASES = [
     ("icnn_noln", T.test_icnn_without_layer_norm_golden, {}),
     ("icnn_train_ragged", T.test_icnn_training_large_ragged_batch_vs_oracle, {}),
     ("esm_proj", T.test_esm_projections_golden, {}),
+    ("trimodal", T.test_trimodal_contrastive_model_golden, {}),
+    ("trimodal_loss", T.test_trimodal_loss_pairs_kernels_vs_f64, {}),
 ]
 
 

@@ -174,3 +174,18 @@ def test_icnn_transport_maps():
     s = encoder_ref._ln(t(z, "cell"), sd, "cell_to_pert.input_norm", 1e-5)
     psi = icnn_ref.icnn_potential(s, sd, "cell_to_pert.transport_net", 3)
     assert torch.allclose(psi, t(z, "psi_cell_to_pert"), atol=2e-5)
+
+
+def test_trimodal_oracle_vs_reference_fixture():
+    """oracle.model_ref.contrastive_model_forward vs the fixture generated from the reference's tri-modal classes
+    (current/tf_clip_codes (1).ipynb cell 41, tools/make_golden.py gen_trimodal)."""
+    from oracle import model_ref
+    z = np.load(os.path.join(G, "trimodal_model.npz"))
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}
+    tt = lambda k: torch.from_numpy(z[k])
+    o = model_ref.contrastive_model_forward(sd, tt("cell_state"), tt("connectivity"), tt("gene_esm"), tt("gene_values"),
+                                            tt("protein_emb"))
+    for k in ("cell_embed", "pert_embed", "protein_embed"):
+        assert (o[k] - tt(k)).abs().max().item() < 3e-5, k
+    for k in ("cell_pert_loss", "cell_protein_loss", "pert_protein_loss", "loss"):
+        assert abs(o[k].item() - float(z[k])) < 3e-5, k

@@ -154,6 +154,54 @@ def gen_notebook():
          loss=loss.item(), **sd_np(model))
 
 
+def gen_trimodal():
+    """Tri-modal ContrastiveModel, current/tf_clip_codes (1).ipynb cell 41 (:13026-13176).  The cell was never executed
+    upstream and its forward cannot run on the documented 2-D inputs (`cell_enc[:, 0]` of a [B, E] tensor is a [B]
+    vector: defect A-19), so the fixture is built from the reference's OWN sub-modules, each called as the forward calls
+    it, with `[:, 0]` applied to the 3-D perturbation output only, and the reference's own loss expressions."""
+    from oracle import model_ref
+    nb = json.load(open(REF + "/current/tf_clip_codes (1).ipynb"))
+    cell = next(c for c in nb["cells"] if "class ContrastiveModel" in "".join(c["source"]))
+    src = "".join(cell["source"])
+    src = src[:src.index("# Helper function to get ESM embeddings")]          # model classes only
+    ns = {}
+    exec(src, ns)
+    torch.manual_seed(0)
+    gene_dim, protein_dim, P, esm_dim, B, G = 21, 64, 64, 40, 16, 5
+    m = ns["ContrastiveModel"](gene_dim, protein_dim, projection_dim=P, esm_dim=esm_dim).eval()
+    with torch.no_grad():                                   # move layer_scale off its 1e-4 init so the MLP branch counts
+        for h in (m.cell_projection, m.pert_projection, m.protein_projection):
+            h.layer_scale.fill_(0.5)
+    g = torch.Generator().manual_seed(11)
+    cell_state = torch.randn(B, gene_dim + 1, generator=g)
+    conn = (torch.rand(B, B, generator=g) > 0.6).float()
+    conn[3] = 0; conn[9] = 0                                 # two isolated cells: masked as attention keys
+    gene_esm = torch.randn(B, G, esm_dim, generator=g)
+    gene_values = torch.randn(B, G, generator=g)
+    protein_emb = torch.randn(B, protein_dim, generator=g)
+    with torch.no_grad():
+        cell_enc = m.cell_encoder(cell_state, conn)          # [B, P]
+        pert_enc = m.pert_encoder(gene_esm, gene_values)     # [B, G, P]
+        prot_enc = m.protein_encoder(protein_emb)            # [B, protein_dim]
+        ce = F.normalize(m.cell_projection(cell_enc), dim=-1)
+        pe = F.normalize(m.pert_projection(pert_enc[:, 0]), dim=-1)
+        pr = F.normalize(m.protein_projection(prot_enc), dim=-1)
+        ls = m.logit_scale.exp()
+        lab = torch.arange(B)
+        sym = lambda a, b: (F.cross_entropy((a @ b.t()) * ls, lab) + F.cross_entropy(((a @ b.t()) * ls).t(), lab)) / 2
+        cp, cpr, ppr = sym(ce, pe), sym(ce, pr), sym(pe, pr)
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    o = model_ref.contrastive_model_forward(sd, cell_state, conn, gene_esm, gene_values, protein_emb)
+    check("trimodal cell embed", o["cell_embed"], ce, 3e-5)
+    check("trimodal pert embed", o["pert_embed"], pe, 3e-5)
+    check("trimodal protein embed", o["protein_embed"], pr, 3e-5)
+    check("trimodal loss", o["loss"], cp + cpr + ppr, 3e-5)
+    save("trimodal_model.npz", cell_state=cell_state.numpy(), connectivity=conn.numpy(), gene_esm=gene_esm.numpy(),
+         gene_values=gene_values.numpy(), protein_emb=protein_emb.numpy(), cell_embed=ce.numpy(), pert_embed=pe.numpy(),
+         protein_embed=pr.numpy(), cell_pert_loss=cp.item(), cell_protein_loss=cpr.item(), pert_protein_loss=ppr.item(),
+         loss=(cp + cpr + ppr).item(), **sd_np(m))
+
+
 # ------------------------------------------------------------------------------------------------ torch layer
 def gen_tlayer():
     torch.manual_seed(0)
@@ -368,6 +416,7 @@ if __name__ == "__main__":
     rc = gen_clip_c1()
     gen_clip_opt(rc)
     gen_notebook()
+    gen_trimodal()
     gen_tlayer()
     gen_esm()
     gen_icnn()
