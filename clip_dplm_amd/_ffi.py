@@ -80,11 +80,15 @@ SIGNATURES = {
     "clipk_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "clipk_rope_qk": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "clipk_attn_fwd_rot": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "clipk_attn_varlen_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "clipk_attn_varlen_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "clipk_embed_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     "clipk_embed_bwd_workspace": (_sz, [_i, _i, _i, _i]),
     "clipk_embed_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "clipk_pool_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "clipk_pool_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "clipk_pool_varlen_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "clipk_pool_varlen_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "clipk_sumsq_workspace": (_sz, [_i64]),
     "clipk_sumsq": (_i, [_vp, _i64, _vp, _vp, _sz, _vp]),
     "clipk_adamw_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp]),

@@ -42,7 +42,25 @@ struct AP {
   float scale;
   int pre_rot;      // backward: q / k in `qkv` are already rotated (clipk_rope_qk): stage them as they are, the
                     // gradients still leave through RoPE^T
+  // packed variable-length batches (current/rna_clip_codes.ipynb:1726-1736: sequences of 30..2542 tokens): sequence b
+  // occupies token rows [cu[b], cu[b+1]) of the packed [T, ...] tensors, L is the LONGEST sequence (grid sizing only),
+  // the per-row statistics (lse, delta) are [H][T].  cu == nullptr: the padded [B, L] layout.
+  const int* cu; int T;
 };
+
+// first token row and length of sequence b (L comes in as p.L)
+__device__ __forceinline__ long seq_rows(const AP& p, int b, int& L) {
+  if (p.cu) {
+    const int s = p.cu[b];
+    L = p.cu[b + 1] - s;
+    return s;
+  }
+  return (long)b * L;
+}
+// index of row r of (sequence b, head h) in the lse / delta arrays
+__device__ __forceinline__ long stat_at(const AP& p, int b, int h, int H, int L, long row0, int r) {
+  return p.cu ? (long)h * p.T + row0 + r : ((long)b * H + h) * L + r;
+}
 
 constexpr float LOG2E = 1.4426950408889634f;
 
@@ -282,12 +300,15 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_FWD) void attn_fwd_kernel(const AP
   const int g = lane >> 4, li = lane & 15;
   // the head dim as a compile-time constant whenever the dispatcher knows it (DX): the `dt < dtv` guards of the
   // d-tile loops fold away - as run-time branches they pushed the dK / dV accumulators through scratch memory
-  const int D = DX > 0 ? DX : p.D, L = p.L, H = p.H;
+  const int D = DX > 0 ? DX : p.D, H = p.H;
+  int L = p.L;                                          // grid: the longest sequence; below: this sequence
   int qb, h, b;
   work_item((L + 127) / 128, H, p.B, qb, h, b);
+  const long row0 = seq_rows(p, b, L);
+  if (qb * 128 >= L) return;                              // packed batches: query block beyond this sequence
   const int cpr = D >> 3;
   const long tokstride = 3L * H * D;
-  const unsigned short* qbase = p.qkv + (long)b * L * tokstride + (long)h * D;
+  const unsigned short* qbase = p.qkv + row0 * tokstride + (long)h * D;
   const unsigned short* kbase = qbase + (long)H * D;
   const unsigned short* vbase = qbase + 2L * H * D;
   const int q0 = qb * 128;
@@ -321,7 +342,7 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_FWD) void attn_fwd_kernel(const AP
     for (int ks = 0; ks < KS; ++ks) qf[qt][ks] = row_frag(smem, RS, wid * 32 + qt * 16 + li, ks, lane);
   __syncthreads();
   kv.store(ktile, vtile, RS, p, L, true);
-  if (tid < KVB) mask_l[tid] = (tid < L && (!p.key_mask || p.key_mask[(long)b * L + tid])) ? 1 : 0;
+  if (tid < KVB) mask_l[tid] = (tid < L && (!p.key_mask || p.key_mask[row0 + tid])) ? 1 : 0;
   __syncthreads();
 
   f32x4 o[DT][2];
@@ -409,7 +430,7 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_FWD) void attn_fwd_kernel(const AP
       kv.store(ktile, vtile, RS, p, L, true);
       if (tid < KVB) {
         const int pos = (kb + 1) * KVB + tid;
-        mask_l[tid] = (pos < L && (!p.key_mask || p.key_mask[(long)b * L + pos])) ? 1 : 0;
+        mask_l[tid] = (pos < L && (!p.key_mask || p.key_mask[row0 + pos])) ? 1 : 0;
       }
       __syncthreads();
     }
@@ -421,8 +442,8 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_FWD) void attn_fwd_kernel(const AP
     const float inv = lt > 0.f ? 1.0f / lt : 0.f;
     const int q = q0 + wid * 32 + qt * 16 + li;
     if (q < L) {
-      if (g == 0) p.lse[((long)b * H + h) * L + q] = lt > 0.f ? m_run[qt] * p.scale + logf(lt) : -INFINITY;
-      unsigned short* orow = p.out + ((long)b * L + q) * ((long)H * D) + (long)h * D;
+      if (g == 0) p.lse[stat_at(p, b, h, H, L, row0, q)] = lt > 0.f ? m_run[qt] * p.scale + logf(lt) : -INFINITY;
+      unsigned short* orow = p.out + (row0 + q) * ((long)H * D) + (long)h * D;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         const int d = dt * 16 + 4 * g;
@@ -524,16 +545,19 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dq_kernel(const
   const int g = lane >> 4, li = lane & 15;
   // the head dim as a compile-time constant whenever the dispatcher knows it (DX): the `dt < dtv` guards of the
   // d-tile loops fold away - as run-time branches they pushed the dK / dV accumulators through scratch memory
-  const int D = DX > 0 ? DX : p.D, L = p.L, H = p.H;
+  const int D = DX > 0 ? DX : p.D, H = p.H;
+  int L = p.L;                                          // grid: the longest sequence; below: this sequence
   int qb, h, b;
   work_item((L + 127) / 128, H, p.B, qb, h, b);
+  const long row0 = seq_rows(p, b, L);
+  if (qb * 128 >= L) return;                              // packed batches: query block beyond this sequence
   const int cpr = D >> 3;
   const long tokstride = 3L * H * D, ostride = (long)H * D;
-  const unsigned short* qbase = p.qkv + (long)b * L * tokstride + (long)h * D;
+  const unsigned short* qbase = p.qkv + row0 * tokstride + (long)h * D;
   const unsigned short* kbase = qbase + (long)H * D;
   const unsigned short* vbase = qbase + 2L * H * D;
-  const unsigned short* dobase = p.dout + (long)b * L * ostride + (long)h * D;
-  const unsigned short* obase = p.out + (long)b * L * ostride + (long)h * D;
+  const unsigned short* dobase = p.dout + row0 * ostride + (long)h * D;
+  const unsigned short* obase = p.out + row0 * ostride + (long)h * D;
   const int q0 = qb * 128;
   const int dtv = (D + 15) >> 4;
   const float c2 = p.scale * LOG2E;
@@ -569,7 +593,7 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dq_kernel(const
 #pragma unroll
       for (int c = 0; c < NCH; ++c) acc += part[tid * NCH + c];
       delta_l[tid] = acc;
-      if (q0 + tid < L) p.delta[((long)b * H + h) * L + q0 + tid] = acc;
+      if (q0 + tid < L) p.delta[stat_at(p, b, h, H, L, row0, q0 + tid)] = acc;
     }
   } else {
     // row owner (rows are rotated in registers): Q rows on threads 0..127, dO rows on threads 128..255, which also
@@ -590,7 +614,7 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dq_kernel(const
           acc += bf16_to_f32(ro.c[i][e] >> 16) * bf16_to_f32(qd.r.c[i][e] >> 16);
         }
       delta_l[qd.row] = acc;
-      if (qd.pos < L) p.delta[((long)b * H + h) * L + qd.pos] = acc;
+      if (qd.pos < L) p.delta[stat_at(p, b, h, H, L, row0, qd.pos)] = acc;
     }
     qd.store(smem, smem + 128 * RS, RS, p, L, true);
     kv.load(kbase, tokstride, vbase, tokstride, 0, L, cpr);
@@ -608,12 +632,12 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dq_kernel(const
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     int q = q0 + wid * 32 + qt * 16 + li; q = q < L ? q : L - 1;
-    lse2[qt] = p.lse[((long)b * H + h) * L + q] * LOG2E;
+    lse2[qt] = p.lse[stat_at(p, b, h, H, L, row0, q)] * LOG2E;
     dl[qt] = delta_l[wid * 32 + qt * 16 + li];
   }
   __syncthreads();
   kv.store(ktile, vtile, RS, p, L, true);
-  if (tid < KVB) mask_l[tid] = (tid < L && (!p.key_mask || p.key_mask[(long)b * L + tid])) ? 1 : 0;
+  if (tid < KVB) mask_l[tid] = (tid < L && (!p.key_mask || p.key_mask[row0 + tid])) ? 1 : 0;
   __syncthreads();
 
   f32x4 dq[DT][2];
@@ -686,7 +710,7 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dq_kernel(const
       kv.store(ktile, vtile, RS, p, L, true);
       if (tid < KVB) {
         const int pos = (kb + 1) * KVB + tid;
-        mask_l[tid] = (pos < L && (!p.key_mask || p.key_mask[(long)b * L + pos])) ? 1 : 0;
+        mask_l[tid] = (pos < L && (!p.key_mask || p.key_mask[row0 + pos])) ? 1 : 0;
       }
       __syncthreads();
     }
@@ -702,7 +726,7 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dq_kernel(const
       for (int r = 0; r < 4; ++r)
         img[(wid * 32 + qt * 16 + li) * ILD + dt * 16 + 4 * g + r] = dq[dt][qt][r] * p.scale;
   __syncthreads();
-  store_grad_rows<(DR > 0)>(img, ILD, p.dqkv + (long)b * L * tokstride + (long)h * D, tokstride, q0, 128, L, D,
+  store_grad_rows<(DR > 0)>(img, ILD, p.dqkv + row0 * tokstride + (long)h * D, tokstride, q0, 128, L, D,
                             p.cosT, p.sinT, tid);
 }
 
@@ -724,15 +748,18 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dkv_kernel(cons
   const int g = lane >> 4, li = lane & 15;
   // the head dim as a compile-time constant whenever the dispatcher knows it (DX): the `dt < dtv` guards of the
   // d-tile loops fold away - as run-time branches they pushed the dK / dV accumulators through scratch memory
-  const int D = DX > 0 ? DX : p.D, L = p.L, H = p.H;
+  const int D = DX > 0 ? DX : p.D, H = p.H;
+  int L = p.L;                                          // grid: the longest sequence; below: this sequence
   int kbk, h, b;
   work_item((L + KPB - 1) / KPB, H, p.B, kbk, h, b);
+  const long row0 = seq_rows(p, b, L);
+  if (kbk * KPB >= L) return;                             // packed batches: key block beyond this sequence
   const int cpr = D >> 3;
   const long tokstride = 3L * H * D, ostride = (long)H * D;
-  const unsigned short* qbase = p.qkv + (long)b * L * tokstride + (long)h * D;
+  const unsigned short* qbase = p.qkv + row0 * tokstride + (long)h * D;
   const unsigned short* kbase = qbase + (long)H * D;
   const unsigned short* vbase = qbase + 2L * H * D;
-  const unsigned short* dobase = p.dout + (long)b * L * ostride + (long)h * D;
+  const unsigned short* dobase = p.dout + row0 * ostride + (long)h * D;
   const int k0 = kbk * KPB;
   const int dtv = (D + 15) >> 4;
   const float c2 = p.scale * LOG2E;
@@ -760,7 +787,7 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dkv_kernel(cons
 #pragma unroll
   for (int kt = 0; kt < KTW; ++kt) {
     const int key = k0 + wid * KPW + kt * 16 + li;
-    kvalid[kt] = key < L && (!p.key_mask || p.key_mask[(long)b * L + key]);
+    kvalid[kt] = key < L && (!p.key_mask || p.key_mask[row0 + key]);
   }
   float kbias[KTW];
 #pragma unroll
@@ -781,8 +808,8 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dkv_kernel(cons
       const int q = qb * QB + tid;
       const bool ok = q < L;
       // queries past the end: lse = +inf makes p = exp2(-inf) = 0
-      lse_l[tid] = ok ? p.lse[((long)b * H + h) * L + q] * LOG2E : INFINITY;
-      dl_l[tid] = ok ? -p.delta[((long)b * H + h) * L + q] : 0.f;      // NEGATED: the dP accumulators start from it
+      lse_l[tid] = ok ? p.lse[stat_at(p, b, h, H, L, row0, q)] * LOG2E : INFINITY;
+      dl_l[tid] = ok ? -p.delta[stat_at(p, b, h, H, L, row0, q)] : 0.f;      // NEGATED: the dP accumulators start from it
     }
     __syncthreads();
     if (qb + 1 < nqb) st.load(qbase, tokstride, dobase, ostride, (qb + 1) * QB, L, cpr);   // prefetch under the MFMAs
@@ -843,8 +870,8 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dkv_kernel(cons
 
   // ---- dK~ / dV -> f32 LDS images -> (RoPE^T for dK) -> bf16 rows of dqkv
   float* img = reinterpret_cast<float*>(smem);
-  unsigned short* dkbase = p.dqkv + (long)b * L * tokstride + (long)H * D + (long)h * D;
-  unsigned short* dvbase = p.dqkv + (long)b * L * tokstride + 2L * H * D + (long)h * D;
+  unsigned short* dkbase = p.dqkv + row0 * tokstride + (long)H * D + (long)h * D;
+  unsigned short* dvbase = p.dqkv + row0 * tokstride + 2L * H * D + (long)h * D;
 #pragma unroll
   for (int kt = 0; kt < KTW; ++kt)
 #pragma unroll
@@ -1410,7 +1437,7 @@ template <int DP, int DR, int DX>
 int launch_fwd(const AP& p, hipStream_t st) {
   if constexpr (DP == 32 && DR == 0) {
     // short heads whose rows need no rotation: whole-head kernel (option attn_whole_fwd = 0: the general one)
-    if (whole_fwd_applies(p.L, p.D)) {
+    if (!p.cu && whole_fwd_applies(p.L, p.D)) {
       switch (p.D) {
         case 16: launch_fwd_whole<16, false>(p, st); break;
         case 24: launch_fwd_whole<24, false>(p, st); break;
@@ -1456,7 +1483,7 @@ int launch_bwd(const AP& p, hipStream_t st) {
     // keeps the two-kernel path (tests compare the two)
     const bool fused_on = clipk_opt_get(OPT_ATTN_FUSED_BWD) != 0;
     // q / k must arrive rotated (clipk_rope_qk) or unrotated-by-design: the chunk-per-lane staging cannot rotate
-    if (fused_on && p.L > 128 && p.L <= FUSED_LMAX && p.D >= 16 && (DR == 0 || p.pre_rot)) {
+    if (!p.cu && fused_on && p.L > 128 && p.L <= FUSED_LMAX && p.D >= 16 && (DR == 0 || p.pre_rot)) {
       switch (p.D) {
         case 16: launch_fused<(DR > 0), 16>(p, st); break;
         case 24: launch_fused<(DR > 0), 24>(p, st); break;
@@ -1612,5 +1639,44 @@ extern "C" int clipk_attn_bwd(const void* qkv, const uint8_t* key_mask, const fl
   p.dout = (const unsigned short*)dout; p.delta = delta; p.dqkv = (unsigned short*)dqkv;
   p.B = B; p.L = L; p.H = H; p.D = D; p.scale = q_scale;
   p.pre_rot = (rope && prerotated) ? 1 : 0;
+  ATTN_DISPATCH(launch_bwd, D, rope, p, (hipStream_t)stream);
+}
+
+// ---- packed variable-length batches: no padded token ever exists, so the Linear / LayerNorm kernels see only real rows
+// ([T, ...] with T = sum of lengths) and attention runs per sequence on rows [cu[b], cu[b+1]).  Replaces the padded
+// batches + key-padding masks of current/rna_clip_codes.ipynb:1824-1857,1936-1946 (sequence lengths 30..2542).
+// Same kernels as the padded entry points (general flash kernels; the whole-head short-sequence variants need one
+// length).  RoPE tables, if given, are indexed by the position INSIDE the sequence and must cover max_len rows.
+extern "C" int clipk_attn_varlen_fwd(const void* qkv, const int* cu_seqlens, const float* rope_cos, const float* rope_sin,
+                                     void* out, float* lse, int B, int T, int max_len, int H, int D, float q_scale,
+                                     void* stream) {
+  if ((rope_cos == nullptr) != (rope_sin == nullptr)) return CLIPK_ERR_BAD_ARG;
+  const bool rope = rope_cos != nullptr;
+  int rc = check_common(qkv, B, max_len, H, D, rope);
+  if (rc) return rc;
+  if (!cu_seqlens || T <= 0 || max_len > T || !out || !lse || !aligned16(out)) return CLIPK_ERR_BAD_ARG;
+  AP p{};
+  p.qkv = (const unsigned short*)qkv; p.key_mask = nullptr; p.cosT = rope_cos; p.sinT = rope_sin;
+  p.out = (unsigned short*)out; p.lse = lse; p.B = B; p.L = max_len; p.H = H; p.D = D; p.scale = q_scale;
+  p.cu = cu_seqlens; p.T = T;
+  ATTN_DISPATCH(launch_fwd, D, rope, p, (hipStream_t)stream);
+}
+
+extern "C" int clipk_attn_varlen_bwd(const void* qkv, const int* cu_seqlens, const float* rope_cos, const float* rope_sin,
+                                     const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                                     int B, int T, int max_len, int H, int D, float q_scale, void* stream) {
+  if ((rope_cos == nullptr) != (rope_sin == nullptr)) return CLIPK_ERR_BAD_ARG;
+  const bool rope = rope_cos != nullptr;
+  int rc = check_common(qkv, B, max_len, H, D, rope);
+  if (rc) return rc;
+  if (!cu_seqlens || T <= 0 || max_len > T || !out || !dout || !lse || !delta || !dqkv) return CLIPK_ERR_BAD_ARG;
+  if (!aligned16(out) || !aligned16(dout) || !aligned16(dqkv)) return CLIPK_ERR_BAD_ARG;
+  AP p{};
+  p.qkv = (const unsigned short*)qkv; p.key_mask = nullptr; p.cosT = rope_cos; p.sinT = rope_sin;
+  p.out = (unsigned short*)out; p.lse = const_cast<float*>(lse);
+  p.dout = (const unsigned short*)dout; p.delta = delta; p.dqkv = (unsigned short*)dqkv;
+  p.B = B; p.L = max_len; p.H = H; p.D = D; p.scale = q_scale;
+  p.cu = cu_seqlens; p.T = T;
+  p.pre_rot = 0;
   ATTN_DISPATCH(launch_bwd, D, rope, p, (hipStream_t)stream);
 }

@@ -330,6 +330,40 @@ __global__ void pool_fwd_kernel(const float* x, const uint8_t* mask, float* y, i
   }
   y[(long)b * d + c] = n > 0 ? s / (float)n : 0.f;
 }
+// packed variable-length batches: sequence b = rows [cu[b], cu[b+1]); mode 0 = its first row, 1 = mean over its rows
+__global__ void pool_varlen_fwd_kernel(const float* x, const int* cu, float* y, int d, int mode) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  const int r0 = cu[b], n = cu[b + 1] - r0;
+  const float* xb = x + (long)r0 * d + c;
+  if (mode == 0 || n <= 0) { y[(long)b * d + c] = n > 0 ? xb[0] : 0.f; return; }
+  float s = 0.f;
+  int l = 0;
+  for (; l + 8 <= n; l += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = xb[(long)(l + u) * d];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; l < n; ++l) s += xb[(long)l * d];
+  y[(long)b * d + c] = s / (float)n;
+}
+// one block row per sequence: dx[rows of b] = dy[b] / n (mode 1) or dy[b] on the first row only (mode 0)
+__global__ void pool_varlen_bwd_kernel(const float* dy, const int* cu, float* dx, int d, int mode) {
+  const int b = blockIdx.y;
+  const int r0 = cu[b], n = cu[b + 1] - r0;
+  const int nch = d >> 2;
+  const long total = (long)n * nch;
+  const float inv = (mode == 1 && n > 0) ? 1.0f / (float)n : 1.0f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int l = (int)(i / nch), c = (int)(i - (long)l * nch);
+    const float sc = (mode == 0) ? (l == 0 ? 1.f : 0.f) : inv;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(dy + (long)b * d + 4 * c);
+    *reinterpret_cast<f32x4*>(dx + ((long)r0 + l) * d + 4 * c) = v * sc;
+  }
+}
 __global__ void pool_bwd_kernel(const float* dy, const uint8_t* mask, float* dx, int B, int L, int d, int mode) {
   const int nch = d >> 2;
   const long total = (long)B * L * nch;
@@ -519,6 +553,17 @@ extern "C" int clipk_pool_bwd(const float* dy, const uint8_t* mask, float* dx, i
   if (d & 3) return CLIPK_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(pool_bwd_kernel, dim3(ew_blocks((long)B * L * (d / 4))), dim3(EW_THREADS), 0, (hipStream_t)stream,
                      dy, mask, dx, B, L, d, mode);
+  return clipk_check_launch();
+}
+
+extern "C" int clipk_pool_varlen_fwd(const float* x, const int* cu_seqlens, float* y, int B, int d, int mode, void* stream) {
+  if (!x || !cu_seqlens || !y || B <= 0 || d <= 0) return CLIPK_ERR_BAD_ARG;
+  hipLaunchKernelGGL(pool_varlen_fwd_kernel, dim3((d + 63) / 64, B), dim3(64), 0, (hipStream_t)stream, x, cu_seqlens, y, d, mode);
+  return clipk_check_launch();
+}
+extern "C" int clipk_pool_varlen_bwd(const float* dy, const int* cu_seqlens, float* dx, int B, int d, int mode, void* stream) {
+  if (!dy || !cu_seqlens || !dx || B <= 0 || d <= 0 || (d & 3)) return CLIPK_ERR_BAD_ARG;
+  hipLaunchKernelGGL(pool_varlen_bwd_kernel, dim3(8, B), dim3(256), 0, (hipStream_t)stream, dy, cu_seqlens, dx, d, mode);
   return clipk_check_launch();
 }
 

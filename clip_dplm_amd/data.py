@@ -32,3 +32,29 @@ def collate_fn(batch):
     rna_embs, rbp_embs = zip(*batch)
     return (pad_sequence(rna_embs, batch_first=True, padding_value=float("nan")),
             pad_sequence(rbp_embs, batch_first=True, padding_value=float("nan")))
+
+
+def pack_sequences(seqs, device=None):
+    """List of per-sample [L_i, ...] tensors -> (packed [sum L_i, ...], cu_seqlens int32 [B+1], max_len): the
+    variable-length batch format of the packed attention path (no NaN padding, no mask)."""
+    lens = torch.tensor([int(t.shape[0]) for t in seqs], dtype=torch.int32)
+    cu = torch.zeros(len(seqs) + 1, dtype=torch.int32)
+    cu[1:] = torch.cumsum(lens, 0)
+    packed = torch.cat([torch.as_tensor(t) for t in seqs], 0)
+    if device is not None:
+        packed, cu = packed.to(device), cu.to(device)
+    return packed, cu, int(lens.max())
+
+
+def collate_packed(batch):
+    """Drop-in alternative to collate_fn for models with a packed path (ProteinRNACLIP.loss_packed): each modality
+    becomes (packed, cu_seqlens, max_len) instead of a NaN-padded [B, L_max, D] tensor.  rna_clip_codes.ipynb:2340
+    logs batches padded to L = 2542 for sequences as short as 30 tokens: that padding never reaches a kernel here."""
+    a, b = zip(*batch)
+    return pack_sequences(a), pack_sequences(b)
+
+
+def unpad(x, valid):
+    """Padded [B, L, ...] + validity mask [B, L] (True / 1 = real token, right-padded) -> packed triple."""
+    lens = valid.long().sum(1)
+    return pack_sequences([x[i, : int(lens[i])] for i in range(x.shape[0])])

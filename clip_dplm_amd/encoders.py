@@ -132,10 +132,12 @@ class _Lin:
 # =================================================================================================
 def _esm_layer_fwd(x, p, meta):
     """x: f32 [T,d].  p: dict of this layer's tensors.  Returns y f32 [T,d] and the saved activations."""
-    B, L, H, D, mask, rope, eps = meta
+    B, L, H, D, mask, rope, eps, seq = meta
     _, h1, m1, r1 = ops.layernorm_fwd(x, p["ln1_w"], p["ln1_b"], eps, want_f32=False, want_bf16=True)
     qkv = ops.gemm_nt(h1, p["qkv"].wb, bias=p["qkv"].b)
-    if PREROTATE_QK and rope is not None:
+    if seq is not None:                                    # packed variable-length batch: rows [cu[b], cu[b+1])
+        ctx, lse = ops.attn_varlen_fwd(qkv, seq[0], seq[1], H, D, rope=rope, q_scale=D ** -0.5)
+    elif PREROTATE_QK and rope is not None:
         # RoPE once, in place: the attention kernels would otherwise rotate every K row 5x and every Q row 4x per
         # layer while staging it.  `qkv` (saved for backward) then holds rotated q / k.
         # (one call; for the short ESM heads also one kernel, which rotates the rows while it stages them.)
@@ -151,7 +153,7 @@ def _esm_layer_fwd(x, p, meta):
 
 def _esm_layer_bwd(dy, dyb, p, saved, meta, need_dx_bf16):
     """dy f32 [T,d] (+ its bf16 copy dyb).  Returns dx f32, dx bf16 (or None) and the parameter grads."""
-    B, L, H, D, mask, rope, eps = meta
+    B, L, H, D, mask, rope, eps, seq = meta
     x, h1, m1, r1, qkv, ctx, lse, x2, h2, m2, r2, g, u = saved
     if dyb is None:
         dyb = ops.to_bf16(dy)
@@ -164,8 +166,11 @@ def _esm_layer_bwd(dy, dyb, p, saved, meta, need_dx_bf16):
                                                   want_f32=True, want_bf16=True)
     dctx = ops.gemm_nt(dx2b, p["out"].wtb)
     gr["out_w"], gr["out_b"] = _wgrad(dx2b, ctx, p["out"])
-    dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, H, D, key_mask=mask, rope=rope, q_scale=D ** -0.5,
-                        prerotated=PREROTATE_QK and rope is not None)
+    if seq is not None:
+        dqkv = ops.attn_varlen_bwd(qkv, ctx, dctx, lse, seq[0], seq[1], H, D, rope=rope, q_scale=D ** -0.5)
+    else:
+        dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, H, D, key_mask=mask, rope=rope, q_scale=D ** -0.5,
+                            prerotated=PREROTATE_QK and rope is not None)
     dh1 = ops.gemm_nt(dqkv, p["qkv"].wtb)
     gr["qkv_w"], gr["qkv_b"] = _wgrad(dqkv, h1, p["qkv"])
     dx, dxb, gr["ln1_w"], gr["ln1_b"] = _ln_bwd(dh1, x, p["ln1_w"], p["ln1_b"], m1, r1, dx_add=dx2,
@@ -180,14 +185,14 @@ class EsmStackFn(torch.autograd.Function):
     """ids -> final-LayerNorm hidden states [B*L, d] (f32)."""
 
     @staticmethod
-    def forward(ctx, module, ids, mask_u8, row_scale, *flat):
+    def forward(ctx, module, ids, mask_u8, row_scale, seq, *flat):
         nl = module.num_layers
         table, fin_w, fin_b = flat[0], flat[1], flat[2]
-        B, L = ids.shape
+        B, L = ids.shape                                    # packed batches come as [T, 1] with seq = (cu, max_len)
         d, H = module.hidden_size, module.num_heads
         D = d // H
-        rope = module.rope(L, ids.device)
-        meta = (B, L, H, D, mask_u8, rope, module.eps)
+        rope = module.rope(L if seq is None else seq[1], ids.device)
+        meta = (B, L, H, D, mask_u8, rope, module.eps, seq)
         x = ops.embed_fwd(ids, table, row_scale=row_scale, mask=mask_u8.view(-1) if mask_u8 is not None else None,
                           mask_token_id=module.mask_token_id if module.token_dropout else -1)
         layers, saved = [], []
@@ -223,7 +228,7 @@ class EsmStackFn(torch.autograd.Function):
             ctx.saved[i] = None                                     # free this layer's activations now
             for j, k in enumerate(_ESM_KEYS):
                 grads[3 + 12 * i + j] = gr[k]
-        if ctx.needs_input_grad[4]:
+        if ctx.needs_input_grad[5]:
             mask_u8 = meta[4]
             dtable = torch.zeros(ctx.table_shape, dtype=torch.float32, device=dx.device)
             ops.embed_bwd(ctx.ids, dx, dtable, row_scale=ctx.row_scale,
@@ -232,7 +237,7 @@ class EsmStackFn(torch.autograd.Function):
             grads[0] = dtable
         ctx.layers = ctx.saved = None
         _join_side(*grads)
-        return (None, None, None, None, *grads)
+        return (None, None, None, None, None, *grads)
 
 
 class _EsmSelf(nn.Module):
@@ -378,17 +383,37 @@ class ESM2Encoder(nn.Module):
                 torch.full((B,), float(L), device=input_ids.device)
             ratio = (input_ids == self.mask_token_id).sum(-1).float() / src_len
             row_scale = ((1 - 0.15 * 0.8) / (1 - ratio)).contiguous()
-        y = EsmStackFn.apply(self, input_ids.contiguous(), mask_u8, row_scale, *self._flat_params())
+        y = EsmStackFn.apply(self, input_ids.contiguous(), mask_u8, row_scale, None, *self._flat_params())
         return y.view(B, L, self.hidden_size)
+
+    def forward_packed(self, input_ids, cu_seqlens, max_len: int):
+        """Packed variable-length batch: input_ids int64 [T] = the sequences back to back, cu_seqlens
+        int32 [B+1] on the device, max_len = the longest sequence.  -> last_hidden_state [T, d].  No padded token
+        exists anywhere: Linear / LayerNorm kernels see T real rows, attention runs per sequence."""
+        T = input_ids.numel()
+        row_scale = None
+        if self.token_dropout:
+            # per-sequence (1 - 0.15 * 0.8) / (1 - mask ratio), expanded per token ([T] scalars: plumbing)
+            lens = (cu_seqlens[1:] - cu_seqlens[:-1]).long()
+            seg = torch.repeat_interleave(torch.arange(lens.numel(), device=input_ids.device), lens)
+            nmask = torch.zeros(lens.numel(), device=input_ids.device).index_add_(
+                0, seg, (input_ids == self.mask_token_id).float())
+            row_scale = ((1 - 0.15 * 0.8) / (1 - nmask / lens.float()))[seg].contiguous()
+        y = EsmStackFn.apply(self, input_ids.reshape(T, 1).contiguous(), None, row_scale,
+                             (cu_seqlens.contiguous(), int(max_len)), *self._flat_params())
+        return y
 
 
 # =================================================================================================
 # post-LN (nn.TransformerEncoderLayer) stack
 # =================================================================================================
 def _post_layer_fwd(x, xb, p, meta):
-    B, L, H, D, mask, act, eps, qs = meta
+    B, L, H, D, mask, act, eps, qs, seq = meta
     qkv = ops.gemm_nt(xb, p["in"].wb, bias=p["in"].b)
-    ctx, lse = ops.attn_fwd(qkv, B, L, H, D, key_mask=mask, rope=None, q_scale=qs)
+    if seq is not None:
+        ctx, lse = ops.attn_varlen_fwd(qkv, seq[0], seq[1], H, D, rope=None, q_scale=qs)
+    else:
+        ctx, lse = ops.attn_fwd(qkv, B, L, H, D, key_mask=mask, rope=None, q_scale=qs)
     s1 = ops.gemm_nt(ctx, p["out"].wb, bias=p["out"].b, residual=x, out_dtype=torch.float32)
     x1, x1b, m1, r1 = ops.layernorm_fwd(s1, p["n1_w"], p["n1_b"], eps, want_f32=True, want_bf16=True)
     if act == "gelu":
@@ -402,7 +427,7 @@ def _post_layer_fwd(x, xb, p, meta):
 
 
 def _post_layer_bwd(dy, p, saved, meta):
-    B, L, H, D, mask, act, eps, qs = meta
+    B, L, H, D, mask, act, eps, qs, seq = meta
     xb, qkv, ctx, lse, s1, x1b, m1, r1, g, u, s2, m2, r2 = saved
     gr = {}
     ds2, ds2b, gr["n2_w"], gr["n2_b"] = _ln_bwd(dy, s2, p["n2_w"], p["n2_b"], m2, r2, want_f32=True, want_bf16=True)
@@ -413,7 +438,10 @@ def _post_layer_bwd(dy, p, saved, meta):
     ds1, ds1b, gr["n1_w"], gr["n1_b"] = _ln_bwd(dx1, s1, p["n1_w"], p["n1_b"], m1, r1, want_f32=True, want_bf16=True)
     dctx = ops.gemm_nt(ds1b, p["out"].wtb)
     gr["out_w"], gr["out_b"] = _wgrad(ds1b, ctx, p["out"])
-    dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, H, D, key_mask=mask, rope=None, q_scale=qs)
+    if seq is not None:
+        dqkv = ops.attn_varlen_bwd(qkv, ctx, dctx, lse, seq[0], seq[1], H, D, rope=None, q_scale=qs)
+    else:
+        dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, H, D, key_mask=mask, rope=None, q_scale=qs)
     dx = ops.gemm_nt(dqkv, p["in"].wtb, residual=ds1, out_dtype=torch.float32)
     gr["in_w"], gr["in_b"] = _wgrad(dqkv, xb, p["in"])
     return dx, gr
@@ -426,11 +454,11 @@ class PostLNStackFn(torch.autograd.Function):
     """x f32 [B*L, E] -> final-LayerNorm output f32 [B*L, E]."""
 
     @staticmethod
-    def forward(ctx, module, x, mask_u8, B, L, *flat):
+    def forward(ctx, module, x, mask_u8, B, L, seq, *flat):
         nl = module.num_layers
         E, H = module.embed_dim, module.nhead
         D = module.head_dim_padded
-        meta = (B, L, H, D, mask_u8, module.activation, module.eps, float(E // H) ** -0.5)
+        meta = (B, L, H, D, mask_u8, module.activation, module.eps, float(E // H) ** -0.5, seq)
         x = x.contiguous()
         xb = ops.to_bf16(x)
         fin_w, fin_b = flat[0], flat[1]
@@ -463,7 +491,7 @@ class PostLNStackFn(torch.autograd.Function):
                 grads[2 + 12 * i + j] = gr[k]
         ctx.layers = ctx.saved = None
         _join_side(*grads)
-        return (None, dx if ctx.needs_input_grad[1] else None, None, None, None, *grads)
+        return (None, dx if ctx.needs_input_grad[1] else None, None, None, None, None, *grads)
 
 
 class _MHAParams(nn.Module):
@@ -547,8 +575,24 @@ class TransformerSeqEncoder(nn.Module):
         mask_u8 = None
         if src_key_padding_mask is not None:
             mask_u8 = (~src_key_padding_mask.bool()).to(torch.uint8).contiguous()      # kernels take 1 = valid
-        y = PostLNStackFn.apply(self, x.reshape(B * L, E), mask_u8, B, L, *self._flat_params())
+        y = PostLNStackFn.apply(self, x.reshape(B * L, E), mask_u8, B, L, None, *self._flat_params())
         return y.view(B, L, E)
+
+    def _check_dropout(self):
+        if self.training and self.dropout > 0.0 and torch.is_grad_enabled():
+            raise NotImplementedError(
+                f"TransformerSeqEncoder: training-mode dropout p={self.dropout} is not implemented in the HIP layer "
+                "stack (INTEGRATION.md §dropout): set `encoder.dropout = 0.0` or call .eval().")
+
+    def forward_packed(self, x, cu_seqlens, max_len: int):
+        """Packed variable-length batch: x f32 [T, E] = the sequences back to back, cu_seqlens int32
+        [B+1] on the device, max_len = the longest sequence.  -> [T, E]; equals forward() on the padded batch with its
+        key-padding mask, row for row, without any padded row going through a kernel."""
+        self._check_dropout()
+        T, E = x.shape
+        B = cu_seqlens.numel() - 1
+        return PostLNStackFn.apply(self, x, None, B, int(max_len), (cu_seqlens.contiguous(), int(max_len)),
+                                   *self._flat_params())
 
 
 class PoolFn(torch.autograd.Function):
@@ -573,3 +617,22 @@ class PoolFn(torch.autograd.Function):
 def pool(x, valid_mask=None, mode: str = "mean"):
     mask_u8 = valid_mask.to(torch.uint8).contiguous() if valid_mask is not None else None
     return PoolFn.apply(x, mask_u8, 0 if mode == "first" else 1)
+
+
+class PoolPackedFn(torch.autograd.Function):
+    """Pooling of a packed variable-length batch: x [T, d], sequence b = rows [cu[b], cu[b+1])."""
+
+    @staticmethod
+    def forward(ctx, x, cu_seqlens, mode):
+        ctx.meta = (x.shape[0], mode)
+        ctx.cu = cu_seqlens
+        return ops.pool_varlen_fwd(x.contiguous(), cu_seqlens, mode)
+
+    @staticmethod
+    def backward(ctx, dy):
+        T, mode = ctx.meta
+        return ops.pool_varlen_bwd(dy.contiguous(), ctx.cu, T, mode), None, None
+
+
+def pool_packed(x, cu_seqlens, mode: str = "mean"):
+    return PoolPackedFn.apply(x, cu_seqlens, 0 if mode == "first" else 1)

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as KF
-from .encoders import ESM2Encoder, ESM2_SHAPES, TransformerSeqEncoder, pool
+from .encoders import ESM2Encoder, ESM2_SHAPES, TransformerSeqEncoder, pool, pool_packed
 from .loss import clip_loss
 from .modeling_clip import KLayerNorm, KLinear, OptimizedProjectionHead, ProjectionHead
 
@@ -150,6 +150,21 @@ class ProteinRNACLIP(nn.Module):
         er = ers[0] if nmb == 1 else torch.cat(ers, 0)
         ep = eps[0] if nmb == 1 else torch.cat(eps, 0)
         return er, ep
+
+    def embed_packed(self, rna_packed, rna_cu, rna_max_len, protein_ids_packed, protein_cu, protein_max_len):
+        """Variable-length batches without padding: rna_packed f32 [T_r, rna_dim], protein_ids_packed
+        int64 [T_p], cu_seqlens int32 [B+1] each (data.collate_packed builds them).  Same embeddings as embed() on the
+        padded batch with masks; the padded rows are never computed."""
+        hr = self.rna_model.forward_packed(rna_packed, rna_cu, rna_max_len)
+        hp = self.protein_model.forward_packed(protein_ids_packed, protein_cu, protein_max_len)
+        er = KF.l2_normalize(self.rna_projection(pool_packed(hr, rna_cu, self.pooling)))
+        ep = KF.l2_normalize(self.protein_projection(pool_packed(hp, protein_cu, self.pooling)))
+        return er, ep
+
+    def loss_packed(self, rna_packed, rna_cu, rna_max_len, protein_ids_packed, protein_cu, protein_max_len, group=None,
+                    symmetric: bool = True):
+        er, ep = self.embed_packed(rna_packed, rna_cu, rna_max_len, protein_ids_packed, protein_cu, protein_max_len)
+        return clip_loss(er, ep, self.logit_scale.exp(), symmetric=symmetric, group=group)
 
     def forward(self, rna_values, protein_ids, rna_mask=None, protein_mask=None):
         er, ep = self.embed(rna_values, protein_ids, rna_mask, protein_mask)

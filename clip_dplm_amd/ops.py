@@ -485,6 +485,38 @@ def attn_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=None, rope=None, q_scale=
     return dqkv
 
 
+def attn_varlen_fwd(qkv, cu_seqlens, max_len, H, D, rope=None, q_scale=1.0):
+    """Packed variable-length self-attention: qkv bf16 [T, 3*H*D], cu_seqlens int32 [B+1] on the device."""
+    _need_cuda(qkv, cu_seqlens)
+    T = qkv.shape[0]
+    B = cu_seqlens.numel() - 1
+    assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous() and qkv.shape == (T, 3 * H * D)
+    assert cu_seqlens.dtype == torch.int32 and cu_seqlens.is_contiguous()
+    out = torch.empty((T, H * D), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((H, T), dtype=torch.float32, device=qkv.device)
+    cos, sin = rope if rope is not None else (None, None)
+    check(_timed("attn_fwd", 0.0,
+                 lambda: _lib().clipk_attn_varlen_fwd(qkv.data_ptr(), cu_seqlens.data_ptr(), ptr(cos), ptr(sin),
+                                                      out.data_ptr(), lse.data_ptr(), B, T, int(max_len), H, D,
+                                                      float(q_scale), _stream())), "clipk_attn_varlen_fwd")
+    return out, lse
+
+
+def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_len, H, D, rope=None, q_scale=1.0):
+    _need_cuda(qkv, out, dout, lse, cu_seqlens)
+    T = qkv.shape[0]
+    B = cu_seqlens.numel() - 1
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((H, T), dtype=torch.float32, device=qkv.device)
+    cos, sin = rope if rope is not None else (None, None)
+    check(_timed("attn_bwd", 0.0,
+                 lambda: _lib().clipk_attn_varlen_bwd(qkv.data_ptr(), cu_seqlens.data_ptr(), ptr(cos), ptr(sin),
+                                                      out.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                                                      dqkv.data_ptr(), B, T, int(max_len), H, D, float(q_scale),
+                                                      _stream())), "clipk_attn_varlen_bwd")
+    return dqkv
+
+
 # --------------------------------------------------------------------------------------------------
 def embed_fwd(ids, table, row_scale=None, mask=None, mask_token_id=-1):
     _need_cuda(ids, table)
@@ -519,6 +551,24 @@ def pool_bwd(dy, B, L, mask=None, mode=1):
     d = dy.shape[-1]
     dx = torch.empty((B * L, d), dtype=torch.float32, device=dy.device)
     check(_lib().clipk_pool_bwd(dy.data_ptr(), ptr(mask), dx.data_ptr(), B, L, d, mode, _stream()), "clipk_pool_bwd")
+    return dx
+
+
+def pool_varlen_fwd(x, cu_seqlens, mode=1):
+    _need_cuda(x, cu_seqlens)
+    B, d = cu_seqlens.numel() - 1, x.shape[-1]
+    y = torch.empty((B, d), dtype=torch.float32, device=x.device)
+    check(_lib().clipk_pool_varlen_fwd(x.data_ptr(), cu_seqlens.data_ptr(), y.data_ptr(), B, d, mode, _stream()),
+          "clipk_pool_varlen_fwd")
+    return y
+
+
+def pool_varlen_bwd(dy, cu_seqlens, T, mode=1):
+    _need_cuda(dy, cu_seqlens)
+    B, d = dy.shape
+    dx = torch.empty((T, d), dtype=torch.float32, device=dy.device)
+    check(_lib().clipk_pool_varlen_bwd(dy.data_ptr(), cu_seqlens.data_ptr(), dx.data_ptr(), B, d, mode, _stream()),
+          "clipk_pool_varlen_bwd")
     return dx
 
 

@@ -262,6 +262,25 @@ int clipk_embed_bwd(const int64_t* ids, const float* dx, const float* row_scale,
 int clipk_pool_fwd(const float* x, const uint8_t* mask, float* y, int B, int L, int d, int mode, void* stream);
 int clipk_pool_bwd(const float* dy, const uint8_t* mask, float* dx, int B, int L, int d, int mode, void* stream);
 
+/* Pooling over packed variable-length batches (sequence b = rows [cu[b], cu[b+1]) of x f32 [T, d]): mode 0 = the first
+ * row, 1 = mean over the sequence's rows; backward writes every row of dx [T, d].  cu_seqlens: DEVICE int32 [B+1]. */
+int clipk_pool_varlen_fwd(const float* x, const int* cu_seqlens, float* y, int B, int d, int mode, void* stream);
+int clipk_pool_varlen_bwd(const float* dy, const int* cu_seqlens, float* dx, int B, int d, int mode, void* stream);
+
+/* Attention over PACKED variable-length batches.  The reference pads every batch to its longest
+ * sequence with NaN rows and masks them as keys (current/rna_clip_codes.ipynb:1824-1857 collate_fn /
+ * create_padding_mask, :1936-1946; lengths 30..2542), so padded rows still run through every Linear, LayerNorm and
+ * attention row.  Here sequence b is rows [cu_seqlens[b], cu_seqlens[b+1]) of the packed tensors:
+ *   qkv bf16 [T, 3*H*D], out / dout bf16 [T, H*D], dqkv bf16 [T, 3*H*D], lse / delta f32 [H, T];
+ *   cu_seqlens: DEVICE int32 [B+1] (cu[0] = 0, cu[B] = T); max_len = longest sequence (grid sizing only);
+ *   rope tables (optional, ESM head dims): f32 [>= max_len, D/2], indexed by the position inside the sequence.
+ * Arithmetic is that of clipk_attn_fwd / clipk_attn_bwd on each sequence alone. */
+int clipk_attn_varlen_fwd(const void* qkv, const int* cu_seqlens, const float* rope_cos, const float* rope_sin,
+                          void* out, float* lse, int B, int T, int max_len, int H, int D, float q_scale, void* stream);
+int clipk_attn_varlen_bwd(const void* qkv, const int* cu_seqlens, const float* rope_cos, const float* rope_sin,
+                          const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
+                          int B, int T, int max_len, int H, int D, float q_scale, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Optimiser step on flat f32 buffers: AdamW (decoupled weight decay, torch.optim.AdamW semantics,
  * rna_clip_codes.ipynb:2033) with the global-norm clip of clip_grad_norm_ (ipynb:2076) folded in:

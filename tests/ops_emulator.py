@@ -282,6 +282,44 @@ def attn_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=None, rope=None, q_scale=
     return g.to(BF)
 
 
+def _segments(cu):
+    cu = [int(v) for v in cu.tolist()]
+    return [(cu[i], cu[i + 1]) for i in range(len(cu) - 1)]
+
+
+def attn_varlen_fwd(qkv, cu_seqlens, max_len, H, D, rope=None, q_scale=1.0):
+    outs, lses = [], []
+    for a, b in _segments(cu_seqlens):
+        o, l = attn_fwd(qkv[a:b].contiguous(), 1, b - a, H, D, rope=None if rope is None else (rope[0][: b - a], rope[1][: b - a]),
+                        q_scale=q_scale)
+        outs.append(o)
+        lses.append(l.reshape(H, b - a))
+    return torch.cat(outs, 0), torch.cat(lses, 1)
+
+
+def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_len, H, D, rope=None, q_scale=1.0):
+    gs = []
+    for a, b in _segments(cu_seqlens):
+        r = None if rope is None else (rope[0][: b - a], rope[1][: b - a])
+        gs.append(attn_bwd(qkv[a:b].contiguous(), out[a:b].contiguous(), dout[a:b].contiguous(),
+                           lse[:, a:b].reshape(1, H, b - a).contiguous(), 1, b - a, H, D, rope=r, q_scale=q_scale))
+    return torch.cat(gs, 0)
+
+
+def pool_varlen_fwd(x, cu_seqlens, mode=1):
+    return torch.stack([x[a] if mode == 0 else x[a:b].mean(0) for a, b in _segments(cu_seqlens)])
+
+
+def pool_varlen_bwd(dy, cu_seqlens, T, mode=1):
+    dx = torch.zeros(T, dy.shape[1], dtype=dy.dtype)
+    for i, (a, b) in enumerate(_segments(cu_seqlens)):
+        if mode == 0:
+            dx[a] = dy[i]
+        else:
+            dx[a:b] = dy[i] / (b - a)
+    return dx
+
+
 def embed_fwd(ids, table, row_scale=None, mask=None, mask_token_id=-1):
     B, L = ids.shape
     x = table[ids]

@@ -620,3 +620,68 @@ def test_options_api(dev):
         ops.set_option("no_such_option", 1)
     with pytest.raises(_ffi.ClipkError):
         ops.set_option("gemm_abl", 1)                       # timing ablations change results: experiment builds only
+
+
+# ------------------------------------------------------------------------------------------------ packed varlen attention
+@pytest.mark.parametrize("H,D,use_rope,lens", [(8, 96, False, [256, 131, 40, 700, 1, 129]),
+                                                (20, 24, True, [256, 200, 37, 129]),
+                                                (4, 64, True, [1024, 300, 513]),
+                                                (3, 32, False, [90, 17, 128]),
+                                                (2, 160, False, [140, 65])])
+def test_attention_varlen_equals_padded_with_mask(dev, H, D, use_rope, lens):
+    """clipk_attn_varlen_{fwd,bwd} on a packed batch against clipk_attn_{fwd,bwd} on the same sequences padded to the
+    longest with a key mask (general kernels on both sides: option attn_*_whole = 0 is not needed because the padded
+    reference may take the whole-head kernels, which are bit-identical to the general ones for the forward).  Outputs,
+    LSE and gradients of the real rows."""
+    ops = _ops()
+    B, Lm = len(lens), max(lens)
+    T = sum(lens)
+    g = torch.Generator().manual_seed(T + D)
+    qkv_pad = (torch.randn(B, Lm, 3 * H * D, generator=g) * 0.5).to(torch.bfloat16)
+    dout_pad = (torch.randn(B, Lm, H * D, generator=g) * 0.5).to(torch.bfloat16)
+    mask = torch.zeros(B, Lm, dtype=torch.uint8)
+    for i, l in enumerate(lens):
+        mask[i, :l] = 1
+    dout_pad = dout_pad * mask[..., None].to(torch.bfloat16)
+    sel = mask.bool().view(-1)
+    qkv_pk = qkv_pad.view(B * Lm, -1)[sel].contiguous().to(dev)
+    dout_pk = dout_pad.view(B * Lm, -1)[sel].contiguous().to(dev)
+    cu = torch.zeros(B + 1, dtype=torch.int32)
+    cu[1:] = torch.cumsum(torch.tensor(lens), 0)
+    cu = cu.to(dev)
+    rope = None
+    if use_rope:
+        inv = 1.0 / (10000 ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
+        fr = torch.arange(Lm, dtype=torch.float32)[:, None] * inv[None]
+        rope = (fr.cos().contiguous().to(dev), fr.sin().contiguous().to(dev))
+    qs = D ** -0.5
+    qp, dp, mk = qkv_pad.view(B * Lm, -1).contiguous().to(dev), dout_pad.view(B * Lm, -1).contiguous().to(dev), mask.to(dev)
+    o_ref, lse_ref = ops.attn_fwd(qp, B, Lm, H, D, key_mask=mk, rope=rope, q_scale=qs)
+    g_ref = ops.attn_bwd(qp, o_ref, dp, lse_ref, B, Lm, H, D, key_mask=mk, rope=rope, q_scale=qs)
+    o, lse = ops.attn_varlen_fwd(qkv_pk, cu, Lm, H, D, rope=rope, q_scale=qs)
+    gk = ops.attn_varlen_bwd(qkv_pk, o, dout_pk, lse, cu, Lm, H, D, rope=rope, q_scale=qs)
+    seld = sel.to(dev)
+    assert torch.allclose(o.float(), o_ref[seld].float(), rtol=0, atol=4e-3), (o.float() - o_ref[seld].float()).abs().max()
+    lse_ref_pk = lse_ref.permute(1, 0, 2).reshape(H, B * Lm)[:, seld]
+    assert torch.allclose(lse, lse_ref_pk, rtol=0, atol=1e-4), (lse - lse_ref_pk).abs().max()
+    gr = g_ref[seld].float()
+    assert torch.isfinite(gk.float()).all()
+    assert (gk.float() - gr).abs().max().item() < 8e-3 * max(1.0, gr.abs().max().item())
+
+
+def test_pool_varlen(dev):
+    ops = _ops()
+    lens = [5, 1, 300, 64]
+    T, d = sum(lens), 96
+    x = _rand((T, d), dev, 41)
+    cu = torch.tensor([0, 5, 6, 306, 370], dtype=torch.int32, device=dev)
+    for mode in (0, 1):
+        y = ops.pool_varlen_fwd(x, cu, mode)
+        ref = torch.stack([x[a] if mode == 0 else x[a:b].mean(0) for a, b in zip(cu[:-1].tolist(), cu[1:].tolist())])
+        assert torch.allclose(y, ref, rtol=1e-5, atol=1e-6)
+        dy = _rand((4, d), dev, 42)
+        dx = ops.pool_varlen_bwd(dy, cu, T, mode)
+        xr = x.clone().requires_grad_(True)
+        yr = torch.stack([xr[a] if mode == 0 else xr[a:b].mean(0) for a, b in zip(cu[:-1].tolist(), cu[1:].tolist())])
+        yr.backward(dy)
+        assert torch.allclose(dx, xr.grad, rtol=1e-5, atol=1e-7)

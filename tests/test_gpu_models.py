@@ -570,3 +570,50 @@ def test_trimodal_loss_pairs_kernels_vs_f64(dev):
     for e, ed in zip(E, Ed):
         assert torch.allclose(e.grad.double(), ed.grad, rtol=1e-4, atol=1e-7), (e.grad.double() - ed.grad).abs().max()
     assert abs(ls.grad.item() - lsd.grad.item()) < 1e-5 * max(1.0, abs(lsd.grad.item()))
+
+
+def _ragged_batch(B, L, seed, dim):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(4, 24, (B, L), generator=g)
+    ids[:, 0] = 0
+    rna = torch.randn(B, L, dim, generator=g)
+    lp = torch.randint(L // 4, L + 1, (B,), generator=g)
+    lr = torch.randint(L // 4, L + 1, (B,), generator=g)
+    lp[0], lr[1] = L, L
+    pmask = (torch.arange(L)[None] < lp[:, None]).long()
+    rmask = (torch.arange(L)[None] < lr[:, None]).long()
+    ids = torch.where(pmask.bool(), ids, torch.ones_like(ids))
+    return rna, ids, rmask, pmask
+
+
+def test_packed_varlen_path_equals_padded_path(dev):
+    """the packed variable-length path (no padded row reaches any kernel: cu_seqlens attention, packed
+    Linear / LayerNorm / pooling) against the padded path with key-padding masks on the same ragged batch: loss and
+    every parameter gradient.  Same kernels and the same per-row arithmetic, so the agreement is far inside the bf16
+    level (only GEMM tile membership of a row and the split-M order of the weight-gradient sums differ)."""
+    import clip_dplm_amd as K
+    from clip_dplm_amd.data import unpad
+    from clip_dplm_amd.encoders import ESM2_SHAPES
+    ESM2_SHAPES["test_packed"] = (2, 96, 4, 384)
+    torch.manual_seed(0)
+    m = K.ProteinRNACLIP(esm="test_packed", rna_dim=64, rna_layers=2, rna_heads=8, rna_ffn=128, projection_dim=64).eval()
+    m = m.to(dev)
+    B, L = 24, 200                                          # L > 128: more than one key block per sequence
+    rna, ids, rmask, pmask = _ragged_batch(B, L, 5, 64)
+    loss_pad = m.loss(rna.to(dev), ids.to(dev), rna_mask=rmask.to(dev), protein_mask=pmask.to(dev))
+    loss_pad.backward()
+    gpad = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+    m.zero_grad(set_to_none=True)
+    (rp, rcu, rmax), (ip, icu, imax) = unpad(rna, rmask.bool()), unpad(ids, pmask.bool())
+    assert rp.shape[0] == int(rmask.sum()) and ip.shape[0] == int(pmask.sum())
+    loss_pk = m.loss_packed(rp.to(dev), rcu.to(dev), rmax, ip.to(dev), icu.to(dev), imax)
+    loss_pk.backward()
+    assert abs(loss_pad.item() - loss_pk.item()) < 2e-4, (loss_pad.item(), loss_pk.item())
+    for n, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        a, b = p.grad.flatten().double(), gpad[n].flatten().double()
+        if b.abs().max() < 1e-10:
+            continue
+        cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
+        assert cos > 0.999, (n, cos)

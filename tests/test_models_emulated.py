@@ -26,6 +26,7 @@ CASES = [
     ("esm_proj", T.test_esm_projections_golden, {}),
     ("trimodal", T.test_trimodal_contrastive_model_golden, {}),
     ("trimodal_loss", T.test_trimodal_loss_pairs_kernels_vs_f64, {}),
+    ("packed_varlen", T.test_packed_varlen_path_equals_padded_path, {}),
 ]
 
 
