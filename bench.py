@@ -55,6 +55,10 @@ def parse_args():
     ap.add_argument("--seq-len", type=int, default=None)
     ap.add_argument("--esm", default=None)
     ap.add_argument("--freeze-esm", action="store_true", help="reference behaviour (3_esm_integration.py:83-84)")
+    ap.add_argument("--lengths", default="full", choices=["full", "ragged-padded", "ragged-packed"],
+                    help="c2 only. full: every sequence L tokens (the BASELINE metric).  ragged-*: SURVEY §8d's padded "
+                         "variant, lengths uniform in [L/4, L]: -padded = [B, L] batches + key-padding masks (what the "
+                         "reference does), -packed = cu_seqlens batches without any padded row (SURVEY §8f-4)")
     ap.add_argument("--dual-stream", action="store_true",
                     help="enqueue the two towers on separate HIP streams (a kernel's HIP-event time then includes "
                          "waiting for the other tower's kernels)")
@@ -208,9 +212,28 @@ def bench_clip(args):
     rna = torch.randn(B, Lr, 768, generator=g).to(device)
     ids = ids.to(device)
 
+    ragged = args.lengths != "full" and not c4
+    if ragged:
+        from clip_dplm_amd.data import unpad
+        lp = torch.randint(Lp // 4, Lp + 1, (B,), generator=g)
+        lr = torch.randint(Lr // 4, Lr + 1, (B,), generator=g)
+        pmask = (torch.arange(Lp)[None] < lp[:, None])
+        rmask = (torch.arange(Lr)[None] < lr[:, None])
+        real_tokens = int(pmask.sum() + rmask.sum())
+        if args.lengths == "ragged-packed":
+            (rp, rcu, rmax), (ip, icu, imax) = unpad(rna.cpu(), rmask), unpad(ids.cpu(), pmask)
+            rp, rcu, ip, icu = rp.to(device), rcu.to(device), ip.to(device), icu.to(device)
+        else:
+            pmask_d, rmask_d = pmask.to(device).long(), rmask.to(device).long()
+
     def step():
         opt.zero_grad()
-        loss = model.loss(rna, ids, group=group)
+        if not ragged:
+            loss = model.loss(rna, ids, group=group)
+        elif args.lengths == "ragged-packed":
+            loss = model.loss_packed(rp, rcu, rmax, ip, icu, imax, group=group)
+        else:
+            loss = model.loss(rna, ids, rna_mask=rmask_d, protein_mask=pmask_d, group=group)
         loss.backward()
         opt.step()
         return loss
@@ -283,6 +306,9 @@ def bench_clip(args):
                    "projection_dim": 512, "hip_streams": 2 if model.dual_stream else 1},
         "loss": round(float(loss.item()), 5),
     }
+    if ragged:
+        out["config"]["lengths"] = (f"{args.lengths}: lengths uniform in [L/4, L]; {real_tokens} real tokens of "
+                                    f"{B * (Lp + Lr)} padded positions ({real_tokens / (B * (Lp + Lr)):.3f})")
     # algorithmic FLOP of one step (8d^2 + 4Ld + 4df per token.layer forward; x3 trained, x1 frozen)
     fl_esm = (8 * d * d + 4 * Lp * d + 4 * d * f) * nl * Lp * (1 if freeze else 3)
     fl_rna = (8 * 768 * 768 + 4 * Lr * 768 + 4 * 768 * 2048) * 6 * Lr * 3
@@ -417,8 +443,20 @@ def bench_c5(args):
     for _ in range(args.steps):
         out_ = model(cell, pert, prot)
     torch.cuda.synchronize()
+    dt_eager = time.perf_counter() - t0
+    # launch-bound in eager mode (~45 small launches per step): replay the same launches from one hipGraph
+    graphed = icnn.GraphedTransport(model, cell, pert, prot)
+    for _ in range(args.warmup):
+        graphed(cell, pert, prot)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out_g = graphed(cell, pert, prot)
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    assert all(torch.equal(out_g[k], out_[k]) for k in out_)          # same kernels, same inputs: same bits
     per_map_bytes = B * 512 * 4 * 2 + 0.79e6 * 4
+    flop = 3 * B * 2.0 * 2 * (512 * 512 + 2 * 256 * 512)              # three maps, forward + input-gradient products
     ach = 3 * per_map_bytes * args.steps / dt / 1e9
     out = {"metric": "samples/sec, ICNN triple transport maps (eval)", "value": round(B * args.steps / dt, 1),
            "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -426,10 +464,15 @@ def bench_c5(args):
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"BASELINE config 5: create_transport_system(512, 512, 512), hidden [512, 256], B={B}, "
                                   "three eval-mode transport maps per step"},
-           "roofline": {"bound": "hbm", "kernel": "ICNN transport map (whole op: all launches of the three maps)",
+           "roofline": {"bound": "hbm", "kernel": "ICNN transport map (whole op: all launches of the three maps, hipGraph replay)",
                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
-                        "algorithmic_bytes_per_step": int(3 * per_map_bytes)}}
+                        "algorithmic_bytes_per_step": int(3 * per_map_bytes),
+                        "f32_mfma_tflops": round(flop * args.steps / dt / 1e12, 1),
+                        "f32_mfma_frac_of_157": round(flop * args.steps / dt / 1e12 / 157.3, 3),
+                        "note": "the op is exact-f32 matrix work (2.1 MFLOP / sample / map at 64 FLOP/clk/SIMD): its own "
+                                "bound is the f32 matrix pipe, not HBM"},
+           "eager_ms_per_step": round(1e3 * dt_eager / args.steps, 4)}
     print(json.dumps(out), flush=True)
 
 

@@ -61,6 +61,7 @@ SIGNATURES = {
     "clipk_ce_logits_lse": (_i, [_vp, _i64, _i, _i, _vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
     "clipk_ce_logits_bwd": (_i, [_vp, _i64, _i, _i, _vp, _i64, _i, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _i64, _vp, _i64, _vp]),
     "clipk_transpose_scale_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "clipk_gemm_f32": (_i, [_vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp]),
     "clipk_gemm_f32_nt": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "clipk_layernorm_fwd": (_i, [_vp, _i, _i64, _vp, _vp, _f, _i, _vp, _vp, _i64, _vp, _vp, _i, _i, _vp]),
     "clipk_layernorm_bwd_workspace": (_sz, [_i, _i]),

@@ -62,37 +62,36 @@ class TransportOutput:                 # 4_transport_maps.py:39-44
     metrics: Optional[Dict[str, float]] = None
 
 
-class _MatmulNT(torch.autograd.Function):
-    """C = A @ B^T in exact f32 on clipk_gemm_f32_nt.  backward() is written with _MatmulNT itself (plus transposed
-    copies), so autograd can differentiate it again: that is what training through T(x) = dPsi/dx needs."""
-
-    KMAX = 512      # the kernel keeps one operand row block in LDS: contraction length <= 768 and a multiple of 4
-
-    @staticmethod
-    def _mm(a, b):
-        out = None
-        for k0 in range(0, a.shape[1], _MatmulNT.KMAX):       # long contractions (dW over a large batch): chunk + add
-            ak, bk = a[:, k0:k0 + _MatmulNT.KMAX], b[:, k0:k0 + _MatmulNT.KMAX]
-            if ak.shape[1] % 4:
-                pad = 4 - ak.shape[1] % 4
-                ak, bk = F.pad(ak, (0, pad)), F.pad(bk, (0, pad))
-            out = ops.gemm_f32_nt(ak.contiguous(), bk.contiguous(), addend=out)
-        return out
+class _MatMul(torch.autograd.Function):
+    """C[M, N] = opA(a) @ opB(b) in exact f32 on clipk_gemm_f32 (opA: a or a stored [K, M]; opB: b [N, K] or b stored
+    [K, N]).  backward() is written with _MatMul itself — every operand layout is a flag of the kernel, no transposed
+    copies — so autograd can differentiate it again: that is what training through T(x) = dPsi/dx needs."""
 
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, ta, tb):
         ctx.save_for_backward(a, b)
-        return _MatmulNT._mm(a.float(), b.float())
+        ctx.flags = (ta, tb)
+        return ops.gemm_f32(a.float(), b.float(), trans_a=ta, trans_b=tb)
 
     @staticmethod
     def backward(ctx, g):
         a, b = ctx.saved_tensors
+        ta, tb = ctx.flags
         da = db = None
         if ctx.needs_input_grad[0]:
-            da = _MatmulNT.apply(g, b.t().contiguous())                       # g @ b
+            # d opA(a) = g @ opB(b)^T^T ... in the kernel's terms: contraction over N
+            da = _MatMul.apply(b, g, not tb, False) if ta else _MatMul.apply(g, b, False, not tb)
         if ctx.needs_input_grad[1]:
-            db = _MatmulNT.apply(g.t().contiguous(), a.t().contiguous())      # g^T @ a
-        return da, db
+            db = _MatMul.apply(a, g, not ta, True) if tb else _MatMul.apply(g, a, True, not ta)
+        return da, db, None, None
+
+
+class _MatmulNT:
+    """a @ b^T (kept under its round-1 name for the call sites below)."""
+
+    @staticmethod
+    def apply(a, b):
+        return _MatMul.apply(a, b, False, False)
 
 
 def _linear_f32(x, weight, bias=None):
@@ -152,7 +151,7 @@ class SingleCellICNN(nn.Module):
 
     # -- shared forward pass: returns Psi [B,1] and what the input gradient needs
     @torch.no_grad()
-    def _forward(self, x: torch.Tensor):
+    def _forward(self, x: torch.Tensor, need_psi: bool = True):
         act = self.config.activation if self.config.activation == "softplus" else "celu"
         x = x.contiguous().float()
         xh, _, m0, r0 = ops.layernorm_fwd(x, self.input_norm.weight, self.input_norm.bias, self.input_norm.eps)
@@ -169,7 +168,8 @@ class SingleCellICNN(nn.Module):
                                     addend_scale=layer.scale)
             z, _, m, r = ops.layernorm_fwd(a, layer.norm.weight, layer.norm.bias, layer.norm.eps, act=act)
             saved.append((a, m, r, pw))
-        psi = z @ self.final.weight.t() + self.final.bias                     # [B,1] dot with one row: plumbing
+        # [B,1] dot with one row: plumbing (not needed for the transport map itself)
+        psi = z @ self.final.weight.t() + self.final.bias if need_psi else None
         return psi, (x, xh, m0, r0, saved, act)
 
     def _forward_diff(self, x: torch.Tensor, return_intermediates: bool = False):
@@ -232,18 +232,18 @@ class SingleCellICNN(nn.Module):
 
     @torch.no_grad()
     def _gradient_eval(self, x: torch.Tensor) -> torch.Tensor:
-        _, (x, xh, m0, r0, saved, act) = self._forward(x)
+        _, (x, xh, m0, r0, saved, act) = self._forward(x, need_psi=False)
         B = x.shape[0]
         dz = self.final.weight.detach().expand(B, -1).contiguous()           # d Psi / d z_K = w
         dxh = None
         for layer, (a, m, r, pw) in zip(reversed(self.layers), reversed(saved)):
-            da, _, _, _ = ops.layernorm_bwd(dz, a, layer.norm.weight, layer.norm.bias, m, r, act=act)
-            wt = layer.linear.weight.detach().t().contiguous()                # [in, out]: da @ W = gemm_nt(da, W^T)
-            dxh = ops.gemm_f32_nt(da, wt, addend=dxh)
+            da, _, _, _ = ops.layernorm_bwd(dz, a, layer.norm.weight, layer.norm.bias, m, r, act=act,
+                                            want_param_grads=False)
+            # da @ W: the weight [out, in] is the kernel's "B stored [K, N]" layout (no transposed copy)
+            dxh = ops.gemm_f32(da, layer.linear.weight.detach(), trans_b=True, addend=dxh)
             if pw is not None:
-                dz = ops.gemm_f32_nt(da, pw.t().contiguous())
-                dz = dz * layer.scale.detach()                                # scalar scale: plumbing
-        t, _, _, _ = ops.layernorm_bwd(dxh, x, self.input_norm.weight, None, m0, r0)
+                dz = ops.gemm_f32(da, pw, trans_b=True, alpha=layer.scale.detach())    # scale_k * da @ softplus(W+)
+        t, _, _, _ = ops.layernorm_bwd(dxh, x, self.input_norm.weight, None, m0, r0, want_param_grads=False)
         return t
 
 
@@ -331,6 +331,37 @@ class TripleTransportMaps(nn.Module):
         if pert_states is not None and protein_states is not None:
             out["pert_to_protein"] = self.pert_to_protein(pert_states, protein_states)
         return out
+
+
+class GraphedTransport:
+    """Eval-mode transport maps replayed from ONE hipGraph: the op is ~15 small launches per map (two LayerNorms, six
+    exact-f32 products, the fused LN + CELU passes), i.e. launch-bound in eager mode.  Static input / output buffers;
+    call with tensors of the captured shapes.
+
+        g = GraphedTransport(maps, cell, pert, protein); out = g(cell, pert, protein)     # dict like maps(...)"""
+
+    def __init__(self, maps: "TripleTransportMaps", cell, pert=None, protein=None, warmup: int = 2):
+        if maps.training:
+            raise ValueError("GraphedTransport captures the eval-mode path (no autograd graph)")
+        self.maps = maps
+        self.static_in = [None if t is None else t.detach().clone().contiguous() for t in (cell, pert, protein)]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm-up on a side stream: workspaces, lazy init
+            for _ in range(warmup):
+                maps(*self.static_in)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_out = maps(*self.static_in)
+
+    @torch.no_grad()
+    def __call__(self, cell, pert=None, protein=None):
+        for dst, src in zip(self.static_in, (cell, pert, protein)):
+            if dst is not None:
+                dst.copy_(src)
+        self.graph.replay()
+        return self.static_out
 
 
 def create_transport_system(cell_dim: int, pert_dim: int, protein_dim: int, hidden_dims: Optional[List[int]] = None,

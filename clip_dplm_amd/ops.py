@@ -290,33 +290,44 @@ def transpose_scale_f32(x, scale=None):
     return out
 
 
-F32_KMAX = 512       # clipk_gemm_f32_nt keeps one operand row block in LDS: contraction <= 768, a multiple of 4
+def gemm_f32(a, b, trans_a=False, trans_b=False, bias=None, addend=None, addend_scale=None, alpha=None):
+    """Exact-f32 out[M, N] = alpha * opA(a) @ opB(b) (+ bias) (+ addend_scale * addend) on the tiled f32-MFMA kernel
+    (alpha / addend_scale: 1-element device tensors).
+    trans_a: a is stored [K, M];  trans_b: b is stored [K, N] (else [N, K], the nn.Linear layout)."""
+    _need_cuda(a, b, bias, addend, addend_scale, alpha)
+    assert a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 2 and b.dim() == 2
+    if a.stride(1) != 1 or a.stride(0) % 4:
+        a = a.contiguous()
+    if b.stride(1) != 1 or b.stride(0) % 4:
+        b = b.contiguous()
+    K, M = (a.shape if trans_a else (a.shape[1], a.shape[0]))
+    Kb, N = (b.shape if trans_b else (b.shape[1], b.shape[0]))
+    assert K == Kb, (a.shape, b.shape, trans_a, trans_b)
+    # float4 staging wants 16-byte aligned rows: zero-pad the stored rows of an operand with an odd leading dimension
+    # (plumbing; M, N, K stay what they are, the kernel never reads the pad as data)
+    if a.stride(0) % 4:
+        a = torch.nn.functional.pad(a, (0, (-a.shape[1]) % 4))
+    if b.stride(0) % 4:
+        b = torch.nn.functional.pad(b, (0, (-b.shape[1]) % 4))
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    if addend is not None:
+        assert addend.shape == (M, N) and addend.stride(1) == 1
+    check(_timed("gemm_f32", 2.0 * M * N * K,
+                 lambda: _lib().clipk_gemm_f32(a.data_ptr(), a.stride(0), int(trans_a), b.data_ptr(), b.stride(0),
+                                               int(trans_b), M, N, K, ptr(alpha), ptr(bias), ptr(addend),
+                                               addend.stride(0) if addend is not None else 0, ptr(addend_scale),
+                                               out.data_ptr(), out.stride(0), _stream())), "clipk_gemm_f32")
+    return out
 
 
 def matmul_f32_nt(a, b):
-    """a[M, K] @ b[N, K]^T in exact f32 for any K: contraction chunks of F32_KMAX chained through the addend."""
-    K = a.shape[1]
-    if K <= F32_KMAX and K % 4 == 0 and a.is_contiguous() and b.is_contiguous():
-        return gemm_f32_nt(a, b)
-    out = None
-    for k0 in range(0, K, F32_KMAX):
-        ak, bk = a[:, k0:k0 + F32_KMAX], b[:, k0:k0 + F32_KMAX]
-        if ak.shape[1] % 4:
-            pad = 4 - ak.shape[1] % 4
-            ak, bk = torch.nn.functional.pad(ak, (0, pad)), torch.nn.functional.pad(bk, (0, pad))
-        out = gemm_f32_nt(ak.contiguous(), bk.contiguous(), addend=out)
-    return out
+    """a[M, K] @ b[N, K]^T in exact f32, any K."""
+    return gemm_f32(a, b)
 
 
 def gemm_f32_nt(x, w, bias=None, addend=None, addend_scale=None):
     """Exact-f32 out = x @ w.T (+ bias) (+ addend_scale * addend): the ICNN's Linear layers."""
-    _need_cuda(x, w, bias, addend, addend_scale)
-    M, K = x.shape
-    N = w.shape[0]
-    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
-    check(_lib().clipk_gemm_f32_nt(x.data_ptr(), M, w.data_ptr(), N, K, ptr(bias), ptr(addend), ptr(addend_scale),
-                                   out.data_ptr(), _stream()), "clipk_gemm_f32_nt")
-    return out
+    return gemm_f32(x, w, bias=bias, addend=addend, addend_scale=addend_scale)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -336,12 +347,14 @@ def layernorm_fwd(x, gamma, beta, eps, act=None, want_f32=True, want_bf16=False,
 
 
 def layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=None, dx_add=None, want_f32=True, want_bf16=False,
-                  dgamma=None, dbeta=None, accumulate=False):
+                  dgamma=None, dbeta=None, accumulate=False, want_param_grads=True):
     _need_cuda(dy, x, gamma, mean, rstd)
     rows, cols = x.shape
     dx32 = torch.empty((rows, cols), dtype=torch.float32, device=x.device) if want_f32 else None
     dx16 = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
-    if dgamma is None:
+    if not want_param_grads:                               # input gradient only (transport maps in eval mode)
+        dgamma = dbeta = None
+    elif dgamma is None:
         dgamma = torch.empty(cols, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(cols, dtype=torch.float32, device=x.device)
         accumulate = False
@@ -353,8 +366,8 @@ def layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=None, dx_add=None, want_f3
     check(_timed("layernorm_bwd", nb,
                  lambda: lib.clipk_layernorm_bwd(dy.data_ptr(), _dt(dy), dy.stride(0), x.data_ptr(), _dt(x), x.stride(0),
                                                  gamma.data_ptr(), ptr(beta), mean.data_ptr(), rstd.data_ptr(), ACT[act],
-                                                 ptr(dx_add), ptr(dx32), ptr(dx16), cols, dgamma.data_ptr(),
-                                                 dbeta.data_ptr(), int(accumulate), rows, cols, ws.data_ptr(),
+                                                 ptr(dx_add), ptr(dx32), ptr(dx16), cols, ptr(dgamma),
+                                                 ptr(dbeta), int(accumulate), rows, cols, ws.data_ptr(),
                                                  ws.numel(), _stream())), "clipk_layernorm_bwd")
     return dx32, dx16, dgamma, dbeta
 

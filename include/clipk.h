@@ -173,6 +173,18 @@ int clipk_gemm_f32_nt(const float* X, int M, const float* W, int N, int K, const
                       const float* addend, const float* addend_scale /* device scalar or NULL (=1) */,
                       float* out, void* stream);
 
+/* Tiled exact-f32 GEMM (v_mfma_f32_32x32x2_f32, 128 x 64 tiles, LDS-staged) with all four operand layouts:
+ *   out[M,N] = alpha[0] * opA(A) · opB(B) (+ bias[N]) (+ addend_scale[0] * addend[M,N])     (alpha NULL = 1)
+ *   transA == 0: A is [M,K] (lda);  transA == 1: A is stored [K,M] (contraction-major: dW = dY^T X)
+ *   transB == 0: B is [N,K] (nn.Linear weight, out = A·B^T);  transB == 1: B is stored [K,N] (dA = dZ · W)
+ * Every product of the ICNN potential, of its input gradient T(x) = dPsi/dx and of the training path's double backward
+ * (triple_flow/2_icnn_core.py:102-119,181-211 under autocast(enabled=False)), and the gradients of the materialised
+ * logits (old/clip.py:67): no transposed copies, any K.  lda / ldb % 4 == 0, A / B 16-byte aligned. */
+int clipk_gemm_f32(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB,
+                   int M, int N, int K, const float* alpha /* device scalar or NULL */, const float* bias,
+                   const float* addend, int64_t ldadd, const float* addend_scale /* device scalar or NULL (=1) */,
+                   float* out, int64_t ldo, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Row-wise normalisation kernels (one wave per row, f32 statistics).
  * LayerNorm forward:  y = (x-mean)*rstd*gamma + beta, optional activation fused after it

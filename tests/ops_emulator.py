@@ -128,6 +128,17 @@ def matmul_f32_nt(a, b):
     return a @ b.t()
 
 
+def gemm_f32(a, b, trans_a=False, trans_b=False, bias=None, addend=None, addend_scale=None, alpha=None):
+    out = (a.t() if trans_a else a) @ (b if trans_b else b.t())
+    if alpha is not None:
+        out = out * alpha
+    if bias is not None:
+        out = out + bias
+    if addend is not None:
+        out = out + (addend_scale if addend_scale is not None else 1.0) * addend
+    return out
+
+
 def transpose_scale_f32(x, scale=None):
     return (x.t() * (scale if scale is not None else 1.0)).contiguous()
 
@@ -161,7 +172,7 @@ def layernorm_fwd(x, gamma, beta, eps, act=None, want_f32=True, want_bf16=False,
     return (y if want_f32 else None), (y.to(BF) if want_bf16 else None), mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=None, dx_add=None, want_f32=True, want_bf16=False,
+def layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=None, dx_add=None, want_f32=True, want_bf16=False, want_param_grads=True,
                   dgamma=None, dbeta=None, accumulate=False):
     xf, dyf = x.float(), dy.float()
     xh = (xf - mean[:, None]) * rstd[:, None]

@@ -685,3 +685,27 @@ def test_pool_varlen(dev):
         yr = torch.stack([xr[a] if mode == 0 else xr[a:b].mean(0) for a, b in zip(cu[:-1].tolist(), cu[1:].tolist())])
         yr.backward(dy)
         assert torch.allclose(dx, xr.grad, rtol=1e-5, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------------ tiled f32 GEMM
+@pytest.mark.parametrize("M,N,K", [(4096, 512, 512), (64, 256, 512), (1030, 130, 66), (300, 64, 1030), (17, 8, 4),
+                                   (2048, 768, 2050)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_f32_all_layouts(dev, M, N, K, ta, tb):
+    """clipk_gemm_f32 (tiled v_mfma_f32_32x32x2_f32): all four operand layouts, ragged M / N / K (K % 16, % 4 != 0,
+    odd leading dimensions), bias and scaled addend, against f64; exact-f32 products: error ~1e-7 * sum |a b|."""
+    ops = _ops()
+    a = _rand((K, M) if ta else (M, K), dev, 51)
+    b = _rand((K, N) if tb else (N, K), dev, 52, 0.1)
+    bias, add = _rand((N,), dev, 53), _rand((M, N), dev, 54)
+    sc = torch.tensor([0.37], device=dev)
+    A = a.double().t() if ta else a.double()
+    Bm = b.double() if tb else b.double().t()
+    ref = A @ Bm
+    bound = 4e-7 * (A.abs() @ Bm.abs()) + 1e-6
+    out = ops.gemm_f32(a, b, trans_a=ta, trans_b=tb)
+    assert ((out.double() - ref).abs() <= bound).all(), (out.double() - ref).abs().max()
+    out2 = ops.gemm_f32(a, b, trans_a=ta, trans_b=tb, bias=bias, addend=add, addend_scale=sc)
+    ref2 = ref + bias.double() + 0.37 * add.double()
+    assert ((out2.double() - ref2).abs() <= bound + 1e-6).all()
+    assert torch.equal(out, ops.gemm_f32(a, b, trans_a=ta, trans_b=tb))        # deterministic
