@@ -117,6 +117,15 @@ def _join_side(*tensors):
                 t.record_stream(cur)
 
 
+def _bucket_done(module, grads):
+    """End of a stack's backward: with every parameter gradient written straight into the flat .grad buffer (all
+    returned grads None) the stack's gradient bucket is final, and a sharded FusedAdamW may start its reduce-scatter on
+    a side stream under the rest of the backward (optim.FusedAdamW._reduce_bucket)."""
+    cb = getattr(module, "_grad_bucket_done", None)
+    if cb is not None and all(g is None for g in grads):
+        cb()
+
+
 class _Lin:
     """Kernel-side view of one Linear: f32 master params + cached bf16 W / W^T.  gw / gb: explicit gradient buffers
     (fused views of several parameters' .grad), used instead of w.grad / b.grad by the direct-accumulation path."""
@@ -210,19 +219,18 @@ class EsmStackFn(torch.autograd.Function):
             saved.append(s if need_bwd else None)
         y, _, mf, rf = ops.layernorm_fwd(x, fin_w, fin_b, module.eps, want_f32=True)
         ctx.module, ctx.meta, ctx.layers, ctx.saved = module, meta, layers, saved
-        ctx.fin = (x, fin_w, mf, rf)
+        ctx.fin = (x, fin_w, fin_b, mf, rf)
         ctx.ids, ctx.row_scale = ids, row_scale
-        ctx.table_shape = table.shape
+        ctx.table = table
         return y
 
     @staticmethod
     def backward(ctx, dy):
         module, meta = ctx.module, ctx.meta
-        x, fin_w, mf, rf = ctx.fin
+        x, fin_w, fin_b, mf, rf = ctx.fin
         nl = module.num_layers
         grads: List[Optional[torch.Tensor]] = [None] * (3 + 12 * nl)
-        dx, dxb, grads[1], grads[2] = ops.layernorm_bwd(dy.contiguous(), x, fin_w, None, mf, rf, want_f32=True,
-                                                        want_bf16=True)
+        dx, dxb, grads[1], grads[2] = _ln_bwd(dy.contiguous(), x, fin_w, fin_b, mf, rf, want_f32=True, want_bf16=True)
         for i in reversed(range(nl)):
             dx, dxb, gr = _esm_layer_bwd(dx, dxb, ctx.layers[i], ctx.saved[i], meta, need_dx_bf16=i > 0)
             ctx.saved[i] = None                                     # free this layer's activations now
@@ -230,13 +238,16 @@ class EsmStackFn(torch.autograd.Function):
                 grads[3 + 12 * i + j] = gr[k]
         if ctx.needs_input_grad[5]:
             mask_u8 = meta[4]
-            dtable = torch.zeros(ctx.table_shape, dtype=torch.float32, device=dx.device)
+            table = ctx.table
+            direct = DIRECT_PARAM_GRADS and _direct_ok(table)       # the kernel accumulates: straight into table.grad
+            dtable = table.grad if direct else torch.zeros(table.shape, dtype=torch.float32, device=dx.device)
             ops.embed_bwd(ctx.ids, dx, dtable, row_scale=ctx.row_scale,
                           mask=mask_u8.view(-1) if mask_u8 is not None else None,
                           mask_token_id=module.mask_token_id if module.token_dropout else -1)
-            grads[0] = dtable
-        ctx.layers = ctx.saved = None
+            grads[0] = None if direct else dtable
+        ctx.layers = ctx.saved = ctx.table = None
         _join_side(*grads)
+        _bucket_done(module, grads)
         return (None, None, None, None, None, *grads)
 
 
@@ -296,6 +307,8 @@ class ESM2Encoder(nn.Module):
     forward(input_ids [B,L] int64, attention_mask [B,L] or None) -> last_hidden_state [B, L, d] (f32).
     q/k/v weights are kept as three nn.Linear (checkpoint compatible) and fused into one [3d, d] GEMM operand.
     """
+
+    grad_bucket = True          # FlatParams stores this stack's parameters as one bucket (multi-GPU gradient overlap)
 
     def __init__(self, num_layers=12, hidden_size=480, num_heads=20, intermediate_size=1920, vocab_size=33,
                  pad_token_id=1, mask_token_id=32, layer_norm_eps=1e-5, token_dropout=True, initializer_range=0.02):
@@ -474,16 +487,16 @@ class PostLNStackFn(torch.autograd.Function):
             saved.append(s if need_bwd else None)
         y, _, mf, rf = ops.layernorm_fwd(x, fin_w, fin_b, module.final_eps, want_f32=True)
         ctx.module, ctx.meta, ctx.layers, ctx.saved = module, meta, layers, saved
-        ctx.fin = (x, fin_w, mf, rf)
+        ctx.fin = (x, fin_w, fin_b, mf, rf)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         module, meta = ctx.module, ctx.meta
-        x, fin_w, mf, rf = ctx.fin
+        x, fin_w, fin_b, mf, rf = ctx.fin
         nl = module.num_layers
         grads: List[Optional[torch.Tensor]] = [None] * (2 + 12 * nl)
-        dx, _, grads[0], grads[1] = ops.layernorm_bwd(dy.contiguous(), x, fin_w, None, mf, rf, want_f32=True)
+        dx, _, grads[0], grads[1] = _ln_bwd(dy.contiguous(), x, fin_w, fin_b, mf, rf, want_f32=True)
         for i in reversed(range(nl)):
             dx, gr = _post_layer_bwd(dx, ctx.layers[i], ctx.saved[i], meta)
             ctx.saved[i] = None
@@ -491,6 +504,7 @@ class PostLNStackFn(torch.autograd.Function):
                 grads[2 + 12 * i + j] = gr[k]
         ctx.layers = ctx.saved = None
         _join_side(*grads)
+        _bucket_done(module, grads)
         return (None, dx if ctx.needs_input_grad[1] else None, None, None, None, None, *grads)
 
 
@@ -523,6 +537,8 @@ class TransformerSeqEncoder(nn.Module):
     Attention runs over axis 1 (per sequence).  To reproduce the notebook's batch-axis attention quirk
      pass x.transpose(0, 1) and the matching mask — see RNARBPCLIPModel.
     """
+
+    grad_bucket = True          # see ESM2Encoder
 
     def __init__(self, embed_dim=768, num_layers=6, nhead=8, dim_feedforward=2048, activation="gelu",
                  layer_norm_eps=1e-12, final_eps=None, dropout: float = 0.0):

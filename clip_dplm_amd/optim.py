@@ -61,13 +61,32 @@ class FlatParams:
                 if id(q) not in seen:
                     seen.add(id(q))
                     order.append((q, q is grp[-1]))               # pad to the alignment only after the last member
-        params = [q for q, _ in order]
-        offs, total = [], 0
-        for p, pad in order:
-            offs.append(total)
-            total += ((p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN) if pad else p.numel()
+        # Gradient buckets (multi-GPU): the parameters of every sub-module that declares `grad_bucket = True` (the two
+        # encoder stacks: their hand-written backward announces when the whole stack's gradients are final) are stored
+        # together, each bucket padded to a multiple of world_size * _ALIGN so that it can be reduce-scattered /
+        # all-gathered on its own while the rest of the backward still runs; everything else forms the last bucket.
+        bucket_of, roots = {}, []
+        for mod in module.modules():
+            if getattr(mod, "grad_bucket", False):
+                roots.append(mod)
+                for q in mod.parameters():
+                    bucket_of.setdefault(id(q), len(roots) - 1)
+        nb = len(roots) + 1
+        by_bucket = [[] for _ in range(nb)]
+        for item in order:
+            by_bucket[bucket_of.get(id(item[0]), nb - 1)].append(item)
         chunk = _ALIGN * max(world_size, 1)
-        total = (total + chunk - 1) // chunk * chunk          # shard size stays _ALIGN-aligned
+        params, offs, total, self.buckets = [], [], 0, []
+        for b, items in enumerate(by_bucket):
+            if not items:
+                continue
+            start = total
+            for p, pad in items:
+                params.append(p)
+                offs.append(total)
+                total += ((p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN) if pad else p.numel()
+            total = (total + chunk - 1) // chunk * chunk      # every bucket splits evenly into _ALIGN-aligned pieces
+            self.buckets.append((start, total, roots[b] if b < len(roots) else None))
         self.params, self.offsets, self.numel = params, offs, total
         self.data = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -85,15 +104,24 @@ class FlatParams:
 
 
 class FusedAdamW:
-    """AdamW (torch.optim.AdamW semantics) + clip_grad_norm_ folded in, on FlatParams; optional sharding."""
+    """AdamW (torch.optim.AdamW semantics) + clip_grad_norm_ folded in, on FlatParams; optional sharding.
+
+    Sharded (group given, one process per GPU, RCCL): ZeRO-1 by BUCKET.  The flat buffer is a sequence of buckets (one
+    per encoder stack + one for the rest, FlatParams); rank r owns the r-th 1/W piece of every bucket, so a bucket can be
+    reduce-scattered as soon as its gradients are final: the encoder stacks' backward calls back when that is the case
+    and the collective runs on a side stream under the rest of the backward (`overlap`, default on for NCCL/RCCL).
+    step() reduces what is left, clips by the global norm (one scalar all-reduce), updates this rank's pieces and
+    all-gathers the updated parameters bucket by bucket.  `grad_comm_dtype=torch.bfloat16` halves the gradient payload
+    (sum in bf16 on the wire: off by default, the reference reduces f32 gradients)."""
 
     def __init__(self, module: torch.nn.Module, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01,
-                 max_grad_norm: Optional[float] = 1.0, group=None):
+                 max_grad_norm: Optional[float] = 1.0, group=None, overlap: Optional[bool] = None,
+                 grad_comm_dtype: torch.dtype = torch.float32):
         self.group = group
         self.world = dist.get_world_size(group) if group is not None else 1
         self.rank = dist.get_rank(group) if group is not None else 0
         # parameter order of module.parameters() (what torch.optim.AdamW(model.parameters()) would index): the flat
-        # buffer may store them in another order (fused qkv groups)
+        # buffer may store them in another order (fused qkv groups, buckets)
         self.param_order = [p for p in module.parameters() if p.requires_grad]
         self.flat = FlatParams(module, self.world)
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
@@ -102,40 +130,84 @@ class FusedAdamW:
         n = self.flat.numel
         self.shard = n // self.world
         dev = self.flat.data.device
+        # this rank's pieces: (flat_lo, flat_hi, offset inside the shard-sized buffers m / v / gshard)
+        self.pieces, off = [], 0
+        for (s0, s1, _) in self.flat.buckets:
+            piece = (s1 - s0) // self.world
+            self.pieces.append((s0 + self.rank * piece, s0 + (self.rank + 1) * piece, off))
+            off += piece
+        assert off == self.shard
         self.m = torch.zeros(self.shard, dtype=torch.float32, device=dev)
         self.v = torch.zeros(self.shard, dtype=torch.float32, device=dev)
         self.gshard = torch.empty(self.shard, dtype=torch.float32, device=dev) if group is not None else None
         self.norm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.grad_comm_dtype = grad_comm_dtype
+        self._nccl = group is not None and dist.get_backend(group) != "gloo"
+        self.overlap = (self._nccl if overlap is None else bool(overlap)) and group is not None
+        self._comm = torch.cuda.Stream(device=dev) if (self._nccl and dev.type == "cuda") else None
+        self._reduced = [False] * len(self.flat.buckets)
+        if self.overlap:
+            for b, (_, _, root) in enumerate(self.flat.buckets):
+                if root is not None:
+                    root._grad_bucket_done = (lambda b=b: self._reduce_bucket(b))
 
     def zero_grad(self):
         self.flat.zero_grad()
+        self._reduced = [False] * len(self.flat.buckets)
+
+    # ---- gradient reduce-scatter of one bucket (called from the encoder stacks' backward, or from step())
+    def _reduce_bucket(self, b: int) -> None:
+        if self.group is None or self._reduced[b]:
+            return
+        s0, s1, _ = self.flat.buckets[b]
+        lo, hi, off = self.pieces[b]
+        dst = self.gshard[off:off + (hi - lo)]
+        src = self.flat.grad[s0:s1]
+        if not self._nccl:                                   # gloo (CPU tests) has no reduce_scatter
+            dist.all_reduce(src, group=self.group)
+            dst.copy_(self.flat.grad[lo:hi])
+        else:
+            cur = torch.cuda.current_stream()
+            stream = self._comm if self._comm is not None else cur
+            if stream is not cur:
+                stream.wait_event(cur.record_event())        # the bucket's gradients are final at this point
+            with torch.cuda.stream(stream):
+                if self.grad_comm_dtype == torch.float32:
+                    dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.SUM, group=self.group)
+                else:
+                    lowp = src.to(self.grad_comm_dtype)
+                    out = torch.empty(hi - lo, dtype=self.grad_comm_dtype, device=src.device)
+                    dist.reduce_scatter_tensor(out, lowp, op=dist.ReduceOp.SUM, group=self.group)
+                    dst.copy_(out)
+        self._reduced[b] = True
 
     @torch.no_grad()
     def step(self, lr: Optional[float] = None) -> torch.Tensor:
         """Returns the (device) squared global gradient norm before clipping."""
         self.step_count += 1
         lr = self.lr if lr is None else lr
-        lo = self.rank * self.shard
-        if self.gshard is not None:
-            if dist.get_backend(self.group) == "gloo":
-                dist.all_reduce(self.flat.grad, group=self.group)
-                self.gshard.copy_(self.flat.grad[lo:lo + self.shard])
-            else:
-                dist.reduce_scatter_tensor(self.gshard, self.flat.grad, op=dist.ReduceOp.SUM, group=self.group)
+        if self.group is not None:
+            for b in range(len(self.flat.buckets)):
+                self._reduce_bucket(b)                       # whatever the backward has not sent yet
+            if self._comm is not None:
+                torch.cuda.current_stream().wait_stream(self._comm)
             g = self.gshard
         else:
             g = self.flat.grad
-        w = self.flat.data[lo:lo + self.shard]
         _kernels.sumsq(g, out=self.norm_sq)
         if self.group is not None:
             dist.all_reduce(self.norm_sq, group=self.group)
         clip = self.max_grad_norm is not None and self.max_grad_norm > 0
-        _kernels.adamw_step(w, g, self.m, self.v, lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count,
-                            grad_norm_sq=self.norm_sq if clip else None,
-                            max_norm=self.max_grad_norm if clip else 0.0)
+        for (lo, hi, off) in self.pieces:
+            n = hi - lo
+            _kernels.adamw_step(self.flat.data[lo:hi], g[off:off + n], self.m[off:off + n], self.v[off:off + n], lr,
+                                self.betas[0], self.betas[1], self.eps, self.wd, self.step_count,
+                                grad_norm_sq=self.norm_sq if clip else None,
+                                max_norm=self.max_grad_norm if clip else 0.0)
         if self.group is not None:
-            dist.all_gather_into_tensor(self.flat.data, w.clone() if dist.get_backend(self.group) == "gloo" else w,
-                                        group=self.group)
+            for (s0, s1, _), (lo, hi, _off) in zip(self.flat.buckets, self.pieces):
+                w = self.flat.data[lo:hi]
+                dist.all_gather_into_tensor(self.flat.data[s0:s1], w if self._nccl else w.clone(), group=self.group)
         KF.mark_weights_dirty()              # bf16 W / W^T copies of the Linear weights are stale now ...
         if self.flat.data.is_cuda and os.environ.get("CLIPK_BATCH_REFRESH", "1") != "0":
             KF.refresh_weight_caches()       # ... rebuild them in one launch (what is left is refreshed lazily)
@@ -148,19 +220,17 @@ class FusedAdamW:
         """Full-length (m, v) on every rank: the moments are sharded 1/W per rank (ZeRO-1)."""
         if self.group is None or self.world == 1:
             return self.m, self.v
-        if dist.get_backend(self.group) == "gloo":
-            full = [torch.zeros(self.flat.numel, dtype=torch.float32, device=self.m.device) for _ in range(2)]
-            lo = self.rank * self.shard
-            full[0][lo:lo + self.shard].copy_(self.m)
-            full[1][lo:lo + self.shard].copy_(self.v)
+        full = [torch.zeros(self.flat.numel, dtype=torch.float32, device=self.m.device) for _ in range(2)]
+        for (s0, s1, _), (lo, hi, off) in zip(self.flat.buckets, self.pieces):
+            for dst, src in ((full[0], self.m), (full[1], self.v)):
+                if self._nccl:
+                    dist.all_gather_into_tensor(dst[s0:s1], src[off:off + hi - lo].contiguous(), group=self.group)
+                else:
+                    dst[lo:hi].copy_(src[off:off + hi - lo])
+        if not self._nccl:
             dist.all_reduce(full[0], group=self.group)
             dist.all_reduce(full[1], group=self.group)
-            return full[0], full[1]
-        m = torch.empty(self.flat.numel, dtype=torch.float32, device=self.m.device)
-        v = torch.empty_like(m)
-        dist.all_gather_into_tensor(m, self.m, group=self.group)
-        dist.all_gather_into_tensor(v, self.v, group=self.group)
-        return m, v
+        return full[0], full[1]
 
     def state_dict(self):
         """torch.optim.AdamW.state_dict() layout: {'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [..]}
@@ -188,7 +258,10 @@ class FusedAdamW:
     def load_state_dict(self, sd):
         """Accepts torch.optim.AdamW.state_dict() (and what state_dict() above returns); the legacy
         {'step', 'm', 'v'} flat format of round 1 is still read when world size matches."""
-        if "param_groups" not in sd:                     # legacy private format
+        if "param_groups" not in sd:                     # legacy private format (single process only)
+            if self.world != 1:
+                raise ValueError("the round-1 {'step','m','v'} optimiser state holds one rank's shard: load a "
+                                 "torch.optim.AdamW-format state (FusedAdamW.state_dict()) instead")
             self.step_count = int(sd["step"])
             self.m.copy_(sd["m"])
             self.v.copy_(sd["v"])
@@ -205,7 +278,6 @@ class FusedAdamW:
         self.eps = float(g["eps"])
         self.wd = float(g["weight_decay"])
         off = {id(p): o for p, o in zip(self.flat.params, self.flat.offsets)}
-        lo, hi = self.rank * self.shard, (self.rank + 1) * self.shard
         steps = set()
         self.m.zero_()
         self.v.zero_()
@@ -215,12 +287,13 @@ class FusedAdamW:
                 continue
             steps.add(int(round(float(st["step"]))))
             o, n = off[id(p)], p.numel()
-            a, b = max(o, lo), min(o + n, hi)            # the part of this parameter that lives in this rank's shard
-            if a >= b:
-                continue
-            for dst, key in ((self.m, "exp_avg"), (self.v, "exp_avg_sq")):
-                src = st[key].reshape(-1).to(device=dst.device, dtype=torch.float32)
-                dst[a - lo:b - lo].copy_(src[a - o:b - o])
+            for (lo, hi, soff) in self.pieces:           # the parts of this parameter that live in this rank's pieces
+                a, b = max(o, lo), min(o + n, hi)
+                if a >= b:
+                    continue
+                for dst, key in ((self.m, "exp_avg"), (self.v, "exp_avg_sq")):
+                    src = st[key].reshape(-1).to(device=dst.device, dtype=torch.float32)
+                    dst[soff + a - lo:soff + b - lo].copy_(src[a - o:b - o])
         if len(steps) > 1:
             raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): the fused step keeps one counter")
         self.step_count = steps.pop() if steps else 0

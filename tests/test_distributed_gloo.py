@@ -92,10 +92,22 @@ def _worker(rank, world, initfile, results):
         pl.backward()
         gsum = popt.flat.grad.detach().clone()               # this rank's contribution, written by the kernels
         dist.all_reduce(gsum)
-        out["pgrad"] = gsum
-        popt.step()                                           # reduce-scatter, shard update, all-gather
-        out["pparams"] = popt.flat.data.detach().clone()
+        # by parameter: the flat layout (bucket padding) depends on the world size
+        out["pgrad"] = torch.cat([gsum[o:o + p.numel()] for p, o in zip(popt.flat.params, popt.flat.offsets)])
+        assert len(popt.flat.buckets) == 3                    # ESM stack | RNA stack | heads + logit_scale
+        popt.step()                                           # bucketed reduce-scatter, piece update, all-gather
+        out["pparams"] = torch.cat([p.detach().reshape(-1) for p in popt.flat.params])
         out["ptrain_loss"] = pl.item()
+        # ---- (5) the same step with the buckets reduced FROM INSIDE the backward (the encoder stacks call back when
+        # their gradients are final; on RCCL that collective runs on a side stream under the rest of the backward)
+        torch.manual_seed(0)
+        pm2 = K.ProteinRNACLIP(esm="test_tiny", rna_dim=64, rna_layers=1, rna_heads=8, rna_ffn=128, projection_dim=32).eval()
+        popt2 = K.FusedAdamW(pm2, lr=1e-3, weight_decay=0.01, max_grad_norm=1.0, group=dist.group.WORLD, overlap=True)
+        popt2.zero_grad()
+        pm2.loss(rna[sl6], ids[sl6], group=dist.group.WORLD).backward()
+        out["buckets_reduced_in_backward"] = list(popt2._reduced)
+        popt2.step()
+        out["pparams_overlap"] = torch.cat([p.detach().reshape(-1) for p in popt2.flat.params])
         results[rank] = out
     finally:
         dist.destroy_process_group()
@@ -170,7 +182,7 @@ def test_world2_matches_single_process():
     popt.zero_grad()
     pl = pm.loss(rna, ids)
     pl.backward()
-    gref = popt.flat.grad.detach().clone()
+    gref = torch.cat([popt.flat.grad[o:o + p.numel()] for p, o in zip(popt.flat.params, popt.flat.offsets)]).clone()
     for r in range(world):
         assert abs(res[r]["ptrain_loss"] - pl.item()) < 2e-3, (res[r]["ptrain_loss"], pl.item())
         # summed per-rank gradients == single-process gradient of the concatenated batch (bf16 operand rounding
@@ -181,3 +193,7 @@ def test_world2_matches_single_process():
         assert torch.nn.functional.cosine_similarity(g, gref, dim=0) > 0.995
     # after the sharded step every rank holds the same parameters (all-gather of the updated shards)
     assert torch.equal(res[0]["pparams"], res[1]["pparams"])
+    # (5) reducing the two encoder buckets from inside the backward changes nothing but the schedule
+    for r in range(world):
+        assert res[r]["buckets_reduced_in_backward"] == [True, True, False]
+        assert torch.equal(res[r]["pparams_overlap"], res[r]["pparams"])
