@@ -353,7 +353,7 @@ def bench_clip(args):
             parity["bar"] = 1e-3
             parity["note"] = "step-0 loss, initial weights, 32 pairs (seed 4321), full depth; oracle = CPU f32 restatement"
             out["parity"] = parity
-    print(json.dumps(out), flush=True)
+    emit(out)
     if dist.is_initialized():
         dist.destroy_process_group()
 
@@ -421,7 +421,7 @@ def bench_c3sim(args):
            "kernels": {"simce_lse": {"avg_us": round(lse_us, 2), "GBps": round(bytes_lse / (lse_us * 1e-6) / 1e9, 1)},
                        "simce_grad": {"avg_us": round(grad_us, 2), "GBps": round(bytes_grad / (grad_us * 1e-6) / 1e9, 1),
                                       "f32_mfma_tflops": round(2 * flop_lse / (grad_us * 1e-6) / 1e12, 1)}}}
-    print(json.dumps(out), flush=True)
+    emit(out)
 
 
 # ====================================================================================================== c5
@@ -473,15 +473,33 @@ def bench_c5(args):
                         "note": "the op is exact-f32 matrix work (2.1 MFLOP / sample / map at 64 FLOP/clk/SIMD): its own "
                                 "bound is the f32 matrix pipe, not HBM"},
            "eager_ms_per_step": round(1e3 * dt_eager / args.steps, 4)}
-    print(json.dumps(out), flush=True)
+    emit(out)
+
+
+_JSON_FD = None
+
+
+def emit(obj) -> None:
+    """The ONE JSON line, on the process's original stdout."""
+    line = (json.dumps(obj) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
 
 
 def main():
+    global _JSON_FD
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         if args.config not in ("c2", "c4"):
             raise SystemExit(f"--config {args.config} is a one-GPU kernel bench")
         sys.exit(self_launch(args))
+    # stdout carries exactly one JSON line: library chatter (RCCL prints a version banner on stdout at the first
+    # collective) is sent to stderr by pointing fd 1 there; the JSON goes to a duplicate of the original stdout
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     if args.config in ("c2", "c4"):
         bench_clip(args)
     elif args.config == "c3sim":
