@@ -34,6 +34,7 @@ class GemmArgs(C.Structure):
         ("dact", C.c_int),
         ("residual", C.c_void_p), ("ldr", C.c_int64), ("r_dtype", C.c_int),
         ("alpha", C.c_float),
+        ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
     ]
 
 
@@ -66,7 +67,7 @@ SIGNATURES = {
     "clipk_layernorm_fwd": (_i, [_vp, _i, _i64, _vp, _vp, _f, _i, _vp, _vp, _i64, _vp, _vp, _i, _i, _vp]),
     "clipk_layernorm_bwd_workspace": (_sz, [_i, _i]),
     "clipk_layernorm_bwd": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i64,
-                                 _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+                                 _vp, _vp, _i, _i, _i, _f, C.c_uint32, _vp, _sz, _vp]),
     "clipk_l2norm_fwd": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
     "clipk_l2norm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "clipk_cast_f32_to_bf16": (_i, [_vp, _vp, _i64, _vp]),
@@ -77,12 +78,13 @@ SIGNATURES = {
     "clipk_act_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _vp]),
     "clipk_dact": (_i, [_vp, _i, _vp, _i, _vp, _i64, _vp]),
     "clipk_axpby_dev": (_i, [_vp, _vp, _vp, _vp, _i64, _vp]),
-    "clipk_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
-    "clipk_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "clipk_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, C.c_uint32, _vp]),
+    "clipk_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, C.c_uint32, _vp]),
     "clipk_rope_qk": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "clipk_attn_fwd_rot": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
-    "clipk_attn_varlen_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
-    "clipk_attn_varlen_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "clipk_attn_varlen_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, C.c_uint32, _vp]),
+    "clipk_attn_varlen_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, C.c_uint32,
+                                   _vp]),
     "clipk_embed_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     "clipk_embed_bwd_workspace": (_sz, [_i, _i, _i, _i]),
     "clipk_embed_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),

@@ -46,7 +46,14 @@ struct AP {
   // occupies token rows [cu[b], cu[b+1]) of the packed [T, ...] tensors, L is the LONGEST sequence (grid sizing only),
   // the per-row statistics (lse, delta) are [H][T].  cu == nullptr: the padded [B, L] layout.
   const int* cu; int T;
+  // dropout on the attention probabilities (nn.MultiheadAttention(dropout=p) inside nn.TransformerEncoderLayer,
+  // current/rna_clip_codes.ipynb:1915): P~ = P * keep / (1 - p) feeds P·V; the softmax normaliser uses P.  drop_thr = 0:
+  // off.  Element index = ((token row of the query) * H + h) * L + key (L = p.L, the padded / longest length).
+  unsigned drop_thr, drop_seed; float drop_scale;
 };
+__device__ __forceinline__ float attn_drop(const AP& p, long qrow, int h, int key) {
+  return drop_mul(p.drop_seed, ((unsigned long long)qrow * p.H + h) * (unsigned long long)p.L + key, p.drop_thr, p.drop_scale);
+}
 
 // first token row and length of sequence b (L comes in as p.L)
 __device__ __forceinline__ long seq_rows(const AP& p, int b, int& L) {
@@ -288,7 +295,9 @@ template <int DP, int BLK> struct StagerFor<DP, 0, BLK> { typedef ChunkStager<DP
 // =================================================================================================
 // forward: one workgroup = 128 queries of one (batch, head); 4 waves x 32 queries; KVB-key staged blocks
 // =================================================================================================
-template <int DP, int DR, int DX>
+// DROP: dropout on the attention probabilities compiled in (a separate instantiation: the p = 0 kernels carry no
+// trace of it)
+template <int DP, int DR, int DX, bool DROP = false>
 __global__ __launch_bounds__(256, Geo<DP>::WG_FWD) void attn_fwd_kernel(const AP p) {
   constexpr int RS = Geo<DP>::RS, KS = Geo<DP>::KS, DT = Geo<DP>::DT, NCH = Geo<DP>::NCH, KVB = Geo<DP>::KVB;
   constexpr int NSUB = KVB / 64;
@@ -412,6 +421,14 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_FWD) void attn_fwd_kernel(const AP
         m_run[qt] = m_new;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[dt][qt] *= alpha;
+        if constexpr (DROP) {                                      // the normaliser above saw P itself
+          const long qrow = row0 + q0 + wid * 32 + qt * 16 + li;
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              s[kt][qt][r] *= attn_drop(p, qrow, h, kb * KVB + sub * 64 + kt * 16 + 4 * g + r);
+        }
         pb[qt][0] = pack_acc_pair(s[0][qt], s[1][qt]);
         pb[qt][1] = pack_acc_pair(s[2][qt], s[3][qt]);
       }
@@ -531,7 +548,9 @@ __device__ __forceinline__ void store_grad_row(const float* row, unsigned short*
 // =================================================================================================
 // backward dQ (+ delta): one workgroup = 128 queries, sweeps KVB-key blocks
 // =================================================================================================
-template <int DP, int DR, int DX>
+// DROP: dropout on the attention probabilities compiled in (a separate instantiation: the p = 0 kernels carry no
+// trace of it)
+template <int DP, int DR, int DX, bool DROP = false>
 __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dq_kernel(const AP p) {
   constexpr int RS = Geo<DP>::RS, KS = Geo<DP>::KS, DT = Geo<DP>::DT, NCH = Geo<DP>::NCH, KVB = Geo<DP>::KVB;
   constexpr int NSUB = KVB / 64, ILD = DP + 4;
@@ -687,7 +706,13 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dq_kernel(const
 #pragma unroll
           for (int qt = 0; qt < 2; ++qt) {
             const float pv = fast_exp2(s[kt][qt][r] * c2 - lse2[qt]);
-            s[kt][qt][r] = pv * dp[kt][qt][r];                     // dS^T (w.r.t. the scaled score)
+            float dpv = dp[kt][qt][r];                             // dP - delta
+            if constexpr (DROP) {                                  // dP passes through the dropout mask, delta does not
+              const long qrow = row0 + q0 + wid * 32 + qt * 16 + li;
+              const float ms = attn_drop(p, qrow, h, kb * KVB + sub * 64 + kt * 16 + 4 * g + r);
+              dpv = (dpv + dl[qt]) * ms - dl[qt];
+            }
+            s[kt][qt][r] = pv * dpv;                               // dS^T (w.r.t. the scaled score)
           }
       bf16x8 db[2][2];
 #pragma unroll
@@ -733,7 +758,9 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dq_kernel(const
 // =================================================================================================
 // backward dK/dV: one workgroup = KVB keys (4 waves x KVB/4), sweeps KVB-query blocks
 // =================================================================================================
-template <int DP, int DR, int DX>
+// DROP: dropout on the attention probabilities compiled in (a separate instantiation: the p = 0 kernels carry no
+// trace of it)
+template <int DP, int DR, int DX, bool DROP = false>
 __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dkv_kernel(const AP p) {
   constexpr int RS = Geo<DP>::RS, KS = Geo<DP>::KS, DT = Geo<DP>::DT, KVB = Geo<DP>::KVB, ILD = DP + 4;
   constexpr int KPB = Geo<DP>::KPB;                       // this workgroup's keys
@@ -844,8 +871,15 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dkv_kernel(cons
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float pv = fast_exp2(s[kt][r] * c2 - ls[r]);
-            s[kt][r] = pv;                                      // P
-            dp[kt][r] = pv * dp[kt][r];                         // dS = P (dP - delta)
+            float pd = pv, dpv = dp[kt][r];
+            if constexpr (DROP) {                               // dV sees the dropped-out P; dP passes through the mask
+              const long qrow = row0 + qb * QB + (2 * s2 + qq) * 16 + 4 * g + r;
+              const float ms = attn_drop(p, qrow, h, k0 + wid * KPW + kt * 16 + li);
+              pd = pv * ms;
+              dpv = (dpv - nd[r]) * ms + nd[r];                 // nd = -delta
+            }
+            s[kt][r] = pd;                                      // P (after dropout) for dV
+            dp[kt][r] = pv * dpv;                               // dS = P (dP - delta)
           }
           pk[qq][kt] = u32x2{pack_bf16x2(s[kt][0], s[kt][1]), pack_bf16x2(s[kt][2], s[kt][3])};
           dsk[qq][kt] = u32x2{pack_bf16x2(dp[kt][0], dp[kt][1]), pack_bf16x2(dp[kt][2], dp[kt][3])};
@@ -1437,7 +1471,7 @@ template <int DP, int DR, int DX>
 int launch_fwd(const AP& p, hipStream_t st) {
   if constexpr (DP == 32 && DR == 0) {
     // short heads whose rows need no rotation: whole-head kernel (option attn_whole_fwd = 0: the general one)
-    if (!p.cu && whole_fwd_applies(p.L, p.D)) {
+    if (!p.cu && !p.drop_thr && whole_fwd_applies(p.L, p.D)) {
       switch (p.D) {
         case 16: launch_fwd_whole<16, false>(p, st); break;
         case 24: launch_fwd_whole<24, false>(p, st); break;
@@ -1447,10 +1481,21 @@ int launch_fwd(const AP& p, hipStream_t st) {
     }
   }
   constexpr size_t lds = lds_fwd<DP>();
+  dim3 grid(((p.L + 127) / 128) * p.H * p.B);
+  if (p.drop_thr) {
+    if constexpr (DR == 0) {                                 // dropout belongs to the post-LN (no RoPE) encoder layers
+      if (lds > 65536)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<DP, DR, DX, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((attn_fwd_kernel<DP, DR, DX, true>), grid, dim3(256), lds, st, p);
+      return clipk_check_launch();
+    } else {
+      return CLIPK_ERR_UNSUPPORTED;
+    }
+  }
   if (lds > 65536)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<DP, DR, DX>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  dim3 grid(((p.L + 127) / 128) * p.H * p.B);
   hipLaunchKernelGGL((attn_fwd_kernel<DP, DR, DX>), grid, dim3(256), lds, st, p);
   return clipk_check_launch();
 }
@@ -1483,7 +1528,7 @@ int launch_bwd(const AP& p, hipStream_t st) {
     // keeps the two-kernel path (tests compare the two)
     const bool fused_on = clipk_opt_get(OPT_ATTN_FUSED_BWD) != 0;
     // q / k must arrive rotated (clipk_rope_qk) or unrotated-by-design: the chunk-per-lane staging cannot rotate
-    if (!p.cu && fused_on && p.L > 128 && p.L <= FUSED_LMAX && p.D >= 16 && (DR == 0 || p.pre_rot)) {
+    if (!p.cu && !p.drop_thr && fused_on && p.L > 128 && p.L <= FUSED_LMAX && p.D >= 16 && (DR == 0 || p.pre_rot)) {
       switch (p.D) {
         case 16: launch_fused<(DR > 0), 16>(p, st); break;
         case 24: launch_fused<(DR > 0), 24>(p, st); break;
@@ -1493,16 +1538,31 @@ int launch_bwd(const AP& p, hipStream_t st) {
     }
   }
   constexpr size_t l1 = lds_dq<DP>(), l2 = lds_dkv<DP>();
+  constexpr int KPB = Geo<DP>::KPB;
+  dim3 gq(((p.L + 127) / 128) * p.H * p.B);
+  dim3 gk(((p.L + KPB - 1) / KPB) * p.H * p.B);
+  if (p.drop_thr) {
+    if constexpr (DR == 0) {
+      if (l1 > 65536)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<DP, DR, DX, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1);
+      if (l2 > 65536)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<DP, DR, DX, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<DP, DR, DX, true>), gq, dim3(256), l1, st, p);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, DR, DX, true>), gk, dim3(256), l2, st, p);
+      return clipk_check_launch();
+    } else {
+      return CLIPK_ERR_UNSUPPORTED;
+    }
+  }
   if (l1 > 65536)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<DP, DR, DX>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1);
   if (l2 > 65536)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<DP, DR, DX>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
-  dim3 gq(((p.L + 127) / 128) * p.H * p.B);
   hipLaunchKernelGGL((attn_bwd_dq_kernel<DP, DR, DX>), gq, dim3(256), l1, st, p);
-  constexpr int KPB = Geo<DP>::KPB;
-  dim3 gk(((p.L + KPB - 1) / KPB) * p.H * p.B);
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<DP, DR, DX>), gk, dim3(256), l2, st, p);
   return clipk_check_launch();
 }
@@ -1540,6 +1600,16 @@ int check_common(const void* qkv, int B, int L, int H, int D, bool rope) {
 
 }  // namespace
 
+static inline int set_dropout(AP& p, float dropout_p, unsigned seed) {
+  if (!(dropout_p >= 0.f) || dropout_p >= 1.f) return CLIPK_ERR_BAD_ARG;
+  if (dropout_p == 0.f) { p.drop_thr = 0; p.drop_seed = 0; p.drop_scale = 1.f; return CLIPK_OK; }
+  double t = (double)dropout_p * 4294967296.0;
+  p.drop_thr = t < 1.0 ? 1u : (t >= 4294967295.0 ? 4294967295u : (unsigned)t);
+  p.drop_seed = seed;
+  p.drop_scale = 1.0f / (1.0f - dropout_p);
+  return CLIPK_OK;
+}
+
 // DX = the head dim when it is one the dispatcher can name at compile time (every RoPE case; multiples of 32
 // otherwise), 0 = run time
 #define ATTN_DISPATCH(FN, D, ROPE, P, ST)                                   \
@@ -1570,7 +1640,8 @@ int check_common(const void* qkv, int B, int L, int H, int D, bool rope) {
   } while (0)
 
 extern "C" int clipk_attn_fwd(const void* qkv, const uint8_t* key_mask, const float* rope_cos, const float* rope_sin,
-                              void* out, float* lse, int B, int L, int H, int D, float q_scale, void* stream) {
+                              void* out, float* lse, int B, int L, int H, int D, float q_scale, float dropout_p,
+                              uint32_t dropout_seed, void* stream) {
   if ((rope_cos == nullptr) != (rope_sin == nullptr)) return CLIPK_ERR_BAD_ARG;
   const bool rope = rope_cos != nullptr;
   int rc = check_common(qkv, B, L, H, D, rope);
@@ -1579,6 +1650,8 @@ extern "C" int clipk_attn_fwd(const void* qkv, const uint8_t* key_mask, const fl
   AP p{};
   p.qkv = (const unsigned short*)qkv; p.key_mask = key_mask; p.cosT = rope_cos; p.sinT = rope_sin;
   p.out = (unsigned short*)out; p.lse = lse; p.B = B; p.L = L; p.H = H; p.D = D; p.scale = q_scale;
+  rc = set_dropout(p, dropout_p, dropout_seed);
+  if (rc) return rc;
   ATTN_DISPATCH(launch_fwd, D, rope, p, (hipStream_t)stream);
 }
 
@@ -1610,7 +1683,7 @@ extern "C" int clipk_attn_fwd_rot(void* qkv, const uint8_t* key_mask, const floa
   if (!whole_fwd_applies(L, D)) {                           // every other shape: the two calls it stands for
     rc = clipk_rope_qk(qkv, rope_cos, rope_sin, B, L, H, D, stream);
     if (rc) return rc;
-    return clipk_attn_fwd(qkv, key_mask, nullptr, nullptr, out, lse, B, L, H, D, q_scale, stream);
+    return clipk_attn_fwd(qkv, key_mask, nullptr, nullptr, out, lse, B, L, H, D, q_scale, 0.f, 0u, stream);
   }
   AP p{};
   p.qkv = (const unsigned short*)qkv; p.key_mask = key_mask; p.cosT = rope_cos; p.sinT = rope_sin;
@@ -1626,7 +1699,8 @@ extern "C" int clipk_attn_fwd_rot(void* qkv, const uint8_t* key_mask, const floa
 
 extern "C" int clipk_attn_bwd(const void* qkv, const uint8_t* key_mask, const float* rope_cos, const float* rope_sin,
                               const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
-                              int B, int L, int H, int D, float q_scale, int prerotated, void* stream) {
+                              int B, int L, int H, int D, float q_scale, int prerotated, float dropout_p,
+                              uint32_t dropout_seed, void* stream) {
   if ((rope_cos == nullptr) != (rope_sin == nullptr)) return CLIPK_ERR_BAD_ARG;
   const bool rope = rope_cos != nullptr;
   int rc = check_common(qkv, B, L, H, D, rope);
@@ -1639,6 +1713,8 @@ extern "C" int clipk_attn_bwd(const void* qkv, const uint8_t* key_mask, const fl
   p.dout = (const unsigned short*)dout; p.delta = delta; p.dqkv = (unsigned short*)dqkv;
   p.B = B; p.L = L; p.H = H; p.D = D; p.scale = q_scale;
   p.pre_rot = (rope && prerotated) ? 1 : 0;
+  rc = set_dropout(p, dropout_p, dropout_seed);
+  if (rc) return rc;
   ATTN_DISPATCH(launch_bwd, D, rope, p, (hipStream_t)stream);
 }
 
@@ -1649,7 +1725,7 @@ extern "C" int clipk_attn_bwd(const void* qkv, const uint8_t* key_mask, const fl
 // length).  RoPE tables, if given, are indexed by the position INSIDE the sequence and must cover max_len rows.
 extern "C" int clipk_attn_varlen_fwd(const void* qkv, const int* cu_seqlens, const float* rope_cos, const float* rope_sin,
                                      void* out, float* lse, int B, int T, int max_len, int H, int D, float q_scale,
-                                     void* stream) {
+                                     float dropout_p, uint32_t dropout_seed, void* stream) {
   if ((rope_cos == nullptr) != (rope_sin == nullptr)) return CLIPK_ERR_BAD_ARG;
   const bool rope = rope_cos != nullptr;
   int rc = check_common(qkv, B, max_len, H, D, rope);
@@ -1659,12 +1735,15 @@ extern "C" int clipk_attn_varlen_fwd(const void* qkv, const int* cu_seqlens, con
   p.qkv = (const unsigned short*)qkv; p.key_mask = nullptr; p.cosT = rope_cos; p.sinT = rope_sin;
   p.out = (unsigned short*)out; p.lse = lse; p.B = B; p.L = max_len; p.H = H; p.D = D; p.scale = q_scale;
   p.cu = cu_seqlens; p.T = T;
+  rc = set_dropout(p, dropout_p, dropout_seed);
+  if (rc) return rc;
   ATTN_DISPATCH(launch_fwd, D, rope, p, (hipStream_t)stream);
 }
 
 extern "C" int clipk_attn_varlen_bwd(const void* qkv, const int* cu_seqlens, const float* rope_cos, const float* rope_sin,
                                      const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
-                                     int B, int T, int max_len, int H, int D, float q_scale, void* stream) {
+                                     int B, int T, int max_len, int H, int D, float q_scale, float dropout_p,
+                                     uint32_t dropout_seed, void* stream) {
   if ((rope_cos == nullptr) != (rope_sin == nullptr)) return CLIPK_ERR_BAD_ARG;
   const bool rope = rope_cos != nullptr;
   int rc = check_common(qkv, B, max_len, H, D, rope);
@@ -1678,5 +1757,7 @@ extern "C" int clipk_attn_varlen_bwd(const void* qkv, const int* cu_seqlens, con
   p.B = B; p.L = max_len; p.H = H; p.D = D; p.scale = q_scale;
   p.cu = cu_seqlens; p.T = T;
   p.pre_rot = 0;
+  rc = set_dropout(p, dropout_p, dropout_seed);
+  if (rc) return rc;
   ATTN_DISPATCH(launch_bwd, D, rope, p, (hipStream_t)stream);
 }

@@ -122,6 +122,21 @@ __device__ __forceinline__ float act_grad(float x, int act) {
   return 1.f;
 }
 
+// ---- dropout: counter-based mask, keep(seed, element index) = hash32(...) >= thr with thr = p * 2^32.  No state, no
+// stored mask: the backward recomputes it from the same (seed, index).  The index is the element's row-major position
+// in the tensor the reference applies nn.Dropout to; the hash is the murmur3 32-bit finaliser over the folded 64-bit
+// index (tests/ reproduce it in torch integer arithmetic to check every dropout site against masked references).
+__device__ __forceinline__ bool drop_keep(unsigned seed, unsigned long long idx, unsigned thr) {
+  unsigned h = (unsigned)idx * 0x9E3779B1u + (unsigned)(idx >> 32) * 0x85EBCA77u + seed;
+  h ^= h >> 16; h *= 0x85EBCA6Bu;
+  h ^= h >> 13; h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h >= thr;
+}
+__device__ __forceinline__ float drop_mul(unsigned seed, unsigned long long idx, unsigned thr, float scale) {
+  return drop_keep(seed, idx, thr) ? scale : 0.f;
+}
+
 // wave-wide reductions over 64 lanes
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -25,6 +25,7 @@ struct EpiArgs {
   const void* residual; long ldr; int r_f32;
   float alpha;
   int nt;           // 1: non-temporal (streaming) output stores (epi_args_from decides)
+  unsigned drop_thr, drop_seed; float drop_scale;   // dropout after the activation (generic epilogue only); thr 0 = off
 };
 
 enum {
@@ -45,6 +46,7 @@ constexpr int epi_stores(int mode, int nj) {
 static inline int epi_mode_for(const clipk_gemm_args* a) {
   const bool c_f32 = a->c_dtype == CLIPK_F32, has_res = a->residual != nullptr, has_aux = a->dact_aux != nullptr;
   const bool has_pre = a->out_preact != nullptr;
+  if (a->drop_p > 0.f) return EPI_GENERIC;               // dropout lives in the run-time epilogue
   const long lim = 0x7fffffffL;                          // buffer-descriptor stores: byte extents must stay < 2 GiB
   if (((long)(a->M - 1) * a->ldc + a->N) * (c_f32 ? 4 : 2) > lim) return EPI_GENERIC;
   if (has_pre && ((long)(a->M - 1) * a->ldp + a->N) * 2 > lim) return EPI_GENERIC;
@@ -218,6 +220,11 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
 #pragma unroll
             for (int c = 0; c < 8; ++c) v[c] = act_apply(v[c], p.act);
           }
+          if (p.drop_thr) {                                   // nn.Dropout on this tensor: index = m * N + n
+            const unsigned long long base = (unsigned long long)gm * (unsigned)N + (unsigned)gn;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] *= drop_mul(p.drop_seed, base + c, p.drop_thr, p.drop_scale);
+          }
           if (p.dact_aux) {
             const u32x4 a = *reinterpret_cast<const u32x4*>(p.dact_aux + (long)gm * p.ldd + gn);
 #pragma unroll
@@ -273,5 +280,11 @@ static inline EpiArgs epi_args_from(const clipk_gemm_args* a) {
   // get slower), in the training step nothing (96.8 vs 96.6 ms): there the consumer of the output runs next and finds
   // less of it in the Infinity Cache.  Off by default.
   e.nt = clipk_opt_get(OPT_EPI_NT);
+  e.drop_thr = 0; e.drop_seed = a->drop_seed; e.drop_scale = 1.f;
+  if (a->drop_p > 0.f && a->drop_p < 1.f) {
+    const double t = (double)a->drop_p * 4294967296.0;
+    e.drop_thr = t < 1.0 ? 1u : (t >= 4294967295.0 ? 4294967295u : (unsigned)t);
+    e.drop_scale = 1.0f / (1.0f - a->drop_p);
+  }
   return e;
 }

@@ -14,6 +14,7 @@
 //   * 1-D grid with an XCD-aware bijective remap; N-tiles vary fastest so one XCD's L2 keeps the A
 //     row panel while it sweeps the (small, L2-resident) weight.
 #include "common.h"
+#include "gemm_epilogue.h"
 #include <stdlib.h>
 
 extern "C" int clipk_gemm_nt_v2_launch(const clipk_gemm_args* a, void* stream);
@@ -41,6 +42,7 @@ struct Params {
   const void* residual; long ldr; int r_f32;
   float alpha;
   int ntn;
+  unsigned drop_thr, drop_seed; float drop_scale;
 };
 
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(const Params p) {
@@ -172,6 +174,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(const Params p) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) v[c] = act_apply(v[c], p.act);
     }
+    if (p.drop_thr) {                                         // nn.Dropout on this tensor: index = m * N + n
+      const unsigned long long base = (unsigned long long)gm * (unsigned)p.N + (unsigned)gn;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] *= drop_mul(p.drop_seed, base + c, p.drop_thr, p.drop_scale);
+    }
     if (p.dact_aux) {
       const u32x4 a = *reinterpret_cast<const u32x4*>(p.dact_aux + (long)gm * p.ldd + gn);
 #pragma unroll
@@ -245,6 +252,7 @@ extern "C" int clipk_gemm_nt(const clipk_gemm_args* a, void* stream) {
   p.dact_aux = (const unsigned short*)a->dact_aux; p.ldd = a->ldd; p.dact = a->dact;
   p.residual = a->residual; p.ldr = a->ldr; p.r_f32 = (a->r_dtype == CLIPK_F32);
   p.alpha = a->alpha;
+  { const EpiArgs e = epi_args_from(a); p.drop_thr = e.drop_thr; p.drop_seed = e.drop_seed; p.drop_scale = e.drop_scale; }
   const int ntm = (a->M + BM - 1) / BM, ntn = (a->N + BN - 1) / BN;
   p.ntn = ntn;
   static std::atomic<uint64_t> attr_set{0};

@@ -96,6 +96,9 @@ struct LnBwd {
   const float* dx_add; float* dx_f32; void* dx_bf16; long lddx;
   float* part;   // [nblocks][2][cols]
   int rows, cols;
+  // dropout mask on the bf16 output only: it is the gradient of a Linear's dropped-out output (d(W x) = keep / (1-p) *
+  // d(residual sum)), the f32 output stays the residual-path gradient.  Index = row * cols + col.  thr 0 = off.
+  unsigned drop_thr, drop_seed; float drop_scale;
 };
 
 template <int VPL, bool DYBF16, bool XBF16>
@@ -158,7 +161,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
         for (int e = 0; e < 4; ++e) dx[e] = rstd * (gy[v][e] - c1 - xh[v][e] * c2);
         dx += addv[v];
         if (p.dx_f32) *reinterpret_cast<f32x4*>(p.dx_f32 + (long)row * p.lddx + 4 * c) = dx;
-        if (p.dx_bf16) store4_bf16(p.dx_bf16, (long)row * p.lddx + 4 * c, dx);
+        if (p.dx_bf16) {
+          if (p.drop_thr) {
+            const unsigned long long base = (unsigned long long)row * (unsigned)p.cols + 4u * c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dx[e] *= drop_mul(p.drop_seed, base + e, p.drop_thr, p.drop_scale);
+          }
+          store4_bf16(p.dx_bf16, (long)row * p.lddx + 4 * c, dx);
+        }
       }
     }
   }
@@ -334,14 +344,20 @@ extern "C" int clipk_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, c
                                    const float* gamma, const float* beta, const float* mean, const float* rstd, int act,
                                    const float* dx_add, float* dx_f32, void* dx_bf16, int64_t lddx,
                                    float* dgamma, float* dbeta, int accumulate,
-                                   int rows, int cols, void* workspace, size_t workspace_bytes, void* stream) {
+                                   int rows, int cols, float drop_p, uint32_t drop_seed,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || rows <= 0 || cols <= 0 || !workspace) return CLIPK_ERR_BAD_ARG;
   if (act != CLIPK_ACT_NONE && !beta) return CLIPK_ERR_BAD_ARG;
   if ((cols & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3)) return CLIPK_ERR_UNSUPPORTED;
   const int blocks = ln_blocks(rows, cols);
   if (workspace_bytes < (size_t)blocks * 2 * cols * sizeof(float)) return CLIPK_ERR_BAD_ARG;
   LnBwd p{dy, (long)lddy, x, (long)ldx, gamma, beta, mean, rstd, act, dx_add, dx_f32, dx_bf16, (long)lddx,
-          (float*)workspace, rows, cols};
+          (float*)workspace, rows, cols, 0u, drop_seed, 1.0f};
+  if (drop_p > 0.f && drop_p < 1.f) {
+    const double t = (double)drop_p * 4294967296.0;
+    p.drop_thr = t < 1.0 ? 1u : (t >= 4294967295.0 ? 4294967295u : (unsigned)t);
+    p.drop_scale = 1.0f / (1.0f - drop_p);
+  }
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = (size_t)4 * 2 * cols * sizeof(float);
 #define CALL(V)                                                                                                   \

@@ -420,41 +420,50 @@ class ESM2Encoder(nn.Module):
 # =================================================================================================
 # post-LN (nn.TransformerEncoderLayer) stack
 # =================================================================================================
-def _post_layer_fwd(x, xb, p, meta):
+def _post_layer_fwd(x, xb, p, meta, dr=None):
+    """dr = None or (p_drop, seed_attn, seed_drop1, seed_ffn, seed_drop2): the four nn.Dropout sites of
+    nn.TransformerEncoderLayer (attention probabilities; out_proj output; FFN activation; linear2 output), each a
+    counter-based mask recomputed in the backward from the same seed."""
     B, L, H, D, mask, act, eps, qs, seq = meta
+    da, d1, df, d2 = (None,) * 4 if dr is None else tuple((dr[0], sd) for sd in dr[1:])
     qkv = ops.gemm_nt(xb, p["in"].wb, bias=p["in"].b)
     if seq is not None:
-        ctx, lse = ops.attn_varlen_fwd(qkv, seq[0], seq[1], H, D, rope=None, q_scale=qs)
+        ctx, lse = ops.attn_varlen_fwd(qkv, seq[0], seq[1], H, D, rope=None, q_scale=qs, dropout=da)
     else:
-        ctx, lse = ops.attn_fwd(qkv, B, L, H, D, key_mask=mask, rope=None, q_scale=qs)
-    s1 = ops.gemm_nt(ctx, p["out"].wb, bias=p["out"].b, residual=x, out_dtype=torch.float32)
+        ctx, lse = ops.attn_fwd(qkv, B, L, H, D, key_mask=mask, rope=None, q_scale=qs, dropout=da)
+    s1 = ops.gemm_nt(ctx, p["out"].wb, bias=p["out"].b, residual=x, out_dtype=torch.float32, dropout=d1)
     x1, x1b, m1, r1 = ops.layernorm_fwd(s1, p["n1_w"], p["n1_b"], eps, want_f32=True, want_bf16=True)
     if act == "gelu":
-        g, u = ops.gemm_nt(x1b, p["fc1"].wb, bias=p["fc1"].b, act="gelu", out_preact=True)
+        g, u = ops.gemm_nt(x1b, p["fc1"].wb, bias=p["fc1"].b, act="gelu", out_preact=True, dropout=df)
     else:
-        g = ops.gemm_nt(x1b, p["fc1"].wb, bias=p["fc1"].b, act="relu")
-        u = g                                                   # relu'(pre) == relu'(relu(pre))
-    s2 = ops.gemm_nt(g, p["fc2"].wb, bias=p["fc2"].b, residual=x1, out_dtype=torch.float32)
+        g = ops.gemm_nt(x1b, p["fc1"].wb, bias=p["fc1"].b, act="relu", dropout=df)
+        u = g                                    # relu'(pre) == relu'(relu(pre)); a dropped element has g = 0 either way
+    s2 = ops.gemm_nt(g, p["fc2"].wb, bias=p["fc2"].b, residual=x1, out_dtype=torch.float32, dropout=d2)
     y, yb, m2, r2 = ops.layernorm_fwd(s2, p["n2_w"], p["n2_b"], eps, want_f32=True, want_bf16=True)
     return y, yb, (xb, qkv, ctx, lse, s1, x1b, m1, r1, g, u, s2, m2, r2)
 
 
-def _post_layer_bwd(dy, p, saved, meta):
+def _post_layer_bwd(dy, p, saved, meta, dr=None):
     B, L, H, D, mask, act, eps, qs, seq = meta
+    da, d1, df, d2 = (None,) * 4 if dr is None else tuple((dr[0], sd) for sd in dr[1:])
     xb, qkv, ctx, lse, s1, x1b, m1, r1, g, u, s2, m2, r2 = saved
     gr = {}
-    ds2, ds2b, gr["n2_w"], gr["n2_b"] = _ln_bwd(dy, s2, p["n2_w"], p["n2_b"], m2, r2, want_f32=True, want_bf16=True)
-    du = ops.gemm_nt(ds2b, p["fc2"].wtb, dact_aux=u, dact=act)
+    # the bf16 copy of d s2 is the gradient of linear2's dropped-out output: masked (drop2); the f32 one is the
+    # residual-path gradient
+    ds2, ds2b, gr["n2_w"], gr["n2_b"] = _ln_bwd(dy, s2, p["n2_w"], p["n2_b"], m2, r2, want_f32=True, want_bf16=True,
+                                                dropout_bf16=d2)
+    du = ops.gemm_nt(ds2b, p["fc2"].wtb, dact_aux=u, dact=act, dropout=df)     # x mask(ffn) x act'(u)
     gr["fc2_w"], gr["fc2_b"] = _wgrad(ds2b, g, p["fc2"])
     dx1 = ops.gemm_nt(du, p["fc1"].wtb, residual=ds2, out_dtype=torch.float32)      # + residual-path gradient
     gr["fc1_w"], gr["fc1_b"] = _wgrad(du, x1b, p["fc1"])
-    ds1, ds1b, gr["n1_w"], gr["n1_b"] = _ln_bwd(dx1, s1, p["n1_w"], p["n1_b"], m1, r1, want_f32=True, want_bf16=True)
+    ds1, ds1b, gr["n1_w"], gr["n1_b"] = _ln_bwd(dx1, s1, p["n1_w"], p["n1_b"], m1, r1, want_f32=True, want_bf16=True,
+                                                dropout_bf16=d1)
     dctx = ops.gemm_nt(ds1b, p["out"].wtb)
     gr["out_w"], gr["out_b"] = _wgrad(ds1b, ctx, p["out"])
     if seq is not None:
-        dqkv = ops.attn_varlen_bwd(qkv, ctx, dctx, lse, seq[0], seq[1], H, D, rope=None, q_scale=qs)
+        dqkv = ops.attn_varlen_bwd(qkv, ctx, dctx, lse, seq[0], seq[1], H, D, rope=None, q_scale=qs, dropout=da)
     else:
-        dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, H, D, key_mask=mask, rope=None, q_scale=qs)
+        dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, H, D, key_mask=mask, rope=None, q_scale=qs, dropout=da)
     dx = ops.gemm_nt(dqkv, p["in"].wtb, residual=ds1, out_dtype=torch.float32)
     gr["in_w"], gr["in_b"] = _wgrad(dqkv, xb, p["in"])
     return dx, gr
@@ -467,7 +476,7 @@ class PostLNStackFn(torch.autograd.Function):
     """x f32 [B*L, E] -> final-LayerNorm output f32 [B*L, E]."""
 
     @staticmethod
-    def forward(ctx, module, x, mask_u8, B, L, seq, *flat):
+    def forward(ctx, module, x, mask_u8, B, L, seq, drop, *flat):
         nl = module.num_layers
         E, H = module.embed_dim, module.nhead
         D = module.head_dim_padded
@@ -482,12 +491,13 @@ class PostLNStackFn(torch.autograd.Function):
             c = module.layer_caches[i]
             p = {"in": _Lin(t[0], t[1], c[0]), "out": _Lin(t[2], t[3], c[1]), "n1_w": t[4], "n1_b": t[5],
                  "fc1": _Lin(t[6], t[7], c[2]), "fc2": _Lin(t[8], t[9], c[3]), "n2_w": t[10], "n2_b": t[11]}
-            x, xb, s = _post_layer_fwd(x, xb, p, meta)
+            x, xb, s = _post_layer_fwd(x, xb, p, meta, None if drop is None else (drop[0],) + tuple(drop[1][i]))
             layers.append(p)
             saved.append(s if need_bwd else None)
         y, _, mf, rf = ops.layernorm_fwd(x, fin_w, fin_b, module.final_eps, want_f32=True)
         ctx.module, ctx.meta, ctx.layers, ctx.saved = module, meta, layers, saved
         ctx.fin = (x, fin_w, fin_b, mf, rf)
+        ctx.drop = drop
         return y
 
     @staticmethod
@@ -498,14 +508,16 @@ class PostLNStackFn(torch.autograd.Function):
         grads: List[Optional[torch.Tensor]] = [None] * (2 + 12 * nl)
         dx, _, grads[0], grads[1] = _ln_bwd(dy.contiguous(), x, fin_w, fin_b, mf, rf, want_f32=True)
         for i in reversed(range(nl)):
-            dx, gr = _post_layer_bwd(dx, ctx.layers[i], ctx.saved[i], meta)
+            drop = ctx.drop
+            dx, gr = _post_layer_bwd(dx, ctx.layers[i], ctx.saved[i], meta,
+                                     None if drop is None else (drop[0],) + tuple(drop[1][i]))
             ctx.saved[i] = None
             for j, k in enumerate(_POST_KEYS):
                 grads[2 + 12 * i + j] = gr[k]
         ctx.layers = ctx.saved = None
         _join_side(*grads)
         _bucket_done(module, grads)
-        return (None, dx if ctx.needs_input_grad[1] else None, None, None, None, None, *grads)
+        return (None, dx if ctx.needs_input_grad[1] else None, None, None, None, None, None, *grads)
 
 
 class _MHAParams(nn.Module):
@@ -544,9 +556,10 @@ class TransformerSeqEncoder(nn.Module):
                  layer_norm_eps=1e-12, final_eps=None, dropout: float = 0.0):
         super().__init__()
         self.embed_dim, self.num_layers, self.nhead = embed_dim, num_layers, nhead
-        # nn.TransformerEncoderLayer's dropout (attention probabilities, both residual branches, FFN activation;
-        # rna_clip_codes.ipynb:1915 uses 0.1).  The kernel stack has no dropout: training with p > 0 raises instead of
-        # silently training unregularised; eval mode (and p = 0, the parity / benchmark setting) is exact.
+        # nn.TransformerEncoderLayer's dropout (rna_clip_codes.ipynb:1915 uses 0.1): attention probabilities, out_proj
+        # output, FFN activation, linear2 output.  In training mode each site draws a counter-based mask inside the
+        # attention kernels / GEMM epilogues from a per-call seed (torch's CPU generator: torch.manual_seed applies);
+        # the backward recomputes the masks, nothing is stored.  Eval mode and p = 0 are the parity setting.
         self.dropout = float(dropout)
         self.activation, self.eps = activation, layer_norm_eps
         self.final_eps = layer_norm_eps if final_eps is None else final_eps
@@ -582,33 +595,29 @@ class TransformerSeqEncoder(nn.Module):
 
     def forward(self, x, src_key_padding_mask=None):
         B, L, E = x.shape
-        if self.training and self.dropout > 0.0 and torch.is_grad_enabled():
-            raise NotImplementedError(
-                f"TransformerSeqEncoder: training-mode dropout p={self.dropout} is not implemented in the HIP layer "
-                "stack (INTEGRATION.md §dropout).  Set `encoder.dropout = 0.0` (or construct with dropout=0.0) to train "
-                "without it, or call .eval(); the reference's nn.TransformerEncoderLayer(dropout=0.1) would drop "
-                "attention probabilities, both residual branches and the FFN activation here.")
         mask_u8 = None
         if src_key_padding_mask is not None:
             mask_u8 = (~src_key_padding_mask.bool()).to(torch.uint8).contiguous()      # kernels take 1 = valid
-        y = PostLNStackFn.apply(self, x.reshape(B * L, E), mask_u8, B, L, None, *self._flat_params())
+        y = PostLNStackFn.apply(self, x.reshape(B * L, E), mask_u8, B, L, None, self._draw_dropout(),
+                                *self._flat_params())
         return y.view(B, L, E)
 
-    def _check_dropout(self):
-        if self.training and self.dropout > 0.0 and torch.is_grad_enabled():
-            raise NotImplementedError(
-                f"TransformerSeqEncoder: training-mode dropout p={self.dropout} is not implemented in the HIP layer "
-                "stack (INTEGRATION.md §dropout): set `encoder.dropout = 0.0` or call .eval().")
+    def _draw_dropout(self):
+        """None (eval mode / p = 0) or (p, [[seed_attn, seed_drop1, seed_ffn, seed_drop2] per layer]): 32-bit seeds from
+        torch's default CPU generator, so torch.manual_seed() makes a training run reproducible."""
+        if not (self.training and self.dropout > 0.0):
+            return None
+        seeds = torch.randint(0, 2 ** 31 - 1, (self.num_layers, 4), dtype=torch.int64).tolist()
+        return (self.dropout, seeds)
 
     def forward_packed(self, x, cu_seqlens, max_len: int):
         """Packed variable-length batch: x f32 [T, E] = the sequences back to back, cu_seqlens int32
         [B+1] on the device, max_len = the longest sequence.  -> [T, E]; equals forward() on the padded batch with its
         key-padding mask, row for row, without any padded row going through a kernel."""
-        self._check_dropout()
         T, E = x.shape
         B = cu_seqlens.numel() - 1
         return PostLNStackFn.apply(self, x, None, B, int(max_len), (cu_seqlens.contiguous(), int(max_len)),
-                                   *self._flat_params())
+                                   self._draw_dropout(), *self._flat_params())
 
 
 class PoolFn(torch.autograd.Function):

@@ -108,8 +108,9 @@ def workspace(nbytes: int, device, tag: str = "ws") -> torch.Tensor:
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, act=None,
             out_dtype=torch.bfloat16, residual: Optional[torch.Tensor] = None, out_preact: bool = False,
             dact_aux: Optional[torch.Tensor] = None, dact=None, alpha: float = 1.0,
-            out: Optional[torch.Tensor] = None):
-    """C = epilogue(a[M,K] @ b[N,K]^T) with a, b bf16.  Returns C (and the bf16 pre-activation if asked)."""
+            out: Optional[torch.Tensor] = None, dropout=None):
+    """C = epilogue(a[M,K] @ b[N,K]^T) with a, b bf16.  Returns C (and the bf16 pre-activation if asked).
+    dropout = (p, seed): nn.Dropout on the value after the activation (before act'(aux) and the residual add)."""
     _need_cuda(a, b, bias, residual, dact_aux)
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
     assert a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[1]
@@ -133,6 +134,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
     else:
         args.residual, args.ldr, args.r_dtype = None, 0, 0
     args.alpha = alpha
+    args.drop_p, args.drop_seed = (float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF) if dropout else (0.0, 0)
     # algorithmic bytes: both operands once, every output / epilogue operand once
     nb = 2.0 * (M * K + N * K) + M * N * (c.element_size() + (2 if out_preact else 0) + (2 if dact_aux is not None else 0)
                                           + (residual.element_size() if residual is not None else 0))
@@ -347,7 +349,7 @@ def layernorm_fwd(x, gamma, beta, eps, act=None, want_f32=True, want_bf16=False,
 
 
 def layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=None, dx_add=None, want_f32=True, want_bf16=False,
-                  dgamma=None, dbeta=None, accumulate=False, want_param_grads=True):
+                  dgamma=None, dbeta=None, accumulate=False, want_param_grads=True, dropout_bf16=None):
     _need_cuda(dy, x, gamma, mean, rstd)
     rows, cols = x.shape
     dx32 = torch.empty((rows, cols), dtype=torch.float32, device=x.device) if want_f32 else None
@@ -367,7 +369,9 @@ def layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=None, dx_add=None, want_f3
                  lambda: lib.clipk_layernorm_bwd(dy.data_ptr(), _dt(dy), dy.stride(0), x.data_ptr(), _dt(x), x.stride(0),
                                                  gamma.data_ptr(), ptr(beta), mean.data_ptr(), rstd.data_ptr(), ACT[act],
                                                  ptr(dx_add), ptr(dx32), ptr(dx16), cols, ptr(dgamma),
-                                                 ptr(dbeta), int(accumulate), rows, cols, ws.data_ptr(),
+                                                 ptr(dbeta), int(accumulate), rows, cols,
+                                                 float(dropout_bf16[0]) if dropout_bf16 else 0.0,
+                                                 (int(dropout_bf16[1]) & 0xFFFFFFFF) if dropout_bf16 else 0, ws.data_ptr(),
                                                  ws.numel(), _stream())), "clipk_layernorm_bwd")
     return dx32, dx16, dgamma, dbeta
 
@@ -450,7 +454,11 @@ def axpby_dev(a, b, s):
 
 
 # --------------------------------------------------------------------------------------------------
-def attn_fwd(qkv, B, L, H, D, key_mask=None, rope=None, q_scale=1.0):
+def _drop(dropout):
+    return (float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF) if dropout else (0.0, 0)
+
+
+def attn_fwd(qkv, B, L, H, D, key_mask=None, rope=None, q_scale=1.0, dropout=None):
     _need_cuda(qkv, key_mask)
     assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous() and qkv.shape == (B * L, 3 * H * D)
     out = torch.empty((B * L, H * D), dtype=torch.bfloat16, device=qkv.device)
@@ -458,7 +466,8 @@ def attn_fwd(qkv, B, L, H, D, key_mask=None, rope=None, q_scale=1.0):
     cos, sin = rope if rope is not None else (None, None)
     check(_timed("attn_fwd", 4.0 * B * H * L * L * D,
                  lambda: _lib().clipk_attn_fwd(qkv.data_ptr(), ptr(key_mask), ptr(cos), ptr(sin), out.data_ptr(),
-                                               lse.data_ptr(), B, L, H, D, float(q_scale), _stream())), "clipk_attn_fwd")
+                                               lse.data_ptr(), B, L, H, D, float(q_scale), *_drop(dropout),
+                                               _stream())), "clipk_attn_fwd")
     return out, lse
 
 
@@ -486,7 +495,7 @@ def attn_fwd_rot_(qkv, B, L, H, D, rope, key_mask=None, q_scale=1.0):
     return out, lse
 
 
-def attn_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=None, rope=None, q_scale=1.0, prerotated=False):
+def attn_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=None, rope=None, q_scale=1.0, prerotated=False, dropout=None):
     _need_cuda(qkv, out, dout, lse)
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
@@ -494,11 +503,12 @@ def attn_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=None, rope=None, q_scale=
     check(_timed("attn_bwd", 10.0 * B * H * L * L * D,
                  lambda: _lib().clipk_attn_bwd(qkv.data_ptr(), ptr(key_mask), ptr(cos), ptr(sin), out.data_ptr(),
                                                dout.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), B, L,
-                                               H, D, float(q_scale), int(bool(prerotated)), _stream())), "clipk_attn_bwd")
+                                               H, D, float(q_scale), int(bool(prerotated)), *_drop(dropout),
+                                               _stream())), "clipk_attn_bwd")
     return dqkv
 
 
-def attn_varlen_fwd(qkv, cu_seqlens, max_len, H, D, rope=None, q_scale=1.0):
+def attn_varlen_fwd(qkv, cu_seqlens, max_len, H, D, rope=None, q_scale=1.0, dropout=None):
     """Packed variable-length self-attention: qkv bf16 [T, 3*H*D], cu_seqlens int32 [B+1] on the device."""
     _need_cuda(qkv, cu_seqlens)
     T = qkv.shape[0]
@@ -511,11 +521,12 @@ def attn_varlen_fwd(qkv, cu_seqlens, max_len, H, D, rope=None, q_scale=1.0):
     check(_timed("attn_fwd", 0.0,
                  lambda: _lib().clipk_attn_varlen_fwd(qkv.data_ptr(), cu_seqlens.data_ptr(), ptr(cos), ptr(sin),
                                                       out.data_ptr(), lse.data_ptr(), B, T, int(max_len), H, D,
-                                                      float(q_scale), _stream())), "clipk_attn_varlen_fwd")
+                                                      float(q_scale), *_drop(dropout), _stream())),
+          "clipk_attn_varlen_fwd")
     return out, lse
 
 
-def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_len, H, D, rope=None, q_scale=1.0):
+def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_len, H, D, rope=None, q_scale=1.0, dropout=None):
     _need_cuda(qkv, out, dout, lse, cu_seqlens)
     T = qkv.shape[0]
     B = cu_seqlens.numel() - 1
@@ -526,7 +537,7 @@ def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_len, H, D, rope=None, q
                  lambda: _lib().clipk_attn_varlen_bwd(qkv.data_ptr(), cu_seqlens.data_ptr(), ptr(cos), ptr(sin),
                                                       out.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr(),
                                                       dqkv.data_ptr(), B, T, int(max_len), H, D, float(q_scale),
-                                                      _stream())), "clipk_attn_varlen_bwd")
+                                                      *_drop(dropout), _stream())), "clipk_attn_varlen_bwd")
     return dqkv
 
 

@@ -75,6 +75,11 @@ typedef struct clipk_gemm_args {
   int dact;                            /* clipk_act whose derivative is applied to aux     */
   const void* residual; int64_t ldr; int r_dtype; /* optional [M,N] bf16/f32, added last   */
   float alpha;                         /* scale applied to the raw product before bias     */
+  /* dropout on the value after the activation (and before act'(aux) / the residual add): v *= keep / (1 - p), with
+   * keep = hash(drop_seed, m * N + n) >= drop_p * 2^32 — nn.Dropout after out_proj / linear2 / the FFN activation of
+   * nn.TransformerEncoderLayer(dropout = p) (current/rna_clip_codes.ipynb:1915).  The same (seed, p) on the matching
+   * backward GEMM reproduces the mask; nothing is stored.  drop_p = 0: off. */
+  float drop_p; uint32_t drop_seed;
 } clipk_gemm_args;
 int clipk_gemm_nt(const clipk_gemm_args* args, void* stream);
 
@@ -197,13 +202,17 @@ int clipk_layernorm_fwd(const void* x, int x_dtype, int64_t ldx, const float* ga
 /* LayerNorm backward: dx (f32 and/or bf16), and per-block partial dgamma/dbeta in workspace followed
  * by a deterministic column reduce into dgamma/dbeta (accumulate flag as above).  If act != NONE the
  * incoming dy is first multiplied by act'(ln_out) where ln_out is recomputed from x, mean, rstd.
- * dx_add: optional f32 [rows,cols] added to the result (residual-stream gradient). */
+ * dx_add: optional f32 [rows,cols] added to the result (residual-stream gradient).
+ * drop_p > 0: the bf16 output (only) is multiplied by the dropout mask keep(drop_seed, row * cols + col) / (1 - p): it is
+ * the gradient of the dropped-out Linear output that was added to the residual stream in front of this LayerNorm
+ * (dropout1 / dropout2 of nn.TransformerEncoderLayer); the f32 output stays the residual-path gradient.
+ * dgamma == dbeta == NULL: input gradient only. */
 size_t clipk_layernorm_bwd_workspace(int rows, int cols);
 int clipk_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, const void* x, int x_dtype, int64_t ldx,
                         const float* gamma, const float* beta, const float* mean, const float* rstd, int act,
                         const float* dx_add, float* dx_f32, void* dx_bf16, int64_t lddx,
                         float* dgamma, float* dbeta, int accumulate,
-                        int rows, int cols, void* workspace, size_t workspace_bytes, void* stream);
+                        int rows, int cols, float drop_p, uint32_t drop_seed, void* workspace, size_t workspace_bytes, void* stream);
 
 /* F.normalize(x, dim=-1) with eps=1e-12 (old/clip.py:63-64): y = x / max(||x||, eps); f32. */
 int clipk_l2norm_fwd(const float* x, float* y, float* norm, int rows, int cols, float eps, void* stream);
@@ -235,14 +244,18 @@ int clipk_axpby_dev(const float* a, const float* b, const float* s, float* y, in
  * out: bf16 [B*L, H*D]; lse: f32 [B, H, L] (log-sum-exp of the scaled scores, saved for backward).
  * Replaces nn.MultiheadAttention inside nn.TransformerEncoderLayer (rna_clip_codes.ipynb:1915) and
  * EsmSelfAttention (modeling_esm.py:306-314,362-384).  D in {8..160}, D % 8 == 0.
+ * dropout_p > 0: dropout on the attention probabilities (P~ = P * keep / (1 - p) feeds P·V, the normaliser uses P),
+ * mask = hash(dropout_seed, ((token row * H + h) * L + key)); pass the same (p, seed) to the backward.
  */
 int clipk_attn_fwd(const void* qkv, const uint8_t* key_mask, const float* rope_cos, const float* rope_sin,
-                   void* out, float* lse, int B, int L, int H, int D, float q_scale, void* stream);
+                   void* out, float* lse, int B, int L, int H, int D, float q_scale, float dropout_p,
+                   uint32_t dropout_seed, void* stream);
 /* Backward: dqkv bf16 [B*L, 3*H*D] from dout bf16 [B*L, H*D]; recomputes P from qkv + lse.
  * delta: f32 [B,H,L] scratch (rowsum(dout*out)) provided by the caller. */
 int clipk_attn_bwd(const void* qkv, const uint8_t* key_mask, const float* rope_cos, const float* rope_sin,
                    const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
-                   int B, int L, int H, int D, float q_scale, int prerotated, void* stream);
+                   int B, int L, int H, int D, float q_scale, int prerotated, float dropout_p, uint32_t dropout_seed,
+                   void* stream);
 /* Rotate-half RoPE (transformers modeling_esm.py:88-110) applied ONCE, in place, to the q and k sections of
  * qkv bf16 [B*L, 3*H*D].  Afterwards call clipk_attn_fwd WITHOUT rope tables and clipk_attn_bwd with the tables and
  * prerotated = 1: q / k are then staged as they are and only the gradients go through RoPE^T. */
@@ -288,10 +301,12 @@ int clipk_pool_varlen_bwd(const float* dy, const int* cu_seqlens, float* dx, int
  *   rope tables (optional, ESM head dims): f32 [>= max_len, D/2], indexed by the position inside the sequence.
  * Arithmetic is that of clipk_attn_fwd / clipk_attn_bwd on each sequence alone. */
 int clipk_attn_varlen_fwd(const void* qkv, const int* cu_seqlens, const float* rope_cos, const float* rope_sin,
-                          void* out, float* lse, int B, int T, int max_len, int H, int D, float q_scale, void* stream);
+                          void* out, float* lse, int B, int T, int max_len, int H, int D, float q_scale, float dropout_p,
+                          uint32_t dropout_seed, void* stream);
 int clipk_attn_varlen_bwd(const void* qkv, const int* cu_seqlens, const float* rope_cos, const float* rope_sin,
                           const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
-                          int B, int T, int max_len, int H, int D, float q_scale, void* stream);
+                          int B, int T, int max_len, int H, int D, float q_scale, float dropout_p, uint32_t dropout_seed,
+                          void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimiser step on flat f32 buffers: AdamW (decoupled weight decay, torch.optim.AdamW semantics,

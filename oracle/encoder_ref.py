@@ -22,8 +22,9 @@ from .clip_ref import _gelu, _linear, _ln
 SD = Dict[str, torch.Tensor]
 
 
-def _mha(q, k, v, nheads: int, key_valid: Optional[torch.Tensor], scale: float):
-    """q,k,v: [B, L, E]; key_valid: [B, L] bool (True = attend).  softmax(q k^T * scale + mask) v."""
+def _mha(q, k, v, nheads: int, key_valid: Optional[torch.Tensor], scale: float, attn_mult=None):
+    """q,k,v: [B, L, E]; key_valid: [B, L] bool (True = attend).  softmax(q k^T * scale + mask) v.
+    attn_mult: optional [B, H, L, L] dropout multiplier (keep / (1 - p)) on the attention probabilities."""
     B, L, E = q.shape
     hd = E // nheads
     q = q.view(B, L, nheads, hd).transpose(1, 2)
@@ -33,27 +34,43 @@ def _mha(q, k, v, nheads: int, key_valid: Optional[torch.Tensor], scale: float):
     if key_valid is not None:
         s = s.masked_fill(~key_valid[:, None, None, :], float("-inf"))
     p = torch.softmax(s, dim=-1)
+    if attn_mult is not None:
+        p = p * attn_mult
     return (p @ v).transpose(1, 2).reshape(B, L, E)
 
 
-def post_ln_layer(x, sd: SD, prefix: str, nheads: int, key_valid, activation: str = "relu", eps: float = 1e-5):
+def post_ln_layer(x, sd: SD, prefix: str, nheads: int, key_valid, activation: str = "relu", eps: float = 1e-5,
+                  drop=None):
     """One nn.TransformerEncoderLayer (batch-first layout [B, L, E] = per-sequence attention).
-    x = LN1(x + MHA(x)); x = LN2(x + W2 act(W1 x)).  Dropout = identity (eval / p=0)."""
+    x = LN1(x + drop1(MHA(x))); x = LN2(x + drop2(W2 drop(act(W1 x)))).  drop = None: dropout is the identity (eval /
+    p = 0); else a dict of keep / (1 - p) multipliers {"attn": [B,H,L,L], "d1": [B,L,E], "ffn": [B,L,F], "d2": [B,L,E]}
+    standing for nn.TransformerEncoderLayer's four nn.Dropout sites (torch/nn/modules/transformer.py _sa_block,
+    _ff_block, MultiheadAttention dropout_p)."""
     E = x.shape[-1]
     qkv = x @ sd[f"{prefix}.self_attn.in_proj_weight"].t() + sd[f"{prefix}.self_attn.in_proj_bias"]
     q, k, v = qkv.split(E, dim=-1)
-    ctx = _mha(q, k, v, nheads, key_valid, (E // nheads) ** -0.5)
-    x = _ln(x + _linear(ctx, sd, f"{prefix}.self_attn.out_proj"), sd, f"{prefix}.norm1", eps)
+    ctx = _mha(q, k, v, nheads, key_valid, (E // nheads) ** -0.5, None if drop is None else drop["attn"])
+    sa = _linear(ctx, sd, f"{prefix}.self_attn.out_proj")
+    if drop is not None:
+        sa = sa * drop["d1"]
+    x = _ln(x + sa, sd, f"{prefix}.norm1", eps)
     h = _linear(x, sd, f"{prefix}.linear1")
     h = torch.relu(h) if activation == "relu" else _gelu(h)
-    return _ln(x + _linear(h, sd, f"{prefix}.linear2"), sd, f"{prefix}.norm2", eps)
+    if drop is not None:
+        h = h * drop["ffn"]
+    ff = _linear(h, sd, f"{prefix}.linear2")
+    if drop is not None:
+        ff = ff * drop["d2"]
+    return _ln(x + ff, sd, f"{prefix}.norm2", eps)
 
 
 def post_ln_encoder(x, sd: SD, prefix: str, num_layers: int, nheads: int, key_valid, activation="relu", eps=1e-5,
-                    final_eps=1e-5):
-    """RNARBPCLIPEncoder.forward (rna_clip_codes.ipynb:1918-1923): layers then a final LayerNorm."""
+                    final_eps=1e-5, drops=None):
+    """RNARBPCLIPEncoder.forward (rna_clip_codes.ipynb:1918-1923): layers then a final LayerNorm.
+    drops: optional list of per-layer dropout multiplier dicts (post_ln_layer)."""
     for i in range(num_layers):
-        x = post_ln_layer(x, sd, f"{prefix}.layers.{i}", nheads, key_valid, activation, eps)
+        x = post_ln_layer(x, sd, f"{prefix}.layers.{i}", nheads, key_valid, activation, eps,
+                          None if drops is None else drops[i])
     return _ln(x, sd, f"{prefix}.layernorm", final_eps)
 
 

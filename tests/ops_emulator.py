@@ -39,13 +39,35 @@ def _act_grad(x, act):
     return torch.ones_like(x)
 
 
+def drop_hash32(seed, idx):
+    """The kernels' dropout hash (csrc/common.h drop_keep) in torch integer arithmetic: idx int64 >= 0 -> uint32."""
+    M = 0xFFFFFFFF
+    lo, hi = idx & M, (idx >> 32) & M
+    h = (lo * 0x9E3779B1 + hi * 0x85EBCA77 + (int(seed) & M)) & M
+    h = h ^ (h >> 16)
+    h = (h * 0x85EBCA6B) & M
+    h = h ^ (h >> 13)
+    h = (h * 0xC2B2AE35) & M
+    return h ^ (h >> 16)
+
+
+def drop_mult(p, seed, idx):
+    """keep / (1 - p) multiplier for element indices idx (any shape, int64)."""
+    t = p * 4294967296.0
+    thr = 1 if t < 1.0 else (4294967295 if t >= 4294967295.0 else int(t))
+    return (drop_hash32(seed, idx) >= thr).float() / (1.0 - p)
+
+
 def gemm_nt(a, b, bias=None, act=None, out_dtype=BF, residual=None, out_preact=False, dact_aux=None, dact=None,
-            alpha=1.0, out=None):
+            alpha=1.0, out=None, dropout=None):
     v = (a.float() @ b.float().t()) * alpha
     if bias is not None:
         v = v + bias
     pre = v.to(BF) if out_preact else None
     v = _act(v, act)
+    if dropout:
+        M_, N_ = v.shape
+        v = v * drop_mult(dropout[0], dropout[1], torch.arange(M_ * N_, dtype=torch.int64).view(M_, N_))
     if dact_aux is not None:
         v = v * _act_grad(dact_aux.float(), dact)
     if residual is not None:
@@ -173,7 +195,7 @@ def layernorm_fwd(x, gamma, beta, eps, act=None, want_f32=True, want_bf16=False,
 
 
 def layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=None, dx_add=None, want_f32=True, want_bf16=False, want_param_grads=True,
-                  dgamma=None, dbeta=None, accumulate=False):
+                  dgamma=None, dbeta=None, accumulate=False, dropout_bf16=None):
     xf, dyf = x.float(), dy.float()
     xh = (xf - mean[:, None]) * rstd[:, None]
     if act is not None:
@@ -189,7 +211,14 @@ def layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=None, dx_add=None, want_f3
         dgamma.copy_(dgamma + dg if accumulate else dg)
         dbeta.copy_(dbeta + db if accumulate else db)
         dg, db = dgamma, dbeta
-    return (dx if want_f32 else None), (dx.to(BF) if want_bf16 else None), dg, db
+    dxb = None
+    if want_bf16:
+        dxb = dx
+        if dropout_bf16:
+            R, Cc = dx.shape
+            dxb = dx * drop_mult(dropout_bf16[0], dropout_bf16[1], torch.arange(R * Cc, dtype=torch.int64).view(R, Cc))
+        dxb = dxb.to(BF)
+    return (dx if want_f32 else None), dxb, dg, db
 
 
 def l2norm_fwd(x, eps=1e-12):
@@ -231,7 +260,7 @@ def axpby_dev(a, b, s):
     return a + s * b
 
 
-def _attn_math(qkv, B, L, H, D, key_mask, rope, q_scale):
+def _attn_math(qkv, B, L, H, D, key_mask, rope, q_scale, dropout=None, row0=0, Lstride=None):
     x = qkv.view(B, L, 3, H, D).permute(2, 0, 3, 1, 4)
     q, k, v = x[0], x[1], x[2]
     if rope is not None:
@@ -246,12 +275,19 @@ def _attn_math(qkv, B, L, H, D, key_mask, rope, q_scale):
     if key_mask is not None:
         s = s.masked_fill(~key_mask.bool()[:, None, None, :], float("-inf"))
     p = torch.softmax(s, -1)
+    if dropout:
+        # index = ((token row of the query) * H + h) * Lstride + key, as the kernels (attention.hip attn_drop)
+        Ls = L if Lstride is None else Lstride
+        qrow = row0 + (torch.arange(B)[:, None] * L + torch.arange(L)[None, :])                 # [B, L]
+        idx = ((qrow[:, None, :, None] * H + torch.arange(H)[None, :, None, None]) * Ls
+               + torch.arange(L)[None, None, None, :]).to(torch.int64)
+        p = p * drop_mult(dropout[0], dropout[1], idx)
     o = p @ v
     return o.permute(0, 2, 1, 3).reshape(B * L, H * D), torch.logsumexp(s, -1)
 
 
-def attn_fwd(qkv, B, L, H, D, key_mask=None, rope=None, q_scale=1.0):
-    o, lse = _attn_math(qkv.float(), B, L, H, D, key_mask, rope, q_scale)
+def attn_fwd(qkv, B, L, H, D, key_mask=None, rope=None, q_scale=1.0, dropout=None, row0=0, Lstride=None):
+    o, lse = _attn_math(qkv.float(), B, L, H, D, key_mask, rope, q_scale, dropout, row0, Lstride)
     return o.to(BF), lse
 
 
@@ -278,7 +314,8 @@ def attn_fwd_rot_(qkv, B, L, H, D, rope, key_mask=None, q_scale=1.0):
     return attn_fwd(qkv, B, L, H, D, key_mask=key_mask, rope=None, q_scale=q_scale)
 
 
-def attn_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=None, rope=None, q_scale=1.0, prerotated=False):
+def attn_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=None, rope=None, q_scale=1.0, prerotated=False, dropout=None,
+             row0=0, Lstride=None):
     with torch.enable_grad():
         q = qkv.float().detach().requires_grad_(True)
         if prerotated and rope is not None:
@@ -288,7 +325,7 @@ def attn_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=None, rope=None, q_scale=
             z = torch.zeros_like(q).requires_grad_(True)
             g, = torch.autograd.grad(_rope_qk(z, B, L, H, D, rope), z, g_rot)
         else:
-            o, _ = _attn_math(q, B, L, H, D, key_mask, rope, q_scale)
+            o, _ = _attn_math(q, B, L, H, D, key_mask, rope, q_scale, dropout, row0, Lstride)
             g, = torch.autograd.grad(o, q, dout.float())
     return g.to(BF)
 
@@ -298,22 +335,23 @@ def _segments(cu):
     return [(cu[i], cu[i + 1]) for i in range(len(cu) - 1)]
 
 
-def attn_varlen_fwd(qkv, cu_seqlens, max_len, H, D, rope=None, q_scale=1.0):
+def attn_varlen_fwd(qkv, cu_seqlens, max_len, H, D, rope=None, q_scale=1.0, dropout=None):
     outs, lses = [], []
     for a, b in _segments(cu_seqlens):
         o, l = attn_fwd(qkv[a:b].contiguous(), 1, b - a, H, D, rope=None if rope is None else (rope[0][: b - a], rope[1][: b - a]),
-                        q_scale=q_scale)
+                        q_scale=q_scale, dropout=dropout, row0=a, Lstride=max_len)
         outs.append(o)
         lses.append(l.reshape(H, b - a))
     return torch.cat(outs, 0), torch.cat(lses, 1)
 
 
-def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_len, H, D, rope=None, q_scale=1.0):
+def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_len, H, D, rope=None, q_scale=1.0, dropout=None):
     gs = []
     for a, b in _segments(cu_seqlens):
         r = None if rope is None else (rope[0][: b - a], rope[1][: b - a])
         gs.append(attn_bwd(qkv[a:b].contiguous(), out[a:b].contiguous(), dout[a:b].contiguous(),
-                           lse[:, a:b].reshape(1, H, b - a).contiguous(), 1, b - a, H, D, rope=r, q_scale=q_scale))
+                           lse[:, a:b].reshape(1, H, b - a).contiguous(), 1, b - a, H, D, rope=r, q_scale=q_scale,
+                           dropout=dropout, row0=a, Lstride=max_len))
     return torch.cat(gs, 0)
 
 

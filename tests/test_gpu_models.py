@@ -617,3 +617,61 @@ def test_packed_varlen_path_equals_padded_path(dev):
             continue
         cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
         assert cos > 0.999, (n, cos)
+
+
+def test_dropout_layer_vs_masked_oracle(dev):
+    """nn.TransformerEncoderLayer's four dropout sites (attention probabilities, out_proj output, FFN activation, linear2
+    output; current/rna_clip_codes.ipynb:1915 trains with p = 0.1) inside the kernel stack, training mode: forward and
+    parameter / input gradients against the CPU oracle given the SAME masks.  The masks are counter-based
+    (csrc/common.h drop_keep); ops_emulator.drop_mult reproduces them in torch integer arithmetic from the seeds the
+    encoder draws.  Also: the keep rate of every site."""
+    import ops_emulator as E
+    import clip_dplm_amd as K
+    from oracle import encoder_ref
+    torch.manual_seed(0)
+    Ed, H, FF, B, L, nl, pdrop = 64, 8, 128, 6, 40, 2, 0.2
+    for act in ("relu", "gelu"):
+        enc = K.TransformerSeqEncoder(Ed, nl, H, FF, activation=act, layer_norm_eps=1e-5, dropout=pdrop)
+        sd = {"e." + k: v.detach().clone() for k, v in enc.state_dict().items()}
+        g = torch.Generator().manual_seed(4)
+        x = torch.randn(B, L, Ed, generator=g)
+        dy = torch.randn(B, L, Ed, generator=g)
+        lens = torch.tensor([40, 33, 17, 40, 5, 29])
+        valid = torch.arange(L)[None] < lens[:, None]
+        enc = enc.to(dev).train()
+        torch.manual_seed(123)
+        xd = x.detach().clone().to(dev).requires_grad_(True)
+        y = enc(xd, src_key_padding_mask=(~valid).to(dev))
+        (y * dy.to(dev)).sum().backward()
+        # the same seeds, then the same masks, on the host
+        torch.manual_seed(123)
+        seeds = torch.randint(0, 2 ** 31 - 1, (nl, 4), dtype=torch.int64).tolist()
+        T = B * L
+        drops = []
+        for sa, s1, sf, s2 in seeds:
+            qrow = torch.arange(T, dtype=torch.int64).view(B, L)
+            aidx = (qrow[:, None, :, None] * H + torch.arange(H)[None, :, None, None]) * L + torch.arange(L)[None, None, None, :]
+            drops.append({"attn": E.drop_mult(pdrop, sa, aidx),
+                          "d1": E.drop_mult(pdrop, s1, torch.arange(T * Ed, dtype=torch.int64)).view(B, L, Ed),
+                          "ffn": E.drop_mult(pdrop, sf, torch.arange(T * FF, dtype=torch.int64)).view(B, L, FF),
+                          "d2": E.drop_mult(pdrop, s2, torch.arange(T * Ed, dtype=torch.int64)).view(B, L, Ed)})
+        for d in drops:
+            for k, v in d.items():
+                keep = (v > 0).float().mean().item()
+                assert abs(keep - (1 - pdrop)) < 0.02, (k, keep)
+        sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        xr = x.detach().clone().requires_grad_(True)
+        ref = encoder_ref.post_ln_encoder(xr, sdr, "e", nl, H, valid, act, 1e-5, 1e-5, drops=drops)
+        (ref * dy).sum().backward()
+        m = valid[..., None].float()
+        err = ((y.detach().cpu() - ref.detach()) * m).abs().max().item()
+        assert err < 0.06, (act, err)                       # bf16 GEMM operands; LayerNorm'ed outputs are O(1)
+        assert_grad_close(xd.grad.cpu() * m, xr.grad * m, f"{act} dx", cos_min=0.99, rel_max=0.3)
+        got = dict(enc.named_parameters())
+        for n in ("layers.0.self_attn.in_proj_weight", "layers.0.linear1.weight", "layers.1.linear2.weight",
+                  "layers.1.self_attn.out_proj.weight", "layers.0.norm1.weight", "layernorm.weight"):
+            assert_grad_close(got[n].grad, sdr["e." + n].grad, f"{act} {n}", cos_min=0.99, rel_max=0.3)
+        # eval mode: dropout off, deterministic
+        enc.eval()
+        with torch.no_grad():
+            assert torch.equal(enc(xd, src_key_padding_mask=(~valid).to(dev)), enc(xd, src_key_padding_mask=(~valid).to(dev)))

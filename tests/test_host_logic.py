@@ -177,24 +177,29 @@ def test_flat_buffer_groups_qkv_for_zero_copy_fusion(monkeypatch):
     assert not torch.equal(before, enc.encoder.layer[1].attention.self.value.weight.detach())
 
 
-def test_dropout_in_training_mode_is_refused_not_ignored(monkeypatch):
-    """The kernel stack has no dropout: a module built with the notebook's p = 0.1 raises in training mode instead of
-    silently training unregularised; p = 0 trains, eval mode runs."""
+def test_dropout_training_mode_runs_and_is_seeded(monkeypatch):
+    """The encoder stacks implement nn.TransformerEncoderLayer's dropout: a module built with the notebook's
+    p = 0.1 trains, differs from p = 0, is reproducible under torch.manual_seed, and eval mode ignores it.  (The masked
+    parity test against the oracle is tests/test_gpu_models.py::test_dropout_layer_vs_masked_oracle, also emulated.)"""
     ops_emulator.install(monkeypatch)
     import clip_dplm_amd as K
+    torch.manual_seed(0)
     m = K.RNARBPCLIPModel(rna_dim=24, rbp_dim=64, projection_dim=32)            # dropout = 0.1 like the notebook
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0                                                         # heads: ATen dropout, not under test
     g = torch.Generator().manual_seed(0)
     rna, rbp = torch.randn(4, 6, 24, generator=g), torch.randn(4, 5, 64, generator=g)
     m.train()
-    with pytest.raises(NotImplementedError, match="dropout"):
-        m(rna, rbp)
+    torch.manual_seed(5); l1 = m(rna, rbp)[2]
+    torch.manual_seed(5); l2 = m(rna, rbp)[2]
+    torch.manual_seed(6); l3 = m(rna, rbp)[2]
+    assert torch.equal(l1, l2) and not torch.equal(l1, l3)
+    l1.backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
     m.eval()
-    assert torch.isfinite(m(rna, rbp)[2])
-    m2 = K.RNARBPCLIPModel(rna_dim=24, rbp_dim=64, projection_dim=32, dropout=0.0).train()
-    for mod in m2.modules():
-        if isinstance(mod, torch.nn.Dropout):
-            mod.p = 0.0
-    assert torch.isfinite(m2(rna, rbp)[2])
+    e1, e2 = m(rna, rbp)[2], m(rna, rbp)[2]
+    assert torch.equal(e1, e2) and not torch.equal(e1, l1.detach())
 
 
 def test_bench_launches_its_own_ranks():

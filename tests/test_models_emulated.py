@@ -27,6 +27,7 @@ CASES = [
     ("trimodal", T.test_trimodal_contrastive_model_golden, {}),
     ("trimodal_loss", T.test_trimodal_loss_pairs_kernels_vs_f64, {}),
     ("packed_varlen", T.test_packed_varlen_path_equals_padded_path, {}),
+    ("dropout_layer", T.test_dropout_layer_vs_masked_oracle, {}),
 ]
 
 
