@@ -66,7 +66,7 @@ SIGNATURES = {
     "clipk_gemm_f32_nt": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "clipk_layernorm_fwd": (_i, [_vp, _i, _i64, _vp, _vp, _f, _i, _vp, _vp, _i64, _vp, _vp, _i, _i, _vp]),
     "clipk_layernorm_bwd_workspace": (_sz, [_i, _i]),
-    "clipk_layernorm_bwd": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i64,
+    "clipk_layernorm_bwd": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i64,
                                  _vp, _vp, _i, _i, _i, _f, C.c_uint32, _vp, _sz, _vp]),
     "clipk_l2norm_fwd": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
     "clipk_l2norm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),

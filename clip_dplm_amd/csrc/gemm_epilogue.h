@@ -34,12 +34,15 @@ enum {
   EPI_RES32 = 1,      // f32 out = acc (+bias) + f32 residual
   EPI_GELU_PRE = 2,   // bf16 pre-activation out and bf16 GELU out (+bias)
   EPI_DGELU = 3,      // bf16 out = acc * GELU'(aux)
+  EPI_RES16 = 4,      // f32 out = acc (+bias) + bf16 residual   (post-LN layers: the residual is the bf16 LayerNorm output)
+  EPI_PRES16 = 5,     // bf16 out = acc (+bias) + bf16 residual  (their input gradients: bf16 residual-path gradient)
 };
 
 // VMEM stores one wave issues in gemm_epilogue<MODE, NJ> (its loads are consumed inside): callers that keep LDS-DMA
 // in flight across the epilogue count them in their s_waitcnt vmcnt(N)
 constexpr int epi_stores(int mode, int nj) {
-  return (mode == EPI_PLAIN || mode == EPI_DGELU) ? 2 * nj : (mode == EPI_RES32 || mode == EPI_GELU_PRE) ? 4 * nj : -1;
+  return (mode == EPI_PLAIN || mode == EPI_DGELU || mode == EPI_PRES16) ? 2 * nj
+         : (mode == EPI_RES32 || mode == EPI_GELU_PRE || mode == EPI_RES16) ? 4 * nj : -1;
 }
 
 // which specialised mode (if any) matches a request
@@ -52,6 +55,8 @@ static inline int epi_mode_for(const clipk_gemm_args* a) {
   if (has_pre && ((long)(a->M - 1) * a->ldp + a->N) * 2 > lim) return EPI_GENERIC;
   if (a->act == CLIPK_ACT_NONE && !has_aux && !has_res && !has_pre && !c_f32) return EPI_PLAIN;
   if (a->act == CLIPK_ACT_NONE && !has_aux && has_res && a->r_dtype == CLIPK_F32 && !has_pre && c_f32) return EPI_RES32;
+  if (a->act == CLIPK_ACT_NONE && !has_aux && has_res && a->r_dtype == CLIPK_BF16 && !has_pre)
+    return c_f32 ? EPI_RES16 : EPI_PRES16;
   if (a->act == CLIPK_ACT_GELU && !has_aux && !has_res && has_pre && !c_f32) return EPI_GELU_PRE;
   if (a->act == CLIPK_ACT_NONE && has_aux && a->dact == CLIPK_ACT_GELU && !has_res && !has_pre && !c_f32) return EPI_DGELU;
   return EPI_GENERIC;
@@ -113,7 +118,7 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
     // stores go through buffer descriptors: an out-of-range lane gets an offset past num_records and the hardware
     // drops its store, so the slice loop has no exec-masked blocks at all (epi_mode_for keeps the extents < 2 GiB)
     constexpr unsigned OOB = 0x80000000u;
-    const int c_elt = (MODE == EPI_RES32) ? 4 : 2;
+    const int c_elt = (MODE == EPI_RES32 || MODE == EPI_RES16) ? 4 : 2;
     const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(((long)(M - 1) * p.ldc + N) * c_elt), 0x00020000);
     const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         MODE == EPI_GELU_PRE ? (void*)p.out_preact : p.C, 0,
@@ -131,6 +136,8 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
         a1 = *reinterpret_cast<const f32x4*>(r + 4);
       }
       if constexpr (MODE == EPI_DGELU) b = *reinterpret_cast<const u32x4*>(p.dact_aux + (long)gm * p.ldd + gnc);
+      if constexpr (MODE == EPI_RES16 || MODE == EPI_PRES16)
+        b = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(p.residual) + (long)gm * p.ldr + gnc);
     };
     fetch(0, r0, r1, ax);
 #pragma unroll
@@ -167,6 +174,25 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
                                                      __float_as_uint(v[3])}, c_rsrc, off, p.nt);
         epi_store(u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]),
                                                      __float_as_uint(v[7])}, c_rsrc, off + 16, p.nt);
+      } else if constexpr (MODE == EPI_RES16 || MODE == EPI_PRES16) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          v[2 * c] += bf16_to_f32((unsigned short)(ax[c] & 0xffffu));
+          v[2 * c + 1] += bf16_to_f32((unsigned short)(ax[c] >> 16));
+        }
+        if constexpr (MODE == EPI_RES16) {
+          const unsigned off = ok ? (unsigned)(((long)gm * p.ldc + gn) * 4) : OOB;
+          epi_store(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
+                    c_rsrc, off, p.nt);
+          epi_store(u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])},
+                    c_rsrc, off + 16, p.nt);
+        } else {
+          u32x4 o;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) o[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
+          const unsigned off = ok ? (unsigned)(((long)gm * p.ldc + gn) * 2) : OOB;
+          epi_store(o, c_rsrc, off, p.nt);
+        }
       } else if constexpr (MODE == EPI_GELU_PRE) {
         u32x4 u, o;
 #pragma unroll

@@ -338,6 +338,8 @@ extern "C" int clipk_gemm_nt_v3_launch(const clipk_gemm_args* a, void* stream) {
   else if (mode == EPI_RES32) launch_v3<EPI_RES32>(p, grid, st);
   else if (mode == EPI_GELU_PRE) launch_v3<EPI_GELU_PRE>(p, grid, st);
   else if (mode == EPI_DGELU) launch_v3<EPI_DGELU>(p, grid, st);
+  else if (mode == EPI_RES16) launch_v3<EPI_RES16>(p, grid, st);
+  else if (mode == EPI_PRES16) launch_v3<EPI_PRES16>(p, grid, st);
   else launch_v3<EPI_GENERIC>(p, grid, st);
   return clipk_check_launch();
 }

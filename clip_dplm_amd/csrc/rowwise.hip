@@ -93,15 +93,16 @@ struct LnBwd {
   const void* dy; long lddy;
   const void* x; long ldx;
   const float* gamma; const float* beta; const float* mean; const float* rstd; int act;
-  const float* dx_add; float* dx_f32; void* dx_bf16; long lddx;
+  const void* dx_add; float* dx_f32; void* dx_bf16; long lddx;
   float* part;   // [nblocks][2][cols]
   int rows, cols;
   // dropout mask on the bf16 output only: it is the gradient of a Linear's dropped-out output (d(W x) = keep / (1-p) *
   // d(residual sum)), the f32 output stays the residual-path gradient.  Index = row * cols + col.  thr 0 = off.
   unsigned drop_thr, drop_seed; float drop_scale;
+  int add_bf16;     // dx_add holds bf16 instead of f32
 };
 
-template <int VPL, bool DYBF16, bool XBF16>
+template <int VPL, bool DYBF16, bool XBF16, bool ADD16 = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
     for (int v = 0; v < VPL; ++v) {
       const int c = lane + 64 * v;
       addv[v] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (p.dx_add && c < nch) addv[v] = *reinterpret_cast<const f32x4*>(p.dx_add + (long)row * p.lddx + 4 * c);
+      if (p.dx_add && c < nch) addv[v] = load4<ADD16>(p.dx_add, (long)row * p.lddx + 4 * c);   // f32, or bf16 (ADD16)
     }
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
@@ -299,12 +300,12 @@ int ln_blocks_cap(int rows, int cap) {
 int ln_blocks(int rows, int cols) { return ln_blocks_cap(rows, cols <= 512 ? 1024 : (cols <= 1024 ? 768 : 512)); }
 int ln_blocks_fwd(int rows) { return ln_blocks_cap(rows, 2048); }
 
-template <int VPL, bool DYBF16, bool XBF16>
+template <int VPL, bool DYBF16, bool XBF16, bool ADD16 = false>
 void launch_ln_bwd(const LnBwd& p, int blocks, size_t lds, hipStream_t st) {
   if (lds > 65536)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_kernel<VPL, DYBF16, XBF16>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_kernel<VPL, DYBF16, XBF16, ADD16>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((ln_bwd_kernel<VPL, DYBF16, XBF16>), dim3(blocks), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((ln_bwd_kernel<VPL, DYBF16, XBF16, ADD16>), dim3(blocks), dim3(256), lds, st, p);
 }
 
 }  // namespace
@@ -342,17 +343,18 @@ extern "C" size_t clipk_layernorm_bwd_workspace(int rows, int cols) {
 
 extern "C" int clipk_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, const void* x, int x_dtype, int64_t ldx,
                                    const float* gamma, const float* beta, const float* mean, const float* rstd, int act,
-                                   const float* dx_add, float* dx_f32, void* dx_bf16, int64_t lddx,
+                                   const void* dx_add, int dx_add_dtype, float* dx_f32, void* dx_bf16, int64_t lddx,
                                    float* dgamma, float* dbeta, int accumulate,
                                    int rows, int cols, float drop_p, uint32_t drop_seed,
                                    void* workspace, size_t workspace_bytes, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || rows <= 0 || cols <= 0 || !workspace) return CLIPK_ERR_BAD_ARG;
   if (act != CLIPK_ACT_NONE && !beta) return CLIPK_ERR_BAD_ARG;
   if ((cols & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3)) return CLIPK_ERR_UNSUPPORTED;
+  if (dx_add && dx_add_dtype == CLIPK_BF16 && !(dy_dtype == CLIPK_BF16 && x_dtype == CLIPK_F32)) return CLIPK_ERR_UNSUPPORTED;
   const int blocks = ln_blocks(rows, cols);
   if (workspace_bytes < (size_t)blocks * 2 * cols * sizeof(float)) return CLIPK_ERR_BAD_ARG;
   LnBwd p{dy, (long)lddy, x, (long)ldx, gamma, beta, mean, rstd, act, dx_add, dx_f32, dx_bf16, (long)lddx,
-          (float*)workspace, rows, cols, 0u, drop_seed, 1.0f};
+          (float*)workspace, rows, cols, 0u, drop_seed, 1.0f, (dx_add && dx_add_dtype == CLIPK_BF16) ? 1 : 0};
   if (drop_p > 0.f && drop_p < 1.f) {
     const double t = (double)drop_p * 4294967296.0;
     p.drop_thr = t < 1.0 ? 1u : (t >= 4294967295.0 ? 4294967295u : (unsigned)t);
@@ -362,7 +364,9 @@ extern "C" int clipk_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, c
   const size_t lds = (size_t)4 * 2 * cols * sizeof(float);
 #define CALL(V)                                                                                                   \
   do {                                                                                                            \
-    if (dy_dtype == CLIPK_BF16 && x_dtype == CLIPK_BF16)                                                          \
+    if (p.add_bf16)                             /* bf16 gradient stream: bf16 dy, f32 x (checked above) */       \
+      launch_ln_bwd<V, true, false, true>(p, blocks, lds, st);                                                    \
+    else if (dy_dtype == CLIPK_BF16 && x_dtype == CLIPK_BF16)                                                     \
       launch_ln_bwd<V, true, true>(p, blocks, lds, st);                                                           \
     else if (dy_dtype == CLIPK_BF16)                                                                              \
       launch_ln_bwd<V, true, false>(p, blocks, lds, st);                                                          \

@@ -363,12 +363,13 @@ def layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=None, dx_add=None, want_f3
     lib = _lib()
     nbytes = lib.clipk_layernorm_bwd_workspace(rows, cols)
     ws = workspace(nbytes, x.device, "ln")
-    nb = rows * cols * (dy.element_size() + x.element_size() + (4 if dx_add is not None else 0) +
+    nb = rows * cols * (dy.element_size() + x.element_size() + (dx_add.element_size() if dx_add is not None else 0) +
                         (4 if want_f32 else 0) + (2 if want_bf16 else 0))
     check(_timed("layernorm_bwd", nb,
                  lambda: lib.clipk_layernorm_bwd(dy.data_ptr(), _dt(dy), dy.stride(0), x.data_ptr(), _dt(x), x.stride(0),
                                                  gamma.data_ptr(), ptr(beta), mean.data_ptr(), rstd.data_ptr(), ACT[act],
-                                                 ptr(dx_add), ptr(dx32), ptr(dx16), cols, ptr(dgamma),
+                                                 ptr(dx_add), _dt(dx_add) if dx_add is not None else F32, ptr(dx32),
+                                                 ptr(dx16), cols, ptr(dgamma),
                                                  ptr(dbeta), int(accumulate), rows, cols,
                                                  float(dropout_bf16[0]) if dropout_bf16 else 0.0,
                                                  (int(dropout_bf16[1]) & 0xFFFFFFFF) if dropout_bf16 else 0, ws.data_ptr(),

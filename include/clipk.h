@@ -202,7 +202,7 @@ int clipk_layernorm_fwd(const void* x, int x_dtype, int64_t ldx, const float* ga
 /* LayerNorm backward: dx (f32 and/or bf16), and per-block partial dgamma/dbeta in workspace followed
  * by a deterministic column reduce into dgamma/dbeta (accumulate flag as above).  If act != NONE the
  * incoming dy is first multiplied by act'(ln_out) where ln_out is recomputed from x, mean, rstd.
- * dx_add: optional f32 [rows,cols] added to the result (residual-stream gradient).
+ * dx_add: optional [rows,cols] f32 or bf16 (dx_add_dtype) added to the result (residual-stream gradient).
  * drop_p > 0: the bf16 output (only) is multiplied by the dropout mask keep(drop_seed, row * cols + col) / (1 - p): it is
  * the gradient of the dropped-out Linear output that was added to the residual stream in front of this LayerNorm
  * (dropout1 / dropout2 of nn.TransformerEncoderLayer); the f32 output stays the residual-path gradient.
@@ -210,7 +210,7 @@ int clipk_layernorm_fwd(const void* x, int x_dtype, int64_t ldx, const float* ga
 size_t clipk_layernorm_bwd_workspace(int rows, int cols);
 int clipk_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, const void* x, int x_dtype, int64_t ldx,
                         const float* gamma, const float* beta, const float* mean, const float* rstd, int act,
-                        const float* dx_add, float* dx_f32, void* dx_bf16, int64_t lddx,
+                        const void* dx_add, int dx_add_dtype, float* dx_f32, void* dx_bf16, int64_t lddx,
                         float* dgamma, float* dbeta, int accumulate,
                         int rows, int cols, float drop_p, uint32_t drop_seed, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -205,7 +205,7 @@ def layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=None, dx_add=None, want_f3
     c2 = (g * xh).mean(-1, keepdim=True)
     dx = rstd[:, None] * (g - c1 - xh * c2)
     if dx_add is not None:
-        dx = dx + dx_add
+        dx = dx + dx_add.float()
     dg, db = (dyf * xh).sum(0), dyf.sum(0)
     if dgamma is not None:
         dgamma.copy_(dgamma + dg if accumulate else dg)

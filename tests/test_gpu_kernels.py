@@ -115,6 +115,12 @@ def test_gemm_nt_specialised_epilogues(dev, kopt, kernel, M, N, K):
     g, u = ops.gemm_nt(a, b, bias=bias, act="gelu", out_preact=True)
     assert torch.allclose(u.float(), ref + bias, **tol)
     assert torch.allclose(g.float(), F.gelu(ref + bias), **tol)
+    # RES16 / PRES16: bf16 residual, f32 or bf16 out
+    res16 = res.to(torch.bfloat16)
+    out = ops.gemm_nt(a, b, bias=bias, residual=res16, out_dtype=torch.float32)
+    assert torch.allclose(out, ref + bias + res16.float(), rtol=1e-4, atol=1e-4 * math.sqrt(K))
+    out = ops.gemm_nt(a, b, residual=res16)
+    assert torch.allclose(out.float(), ref + res16.float(), **tol)
     # DGELU
     auxf = aux.float().requires_grad_(True)
     gref, = torch.autograd.grad(F.gelu(auxf), auxf, torch.ones_like(auxf))
