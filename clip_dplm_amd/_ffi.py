@@ -85,7 +85,7 @@ SIGNATURES = {
     "clipk_attn_varlen_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, C.c_uint32, _vp]),
     "clipk_attn_varlen_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, C.c_uint32,
                                    _vp]),
-    "clipk_embed_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
+    "clipk_embed_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "clipk_embed_bwd_workspace": (_sz, [_i, _i, _i, _i]),
     "clipk_embed_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "clipk_pool_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -146,7 +146,7 @@ __global__ void dact_kernel(const void* dy, const unsigned short* aux, int act, 
 
 // ---- embedding ----------------------------------------------------------------------------------
 __global__ void embed_fwd_kernel(const int64_t* ids, const float* table, const float* row_scale, const uint8_t* mask,
-                                 int mask_token_id, float* x, int B, int L, int d) {
+                                 int mask_token_id, float* x, int B, int L, int d, int V) {
   const int nch = d >> 2;
   const long total = (long)B * L * nch;
   const long stride = (long)gridDim.x * blockDim.x;
@@ -156,8 +156,12 @@ __global__ void embed_fwd_kernel(const int64_t* ids, const float* table, const f
     float sc = row_scale ? row_scale[t / L] : 1.0f;
     if (mask && !mask[t]) sc = 0.f;
     if ((int)id == mask_token_id) sc = 0.f;
-    f32x4 v = *reinterpret_cast<const f32x4*>(table + id * d + 4 * c);
-    *reinterpret_cast<f32x4*>(x + t * d + 4 * c) = v * sc;
+    // an id outside the table never reads memory: its row comes out as NaN, so the mistake surfaces in the loss
+    // (F.embedding would trip a device assert; a silent wild read is the one thing that must not happen)
+    const bool ok = id >= 0 && id < V;
+    const float nanv = __uint_as_float(0x7fc00000u);
+    f32x4 v = ok ? *reinterpret_cast<const f32x4*>(table + id * d + 4 * c) : f32x4{nanv, nanv, nanv, nanv};
+    *reinterpret_cast<f32x4*>(x + t * d + 4 * c) = ok ? v * sc : v;
   }
 }
 
@@ -491,11 +495,11 @@ extern "C" int clipk_axpby_dev(const float* a, const float* b, const float* s, f
 }
 
 extern "C" int clipk_embed_fwd(const int64_t* ids, const float* table, const float* row_scale, const uint8_t* mask,
-                               int mask_token_id, float* x, int B, int L, int d, void* stream) {
-  if (!ids || !table || !x || B <= 0 || L <= 0 || d <= 0) return CLIPK_ERR_BAD_ARG;
+                               int mask_token_id, float* x, int B, int L, int d, int V, void* stream) {
+  if (!ids || !table || !x || B <= 0 || L <= 0 || d <= 0 || V <= 0) return CLIPK_ERR_BAD_ARG;
   if (d & 3) return CLIPK_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(embed_fwd_kernel, dim3(ew_blocks((long)B * L * (d / 4))), dim3(EW_THREADS), 0, (hipStream_t)stream,
-                     ids, table, row_scale, mask, mask_token_id, x, B, L, d);
+                     ids, table, row_scale, mask, mask_token_id, x, B, L, d, V);
   return clipk_check_launch();
 }
 static int embed_bwd_slices(int B, int L) {

@@ -236,6 +236,9 @@ class EsmStackFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.saved is None:
+            raise RuntimeError("EsmStackFn: second backward through the same forward: the stack frees each layer's "
+                               "activations as its backward consumes them (retain_graph is not supported)")
         module, meta = ctx.module, ctx.meta
         x, fin_w, fin_b, mf, rf = ctx.fin
         nl = module.num_layers
@@ -542,6 +545,9 @@ class PostLNStackFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.saved is None:
+            raise RuntimeError("PostLNStackFn: second backward through the same forward: the stack frees each layer's "
+                               "activations as its backward consumes them (retain_graph is not supported)")
         module, meta = ctx.module, ctx.meta
         x, fin_w, fin_b, mf, rf = ctx.fin
         nl = module.num_layers

@@ -89,9 +89,21 @@ def _dt(t: torch.Tensor) -> int:
 
 
 def _need_cuda(*ts):
+    """Every tensor on the GPU, and on the CURRENT one: the kernels are enqueued on the current device's stream, so a
+    tensor of another device would be read through a foreign pointer.  Fails loudly instead."""
+    dev = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise _ffi.ClipkError("libclipk kernels need device tensors (there is no CPU fallback)")
+        if dev is None:
+            dev = t.device
+            if dev.index is not None and dev.index != torch.cuda.current_device():
+                raise _ffi.ClipkError(f"tensor on {dev} but the current device is cuda:{torch.cuda.current_device()}: "
+                                      "wrap the call in `with torch.cuda.device(tensor.device):`")
+        elif t.device != dev:
+            raise _ffi.ClipkError(f"tensors on different devices: {dev} and {t.device}")
 
 
 def workspace(nbytes: int, device, tag: str = "ws") -> torch.Tensor:
@@ -549,7 +561,7 @@ def embed_fwd(ids, table, row_scale=None, mask=None, mask_token_id=-1):
     d = table.shape[1]
     x = torch.empty((B * L, d), dtype=torch.float32, device=table.device)
     check(_lib().clipk_embed_fwd(ids.data_ptr(), table.data_ptr(), ptr(row_scale), ptr(mask), mask_token_id, x.data_ptr(),
-                                 B, L, d, _stream()), "clipk_embed_fwd")
+                                 B, L, d, table.shape[0], _stream()), "clipk_embed_fwd")
     return x
 
 

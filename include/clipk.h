@@ -273,7 +273,7 @@ int clipk_attn_fwd_rot(void* qkv, const uint8_t* key_mask, const float* rope_cos
  */
 int clipk_embed_fwd(const int64_t* ids, const float* table, const float* row_scale /*[B] or NULL*/,
                     const uint8_t* mask /*[B*L] or NULL*/, int mask_token_id,
-                    float* x, int B, int L, int d, void* stream);
+                    float* x, int B, int L, int d, int V /* table rows: ids outside [0, V) give NaN rows */, void* stream);
 /* dtable[V,d] += sum over tokens (torch embedding backward).  V <= 64 (ESM-2: 33): one-hot product on the exact-f32
  * matrix pipe with fixed-order reductions, bitwise reproducible, needs the workspace below; larger vocabularies (or
  * workspace == NULL): per-block LDS tables + float atomics. */

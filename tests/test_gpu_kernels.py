@@ -715,3 +715,13 @@ def test_gemm_f32_all_layouts(dev, M, N, K, ta, tb):
     ref2 = ref + bias.double() + 0.37 * add.double()
     assert ((out2.double() - ref2).abs() <= bound + 1e-6).all()
     assert torch.equal(out, ops.gemm_f32(a, b, trans_a=ta, trans_b=tb))        # deterministic
+
+
+def test_embed_fwd_out_of_range_id_is_loud(dev):
+    """An id outside the table must never read memory: its row is NaN, every other row is exact."""
+    ops = _ops()
+    table = _rand((33, 64), dev, 61)
+    ids = torch.tensor([[0, 5, 32, 40], [7, -1, 2, 3]], device=dev)
+    x = ops.embed_fwd(ids, table).view(2, 4, 64)
+    assert torch.isnan(x[0, 3]).all() and torch.isnan(x[1, 1]).all()
+    assert torch.equal(x[0, 1], table[5]) and torch.equal(x[1, 3], table[3])

@@ -675,3 +675,15 @@ def test_dropout_layer_vs_masked_oracle(dev):
         enc.eval()
         with torch.no_grad():
             assert torch.equal(enc(xd, src_key_padding_mask=(~valid).to(dev)), enc(xd, src_key_padding_mask=(~valid).to(dev)))
+
+
+def test_second_backward_through_a_stack_raises(dev):
+    """The stacks free each layer's activations during the backward: a second backward is refused with a clear error
+    instead of failing somewhere inside."""
+    import clip_dplm_amd as K
+    enc = K.TransformerSeqEncoder(64, 1, 8, 128).to(dev)
+    x = torch.randn(2, 16, 64, device=dev, requires_grad=True)
+    y = enc(x).sum()
+    y.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second backward"):
+        y.backward()
