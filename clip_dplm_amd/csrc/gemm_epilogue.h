@@ -57,7 +57,9 @@ static inline int epi_mode_for(const clipk_gemm_args* a) {
   if (a->act == CLIPK_ACT_NONE && !has_aux && has_res && a->r_dtype == CLIPK_F32 && !has_pre && c_f32) return EPI_RES32;
   if (a->act == CLIPK_ACT_NONE && !has_aux && has_res && a->r_dtype == CLIPK_BF16 && !has_pre)
     return c_f32 ? EPI_RES16 : EPI_PRES16;
-  if (a->act == CLIPK_ACT_GELU && !has_aux && !has_res && has_pre && !c_f32) return EPI_GELU_PRE;
+  // (without a pre-activation output — frozen encoders keep nothing for a backward — the same mode runs with a
+  // zero-length descriptor for u: the hardware drops those stores)
+  if (a->act == CLIPK_ACT_GELU && !has_aux && !has_res && !c_f32) return EPI_GELU_PRE;
   if (a->act == CLIPK_ACT_NONE && has_aux && a->dact == CLIPK_ACT_GELU && !has_res && !has_pre && !c_f32) return EPI_DGELU;
   return EPI_GENERIC;
 }
@@ -121,8 +123,8 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
     const int c_elt = (MODE == EPI_RES32 || MODE == EPI_RES16) ? 4 : 2;
     const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(((long)(M - 1) * p.ldc + N) * c_elt), 0x00020000);
     const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        MODE == EPI_GELU_PRE ? (void*)p.out_preact : p.C, 0,
-        MODE == EPI_GELU_PRE ? (int)(((long)(M - 1) * p.ldp + N) * 2) : 0, 0x00020000);
+        (MODE == EPI_GELU_PRE && p.out_preact) ? (void*)p.out_preact : p.C, 0,
+        (MODE == EPI_GELU_PRE && p.out_preact) ? (int)(((long)(M - 1) * p.ldp + N) * 2) : 0, 0x00020000);
     constexpr int S = 2 * NJ;
     f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f};       // residual of the current slice
     u32x4 ax = {0u, 0u, 0u, 0u};                                       // GELU' argument of the current slice
@@ -202,7 +204,7 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
           const f32x2 y = gelu_erf2(f32x2{v[2 * c], v[2 * c + 1]});           // packed-f32 pipe
           o[c] = pack_bf16x2(y[0], y[1]);
         }
-        const unsigned offu = ok ? (unsigned)(((long)gm * p.ldp + gn) * 2) : OOB;
+        const unsigned offu = (ok && p.out_preact) ? (unsigned)(((long)gm * p.ldp + gn) * 2) : OOB;
         const unsigned off = ok ? (unsigned)(((long)gm * p.ldc + gn) * 2) : OOB;
         epi_store(u, u_rsrc, offu, p.nt);
         epi_store(o, c_rsrc, off, p.nt);

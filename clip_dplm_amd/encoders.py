@@ -139,7 +139,7 @@ class _Lin:
 # =================================================================================================
 # ESM-2 (pre-LN) stack
 # =================================================================================================
-def _esm_layer_fwd(x, p, meta):
+def _esm_layer_fwd(x, p, meta, keep=True):
     """x: f32 [T,d].  p: dict of this layer's tensors.  Returns y f32 [T,d] and the saved activations."""
     B, L, H, D, mask, rope, eps, seq = meta
     _, h1, m1, r1 = ops.layernorm_fwd(x, p["ln1_w"], p["ln1_b"], eps, want_f32=False, want_bf16=True)
@@ -155,7 +155,10 @@ def _esm_layer_fwd(x, p, meta):
         ctx, lse = ops.attn_fwd(qkv, B, L, H, D, key_mask=mask, rope=rope, q_scale=D ** -0.5)
     x2 = ops.gemm_nt(ctx, p["out"].wb, bias=p["out"].b, residual=x, out_dtype=torch.float32)
     _, h2, m2, r2 = ops.layernorm_fwd(x2, p["ln2_w"], p["ln2_b"], eps, want_f32=False, want_bf16=True)
-    g, u = ops.gemm_nt(h2, p["fc1"].wb, bias=p["fc1"].b, act="gelu", out_preact=True)
+    if keep:
+        g, u = ops.gemm_nt(h2, p["fc1"].wb, bias=p["fc1"].b, act="gelu", out_preact=True)
+    else:                                                  # frozen encoder: nothing is kept for a backward
+        g, u = ops.gemm_nt(h2, p["fc1"].wb, bias=p["fc1"].b, act="gelu"), None
     y = ops.gemm_nt(g, p["fc2"].wb, bias=p["fc2"].b, residual=x2, out_dtype=torch.float32)
     return y, (x, h1, m1, r1, qkv, ctx, lse, x2, h2, m2, r2, g, u)
 
@@ -224,7 +227,7 @@ class EsmStackFn(torch.autograd.Function):
             p = {"ln1_w": t[0], "ln1_b": t[1], "qkv": _Lin(t[2], t[3], caches[0], gw, gb, module.qkv_version_fn(i)),
                  "out": _Lin(t[4], t[5], caches[1]),
                  "ln2_w": t[6], "ln2_b": t[7], "fc1": _Lin(t[8], t[9], caches[2]), "fc2": _Lin(t[10], t[11], caches[3])}
-            x, s = _esm_layer_fwd(x, p, meta)
+            x, s = _esm_layer_fwd(x, p, meta, keep=need_bwd)
             layers.append(p)
             saved.append(s if need_bwd else None)
         y, _, mf, rf = ops.layernorm_fwd(x, fin_w, fin_b, module.eps, want_f32=True)

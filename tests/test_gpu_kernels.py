@@ -725,3 +725,22 @@ def test_embed_fwd_out_of_range_id_is_loud(dev):
     x = ops.embed_fwd(ids, table).view(2, 4, 64)
     assert torch.isnan(x[0, 3]).all() and torch.isnan(x[1, 1]).all()
     assert torch.equal(x[0, 1], table[5]) and torch.equal(x[1, 3], table[3])
+
+
+def test_gemm_nt_output_over_2gib_is_cut_into_slabs(dev):
+    """ESM-2-650M at B = 256, L = 1024 writes a 262144 x 5120 bf16 FFN activation (2.7 GB): beyond the 32-bit byte offsets of
+    the buffer-descriptor epilogues.  clipk_gemm_nt cuts such problems along M and keeps the specialised kernels:
+    results equal a direct f32 product, rows on both sides of the cut included; GELU with and without the saved
+    pre-activation (frozen encoders keep none)."""
+    ops = _ops()
+    M, N, K = 270336, 4096, 192
+    a = _rand((M, K), dev, 71, dtype=torch.bfloat16)
+    b = _rand((N, K), dev, 72, 0.05, dtype=torch.bfloat16)
+    bias = _rand((N,), dev, 73)
+    g, u = ops.gemm_nt(a, b, bias=bias, act="gelu", out_preact=True)
+    g2 = ops.gemm_nt(a, b, bias=bias, act="gelu")
+    assert torch.equal(g, g2)
+    for lo in (0, 209664 - 128, 209664, M - 256):               # around the slab boundary and at both ends
+        ref = a[lo:lo + 256].float() @ b.float().t() + bias
+        assert torch.allclose(u[lo:lo + 256].float(), ref, rtol=1e-2, atol=1e-2)
+        assert torch.allclose(g[lo:lo + 256].float(), F.gelu(ref), rtol=1e-2, atol=1e-2)
