@@ -449,6 +449,11 @@ class ESM2Encoder(nn.Module):
 POSTLN_BF16_RESIDUAL = os.environ.get("CLIPK_POSTLN_F32_RESIDUAL", "0") != "1"
 
 
+# (the pre-LayerNorm sums s1 / s2 stay f32: as bf16 they cost 1.7e-3 of loss on the small-width test model for 0.4 % of
+# the step, measured in round 2)
+_SUM_DT = torch.float32
+
+
 def _post_layer_fwd(x, xb, p, meta, dr=None):
     """dr = None or (p_drop, seed_attn, seed_drop1, seed_ffn, seed_drop2): the four nn.Dropout sites of
     nn.TransformerEncoderLayer (attention probabilities; out_proj output; FFN activation; linear2 output), each a
@@ -460,7 +465,7 @@ def _post_layer_fwd(x, xb, p, meta, dr=None):
         ctx, lse = ops.attn_varlen_fwd(qkv, seq[0], seq[1], H, D, rope=None, q_scale=qs, dropout=da)
     else:
         ctx, lse = ops.attn_fwd(qkv, B, L, H, D, key_mask=mask, rope=None, q_scale=qs, dropout=da)
-    s1 = ops.gemm_nt(ctx, p["out"].wb, bias=p["out"].b, residual=x, out_dtype=torch.float32, dropout=d1)
+    s1 = ops.gemm_nt(ctx, p["out"].wb, bias=p["out"].b, residual=x, out_dtype=_SUM_DT, dropout=d1)
     if POSTLN_BF16_RESIDUAL:
         _, x1b, m1, r1 = ops.layernorm_fwd(s1, p["n1_w"], p["n1_b"], eps, want_f32=False, want_bf16=True)
         x1 = x1b
@@ -471,7 +476,7 @@ def _post_layer_fwd(x, xb, p, meta, dr=None):
     else:
         g = ops.gemm_nt(x1b, p["fc1"].wb, bias=p["fc1"].b, act="relu", dropout=df)
         u = g                                    # relu'(pre) == relu'(relu(pre)); a dropped element has g = 0 either way
-    s2 = ops.gemm_nt(g, p["fc2"].wb, bias=p["fc2"].b, residual=x1, out_dtype=torch.float32, dropout=d2)
+    s2 = ops.gemm_nt(g, p["fc2"].wb, bias=p["fc2"].b, residual=x1, out_dtype=_SUM_DT, dropout=d2)
     if POSTLN_BF16_RESIDUAL:
         _, yb, m2, r2 = ops.layernorm_fwd(s2, p["n2_w"], p["n2_b"], eps, want_f32=False, want_bf16=True)
         y = yb
