@@ -64,6 +64,8 @@ def parse_args():
                          "waiting for the other tower's kernels)")
     ap.add_argument("--micro-batches", type=int, default=1, help="with --dual-stream: stream pairs per step")
     ap.add_argument("--wgrad-stream", action="store_true", help="weight-gradient GEMMs on a side stream per tower")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="libclipk kernel-selection option for this run (experiments; results never depend on options)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
@@ -175,6 +177,9 @@ def bench_clip(args):
     rank, world, device = init_distributed()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    for kv in args.opt:
+        name, _, val = kv.partition("=")
+        ops.set_option(name, int(val))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     force_dist = bool(os.environ.get("CLIPK_FORCE_DIST"))     # rehearse the RCCL code path with a 1-rank group

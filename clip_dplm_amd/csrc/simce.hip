@@ -259,19 +259,25 @@ __global__ __launch_bounds__(512) void simce_kernel(const SP p) {
   }
 }
 
-__global__ void simce_lse_finalize(const float* part_ml, int ksplit, int Mx, float* lse, long z_part) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per query: lanes take the key-split partials (m, l) s = lane, lane + 64, ..., merged by wave reductions (fixed
+// order: deterministic).  The serial one-thread-per-query loop was a 64-deep dependent chain of loads + expf (23 us at
+// 64 splits).
+__global__ __launch_bounds__(256) void simce_lse_finalize(const float* part_ml, int ksplit, int Mx, float* lse, long z_part) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= Mx) return;
   part_ml += blockIdx.y * z_part;                 // batched launch: blockIdx.y = problem
   lse += (long)blockIdx.y * Mx;
   float m = -INFINITY;
-  for (int s = 0; s < ksplit; ++s) m = fmaxf(m, part_ml[((long)s * Mx + i) * 2]);
+  for (int s = lane; s < ksplit; s += 64) m = fmaxf(m, part_ml[((long)s * Mx + i) * 2]);
+  m = wave_max(m);
   float l = 0.f;
-  for (int s = 0; s < ksplit; ++s) {
+  for (int s = lane; s < ksplit; s += 64) {
     const float ms = part_ml[((long)s * Mx + i) * 2], ls = part_ml[((long)s * Mx + i) * 2 + 1];
     if (ms > -INFINITY) l += ls * expf(ms - m);
   }
-  lse[i] = m + logf(l);
+  l = wave_sum(l);
+  if (lane == 0) lse[i] = m + logf(l);
 }
 
 __global__ void simce_grad_finalize(const float* slab, const float* dsc_part, int ksplit, int Mx, int P,
@@ -283,10 +289,35 @@ __global__ void simce_grad_finalize(const float* slab, const float* dsc_part, in
   dsc_part += blockIdx.y * z_dsc;
   dX += (long)blockIdx.y * Mx * P;
   if (dscale_partial) dscale_partial += (long)blockIdx.y * Mx;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+  // 64 float4 columns x 4 slab groups per workgroup: group g sums slabs [g ksplit/4, (g+1) ksplit/4) in order (eight
+  // loads in flight), the four group sums are added in group order: a fixed summation tree, so the result does not
+  // depend on scheduling (and equals the plain slab-ordered sum's tree for ksplit <= 4).
+  __shared__ f32x4 red[3][64];
+  const int col = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int per = (ksplit + 3) / 4;
+  const int s0 = g * per, s1 = (s0 + per < ksplit) ? s0 + per : ksplit;
+  const long slab_n = (long)Mx * P;
+  for (long i0 = blockIdx.x * 64L; i0 < n4; i0 += gridDim.x * 64L) {     // (uniform trip count per workgroup)
+    const long i = i0 + col;
     f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < ksplit; ++s) a += reinterpret_cast<const f32x4*>(slab + (long)s * Mx * P)[i];
-    reinterpret_cast<f32x4*>(dX)[i] = a * sc;
+    if (i < n4) {
+      int s = s0;
+      for (; s + 8 <= s1; s += 8) {
+        f32x4 t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = reinterpret_cast<const f32x4*>(slab + (long)(s + e) * slab_n)[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a += t[e];
+      }
+      for (; s < s1; ++s) a += reinterpret_cast<const f32x4*>(slab + (long)s * slab_n)[i];
+    }
+    if (g) red[g - 1][col] = a;
+    __syncthreads();
+    if (g == 0 && i < n4) {
+      a += red[0][col]; a += red[1][col]; a += red[2][col];
+      reinterpret_cast<f32x4*>(dX)[i] = a * sc;
+    }
+    __syncthreads();
   }
   if (dscale_partial) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < Mx; i += (long)gridDim.x * blockDim.x) {
@@ -327,10 +358,44 @@ int launch(const SP& sp, const Plan& pl, hipStream_t st) {
 
 }  // namespace
 
+// simce_tiled.hip: second-generation LSE pass (64 x 64 tiles, gemm_f32-style K-loop)
+extern "C" void clipk_simce_tiled_plan(int Mx, int Nkeys, int* nqb, int* ksplit, int* tps, int* ntiles);
+extern "C" int clipk_simce_lse_tiled_launch(const float* X, int Mx, const float* Y, int Ny, const float* Yc, int Nc, int P,
+                                            const float* scale, int label_offset, float* part_ml, float* pos,
+                                            void* stream);
+extern "C" void clipk_simce_grad_tiled_plan(int Mx, int Nkeys, int* nqb, int* ksplit, int* tps, int* ntiles);
+extern "C" int clipk_simce_grad_tiled_launch(const float* X, int Mx, const float* Y, int Ny, const float* Yc, int Nc,
+                                             int P, const float* scale, int label_offset, const float* lse_x,
+                                             const float* lse_y, float w_row, float w_col, float inv_bg, float* slab,
+                                             float* dsc_part, void* stream);
+static bool use_tiled_grad(int Mx, int Nkeys, int P, int Pw) {
+  const int mode = clipk_opt_get(OPT_SIMCE_KERNEL);
+  if (P > 512) return false;
+  // the first-generation gradient pass walks its P slice in blocks of 32 columns: it needs Pw % 32 == 0
+  if (Pw % 32) return true;
+  if (mode == 1) return false;
+  if (mode == 2) return true;
+  return Mx >= 64 && Nkeys >= 64;
+}
+static bool use_tiled_lse(int Mx, int Nkeys) {
+  const int mode = clipk_opt_get(OPT_SIMCE_KERNEL);
+  if (mode == 1) return false;
+  if (mode == 2) return true;
+  return Mx >= 64 && Nkeys >= 64;
+}
+
 extern "C" size_t clipk_simce_workspace(int Mx, int Nkeys, int P) {
   Plan pl;
   if (!make_plan(Mx, Nkeys, P, &pl)) return 0;
-  return (size_t)pl.ksplit * Mx * ((size_t)P + 2) * sizeof(float);
+  int nqb, ks2, tps, nt;
+  clipk_simce_tiled_plan(Mx, Nkeys, &nqb, &ks2, &tps, &nt);
+  const size_t a = (size_t)pl.ksplit * Mx * ((size_t)P + 2) * sizeof(float);
+  const size_t b = (size_t)ks2 * Mx * 2 * sizeof(float);          // (m, l) partials of the tiled LSE pass
+  int ks3;
+  clipk_simce_grad_tiled_plan(Mx, Nkeys, &nqb, &ks3, &tps, &nt);
+  const size_t c = (size_t)ks3 * Mx * ((size_t)P + 1) * sizeof(float);   // dX slabs + dscale partials of the tiled grad pass
+  const size_t ab = a > b ? a : b;
+  return ab > c ? ab : c;
 }
 
 extern "C" int clipk_simce_lse(const float* X, int Mx, const float* Y, int Ny, const float* Yc, int Nc,
@@ -340,6 +405,16 @@ extern "C" int clipk_simce_lse(const float* X, int Mx, const float* Y, int Ny, c
   Plan pl;
   if (!make_plan(Mx, Ny + Nc, P, &pl)) return CLIPK_ERR_UNSUPPORTED;
   if (!aligned16(X) || !aligned16(Y) || (Yc && !aligned16(Yc))) return CLIPK_ERR_BAD_ARG;
+  if (use_tiled_lse(Mx, Ny + Nc)) {
+    int nqb, ks2, tps, nt;
+    clipk_simce_tiled_plan(Mx, Ny + Nc, &nqb, &ks2, &tps, &nt);
+    if (workspace_bytes < (size_t)ks2 * Mx * 2 * sizeof(float)) return CLIPK_ERR_BAD_ARG;
+    int rc = clipk_simce_lse_tiled_launch(X, Mx, Y, Ny, Yc, Nc, P, scale, label_offset, (float*)workspace, pos, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(simce_lse_finalize, dim3((Mx + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, ks2, Mx, lse, 0L);
+    return clipk_check_launch();
+  }
   if (workspace_bytes < (size_t)pl.ksplit * Mx * 2 * sizeof(float)) return CLIPK_ERR_BAD_ARG;
   SP sp{};
   sp.X = X; sp.Mx = Mx; sp.Y = Y; sp.Ny = Ny; sp.Yc = Yc ? Yc : Y; sp.Nc = Nc;
@@ -348,7 +423,7 @@ extern "C" int clipk_simce_lse(const float* X, int Mx, const float* Y, int Ny, c
   sp.ksplit = pl.ksplit; sp.tiles_per_split = pl.tps; sp.ntiles = pl.ntiles;
   int rc = launch<MODE_LSE>(sp, pl, (hipStream_t)stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(simce_lse_finalize, dim3((Mx + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(simce_lse_finalize, dim3((Mx + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                      (const float*)workspace, pl.ksplit, Mx, lse, 0L);
   return clipk_check_launch();
 }
@@ -364,6 +439,22 @@ extern "C" int clipk_simce_grad(const float* X, int Mx, const float* Y, int Ny, 
   if (!make_plan(Mx, Ny + Nc, P, &pl)) return CLIPK_ERR_UNSUPPORTED;
   if (!aligned16(X) || !aligned16(Y) || (Yc && !aligned16(Yc)) || !aligned16(dX) || !aligned16(workspace))
     return CLIPK_ERR_BAD_ARG;
+  if (use_tiled_grad(Mx, Ny + Nc, P, pl.Pw)) {
+    int nqb, ks3, tps, nt;
+    clipk_simce_grad_tiled_plan(Mx, Ny + Nc, &nqb, &ks3, &tps, &nt);
+    if (workspace_bytes < (size_t)ks3 * Mx * ((size_t)P + 1) * sizeof(float)) return CLIPK_ERR_BAD_ARG;
+    float* slab = (float*)workspace;
+    float* dscp = slab + (size_t)ks3 * Mx * P;
+    int rc = clipk_simce_grad_tiled_launch(X, Mx, Y, Ny, Yc, Nc, P, scale, label_offset, lse_x, lse_y, w_row, w_col,
+                                           inv_bg, slab, dscp, stream);
+    if (rc) return rc;
+    long n4 = (long)Mx * P / 4;
+    int blocks = (int)((n4 + 63) / 64); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(simce_grad_finalize, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)slab,
+                       (const float*)dscp, ks3, Mx, P, scale, dX, dscale_partial, 0L, 0L);
+    return clipk_check_launch();
+  }
+  if (pl.Pw % 32) return CLIPK_ERR_UNSUPPORTED;             // P > 512 with a P slice that is not a multiple of 32
   const size_t need = (size_t)pl.ksplit * Mx * ((size_t)P + 1) * sizeof(float);
   if (workspace_bytes < need) return CLIPK_ERR_BAD_ARG;
   SP sp{};
@@ -375,7 +466,7 @@ extern "C" int clipk_simce_grad(const float* X, int Mx, const float* Y, int Ny, 
   int rc = launch<MODE_GRAD>(sp, pl, (hipStream_t)stream);
   if (rc) return rc;
   long n4 = (long)Mx * P / 4;
-  int blocks = (int)((n4 + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+  int blocks = (int)((n4 + 63) / 64); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(simce_grad_finalize, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                      (const float*)sp.slab, (const float*)sp.dsc_part, pl.ksplit, Mx, P, scale, dX,
                      dscale_partial, 0L, 0L);
@@ -414,7 +505,7 @@ extern "C" int clipk_simce_lse_pairs(const float* E, int nmod, int B, int P, con
   }
   int rc = launch<MODE_LSE>(sp, pl, (hipStream_t)stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(simce_lse_finalize, dim3((B + 255) / 256, npairs), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(simce_lse_finalize, dim3((B + 3) / 4, npairs), dim3(256), 0, (hipStream_t)stream,
                      (const float*)workspace, pl.ksplit, B, lse, z_part);
   return clipk_check_launch();
 }
@@ -448,7 +539,7 @@ extern "C" int clipk_simce_grad_pairs(const float* E, int nmod, int B, int P, co
   int rc = launch<MODE_GRAD>(sp, pl, (hipStream_t)stream);
   if (rc) return rc;
   long n4 = (long)B * P / 4;
-  int blocks = (int)((n4 + 255) / 256); if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+  int blocks = (int)((n4 + 63) / 64); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(simce_grad_finalize, dim3(blocks, npairs), dim3(256), 0, (hipStream_t)stream,
                      (const float*)sp.slab, (const float*)sp.dsc_part, pl.ksplit, B, P, scale, dX, dscale_partial,
                      z_slab, z_dsc);

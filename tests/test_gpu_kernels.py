@@ -744,3 +744,67 @@ def test_gemm_nt_output_over_2gib_is_cut_into_slabs(dev):
         ref = a[lo:lo + 256].float() @ b.float().t() + bias
         assert torch.allclose(u[lo:lo + 256].float(), ref, rtol=1e-2, atol=1e-2)
         assert torch.allclose(g[lo:lo + 256].float(), F.gelu(ref), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("Mx,Ny,Nc,P,off", [(512, 4096, 0, 512, 1024), (100, 300, 0, 64, 0), (128, 128, 200, 128, 0),
+                                            (1000, 1000, 37, 768, 0), (64, 64, 0, 36, 0)])
+def test_simce_tiled_lse_pass(dev, kopt, Mx, Ny, Nc, P, off):
+    """simce_tiled.hip (64 x 64 tiles, K-loop over P) against f64 and against the first-generation kernel: row LSE and
+    positive logit, ragged query / key / P edges, cache columns, label offsets."""
+    ops = _ops()
+    x, y = _unit((Mx, P), dev, 81), _unit((Ny, P), dev, 82)
+    cache = _unit((Nc, P), dev, 83) if Nc else None
+    sc = torch.tensor([14.2849], device=dev)
+    off = min(off, max(Ny - Mx, 0))
+    keys = y if cache is None else torch.cat([y, cache], 0)
+    S = (x.double() @ keys.double().t()) * 14.2849
+    ref_lse = torch.logsumexp(S, 1)
+    ref_pos = S[torch.arange(Mx, device=dev), torch.arange(Mx, device=dev) + off]
+    out = {}
+    for mode in (1, 2):
+        kopt("simce_kernel", mode)
+        lse, pos = ops.simce_lse(x, y, sc, label_offset=off, cache=cache)
+        assert torch.allclose(lse.double(), ref_lse, rtol=0, atol=2e-5), (mode, (lse.double() - ref_lse).abs().max())
+        assert torch.allclose(pos.double(), ref_pos, rtol=0, atol=2e-5), mode
+        out[mode] = lse
+        assert torch.equal(lse, ops.simce_lse(x, y, sc, label_offset=off, cache=cache)[0])      # deterministic
+    assert torch.allclose(out[1], out[2], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("Mx,Ny,Nc,P,off,wr,wc", [(512, 4096, 0, 512, 1024, 0.5, 0.5), (100, 300, 0, 64, 0, 1.0, 0.0),
+                                                  (128, 128, 200, 128, 0, 0.5, 0.5), (200, 200, 0, 36, 0, 0.5, 0.5),
+                                                  (256, 256, 0, 384, 0, 0.5, 0.5)])
+def test_simce_tiled_grad_pass(dev, kopt, Mx, Ny, Nc, P, off, wr, wc):
+    """simce_tiled.hip gradient pass against f64 autograd of  w_row CE(rows of [S | S_cache]) + w_col CE(columns of S)
+    restricted to this block's queries, and against the first-generation kernel: dX and the d scale partials."""
+    ops = _ops()
+    x, y = _unit((Mx, P), dev, 91), _unit((Ny, P), dev, 92)
+    cache = _unit((Nc, P), dev, 93) if Nc else None
+    sc = torch.tensor([14.2849], device=dev)
+    off = min(off, max(Ny - Mx, 0))
+    inv_bg = 1.0 / Ny
+    # arbitrary (consistent) LSE vectors are enough to pin the kernel's arithmetic: use the true ones
+    keys = y if cache is None else torch.cat([y, cache], 0)
+    Sx = (x.double() @ keys.double().t()) * 14.2849
+    lse_x = torch.logsumexp(Sx, 1).float().contiguous()
+    allq = _unit((Ny, P), dev, 94)                                     # the other ranks' queries: only their LSE matters
+    allq[off:off + Mx] = x
+    lse_y = torch.logsumexp((allq.double() @ y.double().t()) * 14.2849, 0).float().contiguous()
+    xd = x.double()
+    S = (xd @ keys.double().t()) * 14.2849
+    lab = torch.arange(Mx, device=dev) + off
+    G = wr * torch.exp(S - lse_x.double()[:, None])
+    G[:, :Ny] += wc * torch.exp(S[:, :Ny] - lse_y.double()[None, :])
+    G[torch.arange(Mx, device=dev), lab] -= (wr + wc)
+    G *= inv_bg
+    ref_dx = (G @ keys.double()) * 14.2849
+    ref_dsc = (G * (S / 14.2849)).sum(1)
+    out = {}
+    for mode in (1, 2):
+        kopt("simce_kernel", mode)
+        dx, dsc = ops.simce_grad(x, y, sc, lse_x, lse_y, wr, wc, inv_bg, label_offset=off, cache=cache)
+        assert torch.allclose(dx.double(), ref_dx, rtol=1e-4, atol=1e-7), (mode, (dx.double() - ref_dx).abs().max())
+        assert torch.allclose(dsc.double(), ref_dsc, rtol=1e-4, atol=1e-7), mode
+        assert torch.equal(dx, ops.simce_grad(x, y, sc, lse_x, lse_y, wr, wc, inv_bg, label_offset=off, cache=cache)[0])
+        out[mode] = dx
+    assert torch.allclose(out[1], out[2], rtol=1e-5, atol=1e-8)
