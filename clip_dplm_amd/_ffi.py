@@ -35,6 +35,8 @@ class GemmArgs(C.Structure):
         ("residual", C.c_void_p), ("ldr", C.c_int64), ("r_dtype", C.c_int),
         ("alpha", C.c_float),
         ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
+        ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
+        ("rope_L", C.c_int), ("rope_hd", C.c_int), ("rope_cols", C.c_int), ("rope_row0", C.c_int),
     ]
 
 

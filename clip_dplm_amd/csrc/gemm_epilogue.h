@@ -26,6 +26,7 @@ struct EpiArgs {
   float alpha;
   int nt;           // 1: non-temporal (streaming) output stores (epi_args_from decides)
   unsigned drop_thr, drop_seed; float drop_scale;   // dropout after the activation (generic epilogue only); thr 0 = off
+  const float* rope_cos; const float* rope_sin; int rope_L, rope_hd, rope_cols, rope_row0;   // EPI_ROPE only
 };
 
 enum {
@@ -36,12 +37,14 @@ enum {
   EPI_DGELU = 3,      // bf16 out = acc * GELU'(aux)
   EPI_RES16 = 4,      // f32 out = acc (+bias) + bf16 residual   (post-LN layers: the residual is the bf16 LayerNorm output)
   EPI_PRES16 = 5,     // bf16 out = acc (+bias) + bf16 residual  (their input gradients: bf16 residual-path gradient)
+  EPI_ROPE = 6,       // bf16 out = rotate-half RoPE of (acc + bias) on the first rope_cols columns, plain on the rest
 };
+constexpr int EPI_UNSUPPORTED = -2;   // epi_mode_for: the request cannot be honoured by any epilogue
 
 // VMEM stores one wave issues in gemm_epilogue<MODE, NJ> (its loads are consumed inside): callers that keep LDS-DMA
 // in flight across the epilogue count them in their s_waitcnt vmcnt(N)
 constexpr int epi_stores(int mode, int nj) {
-  return (mode == EPI_PLAIN || mode == EPI_DGELU || mode == EPI_PRES16) ? 2 * nj
+  return (mode == EPI_PLAIN || mode == EPI_DGELU || mode == EPI_PRES16 || mode == EPI_ROPE) ? 2 * nj
          : (mode == EPI_RES32 || mode == EPI_GELU_PRE || mode == EPI_RES16) ? 4 * nj : -1;
 }
 
@@ -49,8 +52,16 @@ constexpr int epi_stores(int mode, int nj) {
 static inline int epi_mode_for(const clipk_gemm_args* a) {
   const bool c_f32 = a->c_dtype == CLIPK_F32, has_res = a->residual != nullptr, has_aux = a->dact_aux != nullptr;
   const bool has_pre = a->out_preact != nullptr;
-  if (a->drop_p > 0.f) return EPI_GENERIC;               // dropout lives in the run-time epilogue
   const long lim = 0x7fffffffL;                          // buffer-descriptor stores: byte extents must stay < 2 GiB
+  if (a->rope_cos) {                                     // rotation exists in its straight-line mode only
+    const int hd = a->rope_hd;
+    const bool ok = a->rope_sin && (hd == 16 || hd == 32 || hd == 64) && a->rope_L > 0 && a->rope_cols > 0 &&
+                    a->rope_cols % hd == 0 && a->rope_cols <= a->N && a->rope_row0 >= 0 && !c_f32 && !has_res &&
+                    !has_aux && !has_pre && a->act == CLIPK_ACT_NONE && a->drop_p <= 0.f &&
+                    ((long)(a->M - 1) * a->ldc + a->N) * 2 <= lim;
+    return ok ? EPI_ROPE : EPI_UNSUPPORTED;
+  }
+  if (a->drop_p > 0.f) return EPI_GENERIC;               // dropout lives in the run-time epilogue
   if (((long)(a->M - 1) * a->ldc + a->N) * (c_f32 ? 4 : 2) > lim) return EPI_GENERIC;
   if (has_pre && ((long)(a->M - 1) * a->ldp + a->N) * 2 > lim) return EPI_GENERIC;
   if (a->act == CLIPK_ACT_NONE && !has_aux && !has_res && !has_pre && !c_f32) return EPI_PLAIN;
@@ -126,12 +137,39 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
         (MODE == EPI_GELU_PRE && p.out_preact) ? (void*)p.out_preact : p.C, 0,
         (MODE == EPI_GELU_PRE && p.out_preact) ? (int)(((long)(M - 1) * p.ldp + N) * 2) : 0, 0x00020000);
     constexpr int S = 2 * NJ;
-    f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f};       // residual of the current slice
+    f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f};       // residual (RoPE: cosines) of the current slice
+    f32x4 r2 = {0.f, 0.f, 0.f, 0.f}, r3 = {0.f, 0.f, 0.f, 0.f};       // RoPE: sines of the current slice
     u32x4 ax = {0u, 0u, 0u, 0u};                                       // GELU' argument of the current slice
+    // RoPE: the wave's 64 columns hold whole heads (tiles start at multiples of 64 columns, hd divides 64), so a
+    // lane's partner columns (+/- hd/2) are in the same slab row; all 8 columns of a lane sit on one side of the head
+    int rp_chunk = 0, rp_tcol = 0;
+    bool rp_on = false, rp_lo = false;
+    float bvp[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (MODE == EPI_ROPE) {
+      const int half = p.rope_hd >> 1, d0 = ecol & (p.rope_hd - 1);
+      rp_lo = d0 < half;
+      rp_tcol = rp_lo ? d0 : d0 - half;
+      rp_chunk = (rp_lo ? ecol + half : ecol - half) >> 2;
+      rp_on = col_ok && gn < p.rope_cols;
+      if (p.bias && rp_on) {                                           // the partner columns' bias
+        const float* bp = p.bias + (rp_lo ? gn + half : gn - half);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { bvp[c] = b0[c]; bvp[4 + c] = b1[c]; }
+      }
+    }
     auto row_of = [&](int s) { return mbase + (s >> 1) * 16 + (s & 1) * 8 + (lane >> 3); };
-    auto fetch = [&](int s, f32x4& a0, f32x4& a1, u32x4& b) {
+    auto fetch = [&](int s, f32x4& a0, f32x4& a1, u32x4& b, f32x4& a2, f32x4& a3) {
       int gm = row_of(s);
       gm = gm < M ? gm : M - 1;
+      if constexpr (MODE == EPI_ROPE) {
+        const int pos = (gm + p.rope_row0) % p.rope_L;
+        const long t = (long)pos * (p.rope_hd >> 1) + rp_tcol;
+        a0 = *reinterpret_cast<const f32x4*>(p.rope_cos + t);
+        a1 = *reinterpret_cast<const f32x4*>(p.rope_cos + t + 4);
+        a2 = *reinterpret_cast<const f32x4*>(p.rope_sin + t);
+        a3 = *reinterpret_cast<const f32x4*>(p.rope_sin + t + 4);
+      }
       if constexpr (MODE == EPI_RES32) {
         const float* r = reinterpret_cast<const float*>(p.residual) + (long)gm * p.ldr + gnc;
         a0 = *reinterpret_cast<const f32x4*>(r);
@@ -141,7 +179,24 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
       if constexpr (MODE == EPI_RES16 || MODE == EPI_PRES16)
         b = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(p.residual) + (long)gm * p.ldr + gnc);
     };
-    fetch(0, r0, r1, ax);
+    // Operand prefetch ring.  vmcnt retires in issue order and counts stores too, so waiting for the operands of
+    // slice s also waits for every store issued before their load: with the load one slice ahead that is the store of
+    // slice s - 2, i.e. each wave moves two slices per store round trip.  The distance therefore grows as the
+    // accumulators die (slice pair j frees 16 registers): 1, 2, 3, then RING - 1 slices ahead.
+#ifndef CLIPK_EPI_RING
+#define CLIPK_EPI_RING 4
+#endif
+    constexpr int RING = CLIPK_EPI_RING;
+    f32x4 R0[RING], R1[RING], R2[RING], R3[RING];
+    u32x4 AX[RING];
+#pragma unroll
+    for (int t = 0; t < RING; ++t) { R0[t] = r0; R1[t] = r1; R2[t] = r2; R3[t] = r3; AX[t] = ax; }
+    auto hi = [](int s) {                                    // last slice whose operands are requested by slice s
+      if (s < 0) return -1;
+      int a = 1 + (s >> 1); a = a > RING - 1 ? RING - 1 : a;
+      const int t = s + a;
+      return t < S - 1 ? t : S - 1;
+    };
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       const int j = s >> 1;
@@ -149,9 +204,10 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(eb + slab_off<SWZ>(li, i * 4 + g)) = acc[i][j] * alpha;
       }
-      f32x4 n0 = r0, n1 = r1;
-      u32x4 nx = ax;
-      if (s + 1 < S) fetch(s + 1, n0, n1, nx);                         // one slice ahead of its use
+#pragma unroll
+      for (int t = (s == 0 ? 0 : hi(s - 1) + 1); t <= hi(s); ++t)
+        fetch(t, R0[t % RING], R1[t % RING], AX[t % RING], R2[t % RING], R3[t % RING]);
+      r0 = R0[s % RING]; r1 = R1[s % RING]; r2 = R2[s % RING]; r3 = R3[s % RING]; ax = AX[s % RING];
       const int row = (s & 1) * 8 + (lane >> 3);
       const int gm = row_of(s);
       float v[8];
@@ -162,7 +218,27 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
         for (int c = 0; c < 4; ++c) { v[c] = v0[c] + bv[c]; v[4 + c] = v1[c] + bv[4 + c]; }
       }
       const bool ok = col_ok && gm < M;
-      if constexpr (MODE == EPI_PLAIN) {
+      if constexpr (MODE == EPI_ROPE) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(eb + slab_off<SWZ>(row, rp_chunk));
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(eb + slab_off<SWZ>(row, rp_chunk + 1));
+        u32x4 o;
+#pragma unroll
+        for (int c = 0; c < 8; c += 2) {
+          float y[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int k = c + e;
+            const float vp = (k < 4 ? w0[k] : w1[k - 4]) + bvp[k];
+            const float cs = rp_on ? (k < 4 ? r0[k] : r1[k - 4]) : 1.0f;
+            const float sn = rp_on ? (k < 4 ? r2[k] : r3[k - 4]) : 0.0f;
+            // explicit mul + fma, as rope_regs (attention.hip): x1' = fma(x1, c, -(x2 s)), x2' = fma(x2, c, x1 s)
+            y[e] = fmaf(v[k], cs, rp_lo ? -(vp * sn) : vp * sn);
+          }
+          o[c >> 1] = pack_bf16x2(y[0], y[1]);
+        }
+        const unsigned off = ok ? (unsigned)(((long)gm * p.ldc + gn) * 2) : OOB;
+        epi_store(o, c_rsrc, off, p.nt);
+      } else if constexpr (MODE == EPI_PLAIN) {
         u32x4 o;
 #pragma unroll
         for (int c = 0; c < 4; ++c) o[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
@@ -219,7 +295,6 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
         const unsigned off = ok ? (unsigned)(((long)gm * p.ldc + gn) * 2) : OOB;
         epi_store(o, c_rsrc, off, p.nt);
       }
-      r0 = n0; r1 = n1; ax = nx;
     }
   } else {
 #pragma unroll
@@ -308,6 +383,8 @@ static inline EpiArgs epi_args_from(const clipk_gemm_args* a) {
   // get slower), in the training step nothing (96.8 vs 96.6 ms): there the consumer of the output runs next and finds
   // less of it in the Infinity Cache.  Off by default.
   e.nt = clipk_opt_get(OPT_EPI_NT);
+  e.rope_cos = a->rope_cos; e.rope_sin = a->rope_sin; e.rope_L = a->rope_L; e.rope_hd = a->rope_hd;
+  e.rope_cols = a->rope_cols; e.rope_row0 = a->rope_row0;
   e.drop_thr = 0; e.drop_seed = a->drop_seed; e.drop_scale = 1.f;
   if (a->drop_p > 0.f && a->drop_p < 1.f) {
     const double t = (double)a->drop_p * 4294967296.0;

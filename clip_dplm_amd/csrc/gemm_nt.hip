@@ -244,6 +244,7 @@ extern "C" int clipk_gemm_nt(const clipk_gemm_args* a, void* stream) {
     if (a->out_preact) c.out_preact = (char*)a->out_preact + m0 * a->ldp * 2;
     if (a->dact_aux) c.dact_aux = (const char*)a->dact_aux + m0 * a->ldd * 2;
     if (a->residual) c.residual = (const char*)a->residual + m0 * a->ldr * r_elt;
+    c.rope_row0 = a->rope_row0 + (int)m0;                 // positions count from the first row of the whole problem
     // dropout masks are indexed by the global element position m * N + n: not supported across slabs
     if (a->drop_p > 0.f) return CLIPK_ERR_UNSUPPORTED;
     const int rc = gemm_nt_one(&c, stream);
@@ -275,6 +276,7 @@ static int gemm_nt_one(const clipk_gemm_args* a, void* stream) {
   if (!force_v1 && v3_ok && ((v3mode == 1 && a->M >= 2048) || (v3mode < 0 && tiles256 >= 192)))
     return clipk_gemm_nt_v3_launch(a, stream);
   if (!force_v1 && (a->K & 31) == 0) return clipk_gemm_nt_v2_launch(a, stream);
+  if (a->rope_cos) return CLIPK_ERR_UNSUPPORTED;           // the generic-K kernel has no rotation
   Params p;
   p.A = (const unsigned short*)a->A; p.lda = a->lda;
   p.B = (const unsigned short*)a->B; p.ldb = a->ldb;

@@ -174,6 +174,8 @@ extern "C" int clipk_gemm_nt_v2_launch(const clipk_gemm_args* a, void* stream) {
   const bool big = clipk_opt_get(OPT_GEMM_BM) == 256;      // A/B switches for tools/bench_kernels.py
   const int stages = clipk_opt_get(OPT_GEMM_STAGES);
   const int mode = clipk_opt_get(OPT_GEMM_EPI_GENERIC) == 1 ? EPI_GENERIC : epi_mode_for(a);
+  if (mode == EPI_UNSUPPORTED) return CLIPK_ERR_UNSUPPORTED;
+  if (a->rope_cos && (mode != EPI_ROPE || big || stages == 2)) return CLIPK_ERR_UNSUPPORTED;   // never unrotated
   static std::atomic<uint64_t> attr_set{0};
   clipk_once_per_device(attr_set, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_v2_kernel<256, 2>),
@@ -196,6 +198,7 @@ extern "C" int clipk_gemm_nt_v2_launch(const clipk_gemm_args* a, void* stream) {
     else if (mode == EPI_DGELU) hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, EPI_DGELU>), grid, blk, lds, st, p);
     else if (mode == EPI_RES16) hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, EPI_RES16>), grid, blk, lds, st, p);
     else if (mode == EPI_PRES16) hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, EPI_PRES16>), grid, blk, lds, st, p);
+    else if (mode == EPI_ROPE) hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, EPI_ROPE>), grid, blk, lds, st, p);
     else hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1>), grid, blk, lds, st, p);
   }
   return clipk_check_launch();

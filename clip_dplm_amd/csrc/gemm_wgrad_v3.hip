@@ -292,6 +292,7 @@ extern "C" void clipk_wgrad_v3_plan(int M, int N, int K, int* ntn, int* ntk, int
   *ntn = (N + BN - 1) / BN; *ntk = (K + BKO - 1) / BKO;
   const int ntiles = *ntn * *ntk;
   int s = 256 / ntiles;
+  if (clipk_opt_get(OPT_WGRAD_SPLITS) > 0) s = clipk_opt_get(OPT_WGRAD_SPLITS);
   if (s < 1) s = 1;
   const int max_splits = (M + 8 * BMS - 1) / (8 * BMS);         // at least 512 rows per split
   if (s > max_splits) s = max_splits;

@@ -38,6 +38,7 @@ _SIDE = {}
 
 
 PREROTATE_QK = os.environ.get("CLIPK_PREROTATE", "1") != "0"   # ESM: RoPE on q / k once after the qkv GEMM, not at every staging
+ROPE_IN_QKV_EPILOGUE = os.environ.get("CLIPK_ROPE_EPILOGUE", "1") != "0"   # hd in {16, 32, 64}: rotate in the qkv GEMM's epilogue
 DIRECT_PARAM_GRADS = True      # weight-gradient kernels accumulate straight into existing .grad buffers
 
 
@@ -143,6 +144,13 @@ def _esm_layer_fwd(x, p, meta, keep=True):
     """x: f32 [T,d].  p: dict of this layer's tensors.  Returns y f32 [T,d] and the saved activations."""
     B, L, H, D, mask, rope, eps, seq = meta
     _, h1, m1, r1 = ops.layernorm_fwd(x, p["ln1_w"], p["ln1_b"], eps, want_f32=False, want_bf16=True)
+    if seq is None and PREROTATE_QK and ROPE_IN_QKV_EPILOGUE and rope is not None and D in (16, 32, 64):
+        # heads that tile the GEMM's 64-column wave slices (ESM-2-650M: 20 x 64): q / k leave the projection's epilogue
+        # already rotated - no second pass over them.  (hd = 24 of the 35M model does not tile: branch below.)
+        qkv = ops.gemm_nt(h1, p["qkv"].wb, bias=p["qkv"].b, rope=(rope[0], rope[1], L, D, 2 * H * D))
+        ctx, lse = ops.attn_fwd(qkv, B, L, H, D, key_mask=mask, rope=None, q_scale=D ** -0.5)
+        x2 = ops.gemm_nt(ctx, p["out"].wb, bias=p["out"].b, residual=x, out_dtype=torch.float32)
+        return _esm_layer_ffn_fwd(x, x2, p, eps, keep, (h1, m1, r1, qkv, ctx, lse))
     qkv = ops.gemm_nt(h1, p["qkv"].wb, bias=p["qkv"].b)
     if seq is not None:                                    # packed variable-length batch: rows [cu[b], cu[b+1])
         ctx, lse = ops.attn_varlen_fwd(qkv, seq[0], seq[1], H, D, rope=rope, q_scale=D ** -0.5)
@@ -154,6 +162,11 @@ def _esm_layer_fwd(x, p, meta, keep=True):
     else:
         ctx, lse = ops.attn_fwd(qkv, B, L, H, D, key_mask=mask, rope=rope, q_scale=D ** -0.5)
     x2 = ops.gemm_nt(ctx, p["out"].wb, bias=p["out"].b, residual=x, out_dtype=torch.float32)
+    return _esm_layer_ffn_fwd(x, x2, p, eps, keep, (h1, m1, r1, qkv, ctx, lse))
+
+
+def _esm_layer_ffn_fwd(x, x2, p, eps, keep, att):
+    h1, m1, r1, qkv, ctx, lse = att
     _, h2, m2, r2 = ops.layernorm_fwd(x2, p["ln2_w"], p["ln2_b"], eps, want_f32=False, want_bf16=True)
     if keep:
         g, u = ops.gemm_nt(h2, p["fc1"].wb, bias=p["fc1"].b, act="gelu", out_preact=True)

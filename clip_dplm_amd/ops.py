@@ -120,10 +120,12 @@ def workspace(nbytes: int, device, tag: str = "ws") -> torch.Tensor:
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, act=None,
             out_dtype=torch.bfloat16, residual: Optional[torch.Tensor] = None, out_preact: bool = False,
             dact_aux: Optional[torch.Tensor] = None, dact=None, alpha: float = 1.0,
-            out: Optional[torch.Tensor] = None, dropout=None):
+            out: Optional[torch.Tensor] = None, dropout=None, rope=None):
     """C = epilogue(a[M,K] @ b[N,K]^T) with a, b bf16.  Returns C (and the bf16 pre-activation if asked).
-    dropout = (p, seed): nn.Dropout on the value after the activation (before act'(aux) and the residual add)."""
-    _need_cuda(a, b, bias, residual, dact_aux)
+    dropout = (p, seed): nn.Dropout on the value after the activation (before act'(aux) and the residual add).
+    rope = (cos, sin, L, hd, cols): rotate-half RoPE (tables f32 [L, hd/2], position = row mod L) on the first `cols`
+    output columns in the epilogue (ESM-2's fused qkv projection: cols = 2 * hidden)."""
+    _need_cuda(a, b, bias, residual, dact_aux, *(rope[:2] if rope else ()))
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
     assert a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[1]
     assert a.stride(1) == 1 and b.stride(1) == 1
@@ -147,6 +149,15 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
         args.residual, args.ldr, args.r_dtype = None, 0, 0
     args.alpha = alpha
     args.drop_p, args.drop_seed = (float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF) if dropout else (0.0, 0)
+    if rope is not None:
+        cos, sin, rl, hd, cols = rope
+        assert cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous()
+        assert cos.shape == (rl, hd // 2) and sin.shape == (rl, hd // 2)
+        args.rope_cos, args.rope_sin = cos.data_ptr(), sin.data_ptr()
+        args.rope_L, args.rope_hd, args.rope_cols, args.rope_row0 = int(rl), int(hd), int(cols), 0
+    else:
+        args.rope_cos, args.rope_sin = None, None
+        args.rope_L = args.rope_hd = args.rope_cols = args.rope_row0 = 0
     # algorithmic bytes: both operands once, every output / epilogue operand once
     nb = 2.0 * (M * K + N * K) + M * N * (c.element_size() + (2 if out_preact else 0) + (2 if dact_aux is not None else 0)
                                           + (residual.element_size() if residual is not None else 0))

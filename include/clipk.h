@@ -80,6 +80,14 @@ typedef struct clipk_gemm_args {
    * nn.TransformerEncoderLayer(dropout = p) (current/rna_clip_codes.ipynb:1915).  The same (seed, p) on the matching
    * backward GEMM reproduces the mask; nothing is stored.  drop_p = 0: off. */
   float drop_p; uint32_t drop_seed;
+  /* rotary position embedding on the first rope_cols output columns (ESM-2's fused [q | k | v] projection: the q and k
+   * thirds), applied to the f32 value (product + bias) before the single bf16 rounding: heads are rope_hd consecutive
+   * columns, out[d] = x[d] cos[pos, d mod hd/2] -/+ x[d +/- hd/2] sin[pos, d mod hd/2] (rotate-half, transformers
+   * modeling_esm.py:48-52,74-79), pos = (row + rope_row0) mod rope_L, tables f32 [rope_L, rope_hd/2].  Replaces the
+   * separate clipk_rope_qk pass after the projection (one read + one write of q and k per layer).  rope_cos = NULL:
+   * off.  Requirements: bf16 output, no activation / residual / aux / dropout, rope_hd in {16, 32, 64},
+   * rope_cols % rope_hd == 0, K % 32 == 0; anything else returns CLIPK_ERR_UNSUPPORTED (never silently unrotated). */
+  const float* rope_cos; const float* rope_sin; int rope_L, rope_hd, rope_cols, rope_row0;
 } clipk_gemm_args;
 int clipk_gemm_nt(const clipk_gemm_args* args, void* stream);
 

@@ -59,10 +59,19 @@ def drop_mult(p, seed, idx):
 
 
 def gemm_nt(a, b, bias=None, act=None, out_dtype=BF, residual=None, out_preact=False, dact_aux=None, dact=None,
-            alpha=1.0, out=None, dropout=None):
+            alpha=1.0, out=None, dropout=None, rope=None):
     v = (a.float() @ b.float().t()) * alpha
     if bias is not None:
         v = v + bias
+    if rope is not None:                                  # rotate-half on the first `cols` columns, heads of hd columns
+        cos, sin, L, hd, cols = rope
+        M_ = v.shape[0]
+        pos = torch.arange(M_) % L
+        c = torch.cat([cos[pos], cos[pos]], -1)[:, None, :]            # [M, 1, hd]
+        s_ = torch.cat([sin[pos], sin[pos]], -1)[:, None, :]
+        x = v[:, :cols].reshape(M_, cols // hd, hd)
+        rot = torch.cat([-x[..., hd // 2:], x[..., :hd // 2]], -1)
+        v = torch.cat([(x * c + rot * s_).reshape(M_, cols), v[:, cols:]], 1)
     pre = v.to(BF) if out_preact else None
     v = _act(v, act)
     if dropout:

@@ -746,6 +746,46 @@ def test_gemm_nt_output_over_2gib_is_cut_into_slabs(dev):
         assert torch.allclose(g[lo:lo + 256].float(), F.gelu(ref), rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("kernel,M", [("v2", 1000), ("v3", 2048 + 24)])
+@pytest.mark.parametrize("H,D", [(3, 64), (4, 32), (8, 16)])
+def test_gemm_nt_rope_epilogue(dev, kopt, kernel, M, H, D):
+    """RoPE in the qkv projection's epilogue (EPI_ROPE): q and k thirds rotated on the f32 value (product + bias)
+    before the one bf16 rounding, v third untouched; positions wrap at L (several sequences per launch, ragged M).
+    Reference: f32 product of the same bf16 operands + rotate-half (transformers modeling_esm.py:48-52,74-79)."""
+    import ops_emulator
+    ops = _ops()
+    kopt("gemm_kernel", 3 if kernel == "v3" else 2)
+    d, L, K = H * D, 250, 192
+    a = _rand((M, K), dev, 91, dtype=torch.bfloat16)
+    w = _rand((3 * d, K), dev, 92, 0.08, dtype=torch.bfloat16)
+    bias = _rand((3 * d,), dev, 93)
+    cos, sin = _rope_tables(L, D, dev)
+    out = ops.gemm_nt(a, w, bias=bias, rope=(cos, sin, L, D, 2 * d))
+    ref = ops_emulator.gemm_nt(a.cpu(), w.cpu(), bias=bias.cpu(), out_dtype=torch.float32,
+                               rope=(cos.cpu(), sin.cpu(), L, D, 2 * d))
+    err = (out.float().cpu() - ref).abs()
+    assert (err <= 2.0 ** -8 * ref.abs() + 1e-3).all(), float(err.max())       # one bf16 rounding of an f32 value
+    plain = ops.gemm_nt(a, w, bias=bias)
+    assert torch.equal(out[:, 2 * d:], plain[:, 2 * d:])                         # v: the plain epilogue's bits
+    rot2 = ops.rope_qk_(plain.clone()[: (M // L) * L].contiguous(), M // L, L, H, D, (cos, sin))
+    assert torch.allclose(out[: (M // L) * L].float(), rot2.float(), rtol=2e-2, atol=2e-2)   # vs the two-pass path
+
+
+def test_gemm_nt_rope_epilogue_refuses_what_it_cannot_rotate(dev):
+    """Heads that do not tile the 64-column wave slices (hd = 24) or a rotation combined with another epilogue must be
+    an error, never an unrotated result."""
+    from clip_dplm_amd._ffi import ClipkError
+    ops = _ops()
+    a = _rand((512, 64), dev, 94, dtype=torch.bfloat16)
+    w = _rand((144, 64), dev, 95, dtype=torch.bfloat16)
+    cos, sin = _rope_tables(128, 24, dev)
+    with pytest.raises(ClipkError):
+        ops.gemm_nt(a, w, rope=(cos, sin, 128, 24, 96))
+    cos, sin = _rope_tables(128, 16, dev)
+    with pytest.raises(ClipkError):
+        ops.gemm_nt(a, w, act="gelu", rope=(cos, sin, 128, 16, 96))
+
+
 @pytest.mark.parametrize("Mx,Ny,Nc,P,off", [(512, 4096, 0, 512, 1024), (100, 300, 0, 64, 0), (128, 128, 200, 128, 0),
                                             (1000, 1000, 37, 768, 0), (64, 64, 0, 36, 0)])
 def test_simce_tiled_lse_pass(dev, kopt, Mx, Ny, Nc, P, off):

@@ -111,6 +111,22 @@ def bench_wgrad():
     print(f"sum: v2 {tot[2]:.2f} ms, v3 {tot[3]:.2f} ms")
 
 
+def bench_wgrad_splits():
+    """v3 weight-gradient kernel: M-split count sweep per shape (option wgrad_splits; 0 = the plan's own choice)."""
+    ops.set_option("wgrad_kernel", 3)
+    arms = [0] + [int(v) for v in os.environ.get("BENCH_SPLITS", "8 16 24 32").split()]
+    print(f"{'shape':12s} " + " ".join(f"{('s=' + str(a)) if a else 'auto':>9s}" for a in arms) + "   (us)")
+    for name, M, N, K, _ in GEMM_SHAPES[:8]:
+        dy, x = rnd((M, N), scale=0.1), rnd((M, K))
+        res = []
+        for a in arms:
+            ops.set_option("wgrad_splits", a)
+            med, _ = timeit(lambda: ops.gemm_wgrad(dy, x, want_bias=True))
+            res.append(med * 1e3)
+        print(f"{name:12s} " + " ".join(f"{r:9.1f}" for r in res), flush=True)
+    ops.reset_options()
+
+
 def bench_attn():
     for name, B, L, H, D, rope in (("esm 35M", 512, 256, 20, 24, True), ("rna", 512, 256, 8, 96, False)):
         qkv = rnd((B * L, 3 * H * D))
@@ -147,6 +163,8 @@ if __name__ == "__main__":
         bench_gemm()
     if what in ("wgrad", "all"):
         bench_wgrad()
+    if what == "wsplit":
+        bench_wgrad_splits()
     if what in ("attn", "all"):
         bench_attn()
     if what in ("ln", "all"):
