@@ -92,6 +92,43 @@ def test_c2_full_depth_padded_loss_vs_oracle(dev):
     assert err <= 1e-3, (loss.item(), ref.item())
 
 
+def test_c2_full_size_properties_at_the_metric_batch(dev):
+    """The bench workload itself (B = 1024 pairs, L = 256, full depth: 262144 token rows through every kernel at the
+    shapes bench.py times), checked through size-independent properties the CPU oracle is too slow for:
+      * a sample's embedding does not depend on its position in the batch or on its neighbours: encoding a permuted
+        batch gives the permuted embeddings BIT FOR BIT (GEMM rows, LayerNorm rows, attention heads, pooling are
+        per-sample; the tile a row lands in changes, its arithmetic does not);
+      * a 64-pair slice of the batch, encoded alone, gives the same embeddings (the kernels the small problem selects
+        differ - 128x128 instead of persistent 256x256 GEMM tiles - so this one is a tolerance, 2e-3 on unit vectors);
+      * the fused loss at B = 1024 equals the f64 cross-entropy of the same embeddings to 1e-5, and the two directions
+        of the symmetric loss swap under swapping the towers' embeddings."""
+    import clip_dplm_amd as K
+    from clip_dplm_amd.loss import clip_loss
+    torch.manual_seed(0)
+    m = K.ProteinRNACLIP(esm="esm2_t12_35M_UR50D").eval().to(dev)
+    B, L = 1024, 256
+    rna, ids = _c2_batch(B, L, 4321)
+    rna, ids = rna.to(dev), ids.to(dev)
+    with torch.no_grad():
+        er, ep = m.embed(rna, ids)
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(7)).to(dev)
+        er_p, ep_p = m.embed(rna[perm].contiguous(), ids[perm].contiguous())
+        assert torch.equal(er_p, er[perm]) and torch.equal(ep_p, ep[perm])
+        er_s, ep_s = m.embed(rna[100:164].contiguous(), ids[100:164].contiguous())
+        assert (er_s - er[100:164]).abs().max().item() < 2e-3 and (ep_s - ep[100:164]).abs().max().item() < 2e-3
+        assert torch.allclose(er.norm(dim=-1), torch.ones(B, device=dev), atol=1e-5)
+        sc = m.logit_scale.exp()
+        loss = clip_loss(er, ep, sc, symmetric=True).item()
+        S = (er.double() @ ep.double().t()) * sc.double()
+        lab = torch.arange(B, device=dev)
+        ref = 0.5 * (F.cross_entropy(S, lab) + F.cross_entropy(S.t(), lab)).item()
+        assert abs(loss - ref) < 1e-5, (loss, ref)
+        row = clip_loss(er, ep, sc, symmetric=False).item()
+        col = clip_loss(ep, er, sc, symmetric=False).item()
+        assert abs(row - F.cross_entropy(S, lab).item()) < 1e-5 and abs(col - F.cross_entropy(S.t(), lab).item()) < 1e-5
+        assert abs(0.5 * (row + col) - loss) < 1e-6
+
+
 # ----------------------------------------------------------------------------------------------------- config 3
 @pytest.mark.parametrize("rank", [0, 3, 7])
 def test_c3_simce_rank_block_vs_f64(dev, rank):
@@ -206,6 +243,39 @@ def test_c4_gemm_shapes(dev, M, N, K):
     tol = 2e-4 * math.sqrt(M)
     assert torch.allclose(dw, wref, rtol=1e-4, atol=tol), (dw - wref).abs().max()
     assert torch.allclose(db, dy.float().sum(0), rtol=1e-4, atol=tol)
+
+
+def test_c4_full_size_frozen_encoder_properties(dev):
+    """Config 4 at its own size (B = 256 sequences x L = 1024 = 262144 token rows, frozen encoder: the no-grad forward
+    bench.py --config c4 times, with the FFN activation cut into M slabs and q / k rotated in the qkv epilogue), two
+    layers of the 650M shape.  Size-independent properties: (1) a permuted batch gives the permuted outputs bit for
+    bit; (2) sequences 64..67 encoded alone (different kernels: 128x128 GEMM tiles, no slabs) agree at bf16 level;
+    (3) rotating in the epilogue agrees with the separate rotation pass at bf16 level."""
+    import clip_dplm_amd as K
+    from clip_dplm_amd import encoders
+    torch.manual_seed(5)
+    enc = K.ESM2Encoder(num_layers=2, hidden_size=1280, num_heads=20, intermediate_size=5120).eval().to(dev)
+    for q in enc.parameters():
+        q.requires_grad_(False)
+    B, L = 256, 1024
+    g = torch.Generator().manual_seed(11)
+    ids = torch.randint(4, 24, (B, L), generator=g)
+    ids[:, 0], ids[:, -1] = 0, 2
+    ids = ids.to(dev)
+    with torch.no_grad():
+        y = enc(ids)
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).to(dev)
+        assert torch.equal(enc(ids[perm].contiguous()), y[perm])
+        ys = enc(ids[64:68].contiguous())
+        assert (ys - y[64:68]).abs().max().item() < 0.05                # final-LayerNorm outputs are O(1)
+        old = encoders.ROPE_IN_QKV_EPILOGUE
+        try:
+            encoders.ROPE_IN_QKV_EPILOGUE = False
+            y2 = enc(ids[:32].contiguous())
+        finally:
+            encoders.ROPE_IN_QKV_EPILOGUE = old
+        assert (y2 - y[:32]).abs().max().item() < 0.05
+        assert torch.isfinite(y).all()
 
 
 # ----------------------------------------------------------------------------------------------------- config 5
