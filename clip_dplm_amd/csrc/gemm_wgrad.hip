@@ -190,7 +190,7 @@ __global__ __launch_bounds__(NTHREADS, 3) void wgrad_kernel(const WP p) {
   }
 }
 
-__global__ void wgrad_reduce_kernel(const float* slab, const float* bslab, int splits, int N, int K,
+__global__ void wgrad_reduce_kernel(const float* slab, const float* bslab, int splits, int bsplits, int N, int K,
                                     float* dW, long lddw, float* dbias, int accumulate) {
   const long total4 = (long)N * K / 4;
   const int k4 = K >> 2;
@@ -213,7 +213,14 @@ __global__ void wgrad_reduce_kernel(const float* slab, const float* bslab, int s
   if (dbias) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < N; i += stride) {
       float a = 0.f;
-      for (int s = 0; s < splits; ++s) a += bslab[(long)s * N + i];
+      int s = 0;
+      for (; s + 8 <= bsplits; s += 8) {                     // eight loads in flight; fixed summation order
+        float t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = bslab[(long)(s + e) * N + i];
+        a += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+      }
+      for (; s < bsplits; ++s) a += bslab[(long)s * N + i];
       dbias[i] = accumulate ? dbias[i] + a : a;
     }
   }
@@ -250,8 +257,9 @@ extern "C" size_t clipk_gemm_wgrad_workspace(int M, int N, int K) {
   const Plan pl = make_plan(M, N, K);
   int ntn, ntk, splits, mps;
   clipk_wgrad_v3_plan(M, N, K, &ntn, &ntk, &splits, &mps);
-  const int smax = pl.splits > splits ? pl.splits : splits;    // either kernel may be chosen at launch time
-  return (size_t)smax * ((size_t)N * K + N) * sizeof(float);
+  // either kernel may be chosen at launch time; the 256 x 256 kernel keeps one bias partial per (split, k-tile)
+  const size_t a = (size_t)pl.splits * ((size_t)N * K + N), b = (size_t)splits * ((size_t)N * K + (size_t)ntk * N);
+  return (a > b ? a : b) * sizeof(float);
 }
 
 extern "C" int clipk_gemm_wgrad(const void* dY, int64_t lddy, const void* X, int64_t ldx,
@@ -264,7 +272,7 @@ extern "C" int clipk_gemm_wgrad(const void* dY, int64_t lddy, const void* X, int
   if (use_v3(M, N, K)) {
     clipk_wgrad_v3_args a;
     clipk_wgrad_v3_plan(M, N, K, &a.ntn, &a.ntk, &a.splits, &a.m_per_split);
-    if (workspace_bytes < (size_t)a.splits * ((size_t)N * K + N) * sizeof(float)) return CLIPK_ERR_BAD_ARG;
+    if (workspace_bytes < (size_t)a.splits * ((size_t)N * K + (size_t)a.ntk * N) * sizeof(float)) return CLIPK_ERR_BAD_ARG;
     a.dY = (const unsigned short*)dY; a.lddy = lddy;
     a.X = (const unsigned short*)X; a.ldx = ldx;
     a.slab = (float*)workspace;
@@ -275,7 +283,7 @@ extern "C" int clipk_gemm_wgrad(const void* dY, int64_t lddy, const void* X, int
     long total4 = (long)N * K / 4;
     int blocks = (int)((total4 + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)a.slab, (const float*)a.bslab,
-                       a.splits, N, K, dW, (long)lddw, dbias, accumulate);
+                       a.splits, a.splits * a.ntk, N, K, dW, (long)lddw, dbias, accumulate);
     return clipk_check_launch();
   }
   const Plan pl = make_plan(M, N, K);
@@ -294,6 +302,6 @@ extern "C" int clipk_gemm_wgrad(const void* dY, int64_t lddy, const void* X, int
   long total4 = (long)N * K / 4;
   int blocks = (int)((total4 + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)p.slab, (const float*)p.bslab,
-                     pl.splits, N, K, dW, (long)lddw, dbias, accumulate);
+                     pl.splits, pl.splits, N, K, dW, (long)lddw, dbias, accumulate);
   return clipk_check_launch();
 }

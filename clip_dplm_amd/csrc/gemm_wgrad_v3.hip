@@ -15,8 +15,11 @@
 //     check and load zeros, which is exactly what the contraction needs at the ragged end;
 //   * M is split over workgroups so that one launch puts ~one workgroup on every CU; each workgroup runs ONE long
 //     main loop (M / splits / 64 = 30..100 steps), so unlike the forward GEMM nothing needs to be persistent;
-//   * the bias gradient is 4 extra MFMAs per step and wave against an all-ones fragment: the four k-waves of an
-//     n-wave hold identical dY fragments, so each of them sums two of the eight n-tiles (8 VGPRs, not 32).
+//   * the bias gradient is MFMAs against an all-ones fragment: the four k-waves of an n-wave hold identical dY
+//     fragments, so wave wk sums n-tile wk of each half (2 MFMAs in phase 1, 2 in phase 3: every wave of the
+//     workgroup gets the same 18 instead of 16 MFMAs in those phases), and the ntk workgroups that share a dY panel
+//     take turns by step (T mod ntk == tk), so no workgroup of the launch is slower than the others.  Partial sums
+//     per (split, tk) go to the bias slab [splits * ntk][N].
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -25,7 +28,7 @@ struct clipk_wgrad_v3_args {
   const unsigned short* dY; long lddy;
   const unsigned short* X; long ldx;
   float* slab;        // [splits][N][K]
-  float* bslab;       // [splits][N] or null
+  float* bslab;       // [splits * ntk][N] or null
   int M, N, K;
   int ntn, ntk, splits, m_per_split;
 };
@@ -91,7 +94,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_v3_kernel(const clipk_wgrad_v3_a
   const int m_beg = split * p.m_per_split;
   int m_end = m_beg + p.m_per_split; m_end = m_end < M ? m_end : M;
   const int nkt = (m_end - m_beg + BMS - 1) / BMS;             // >= 1
-  const bool do_bias = (p.bslab != nullptr) && (tk == 0);
+  const bool has_bias = p.bslab != nullptr;
+  int bias_T = tk;                                             // next step whose dY rows this workgroup sums
 
   // ---- LDS-DMA assignment: wave w fills pieces 2w, 2w+1 (4 rows x 256 B each) of every half-tile.
   // lane -> (row in piece = lane>>4, physical 16-B slot = lane&15); the slot's 32-B segment (slot>>1) holds the
@@ -148,6 +152,19 @@ __global__ __launch_bounds__(512, 1) void wgrad_v3_kernel(const clipk_wgrad_v3_a
 
   bf16x8 yf[4][2], xf[2][2][2];
 
+  // dY column sums: accb[half] += yf[wk] x ones (wk is wave-uniform: a branch, not an indexed register array)
+  auto bias_tile = [&](int half) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (wk == t) {
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) {
+          if (half == 0) accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[t][ms], ones, accb[0], 0, 0, 0);
+          else accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[t][ms], ones, accb[1], 0, 0, 0);
+        }
+      }
+  };
+
   // TM 0: steady state; 1: step nkt-2 (only the last half-tile of step nkt-1 left to fetch); 2: last step
   auto step_body = [&](auto mode_c, int T) {
     constexpr int TM = decltype(mode_c)::value;
@@ -185,21 +202,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_v3_kernel(const clipk_wgrad_v3_a
     CLIPK_SB();
     __builtin_amdgcn_s_setprio(1);
     quad<1, 0>(acc, yf, xf);
-    if (do_bias && wk < 2) {                                    // n-tiles 0..3 are live: k-waves 0, 1 sum two each
-      if (wk == 0) {
-#pragma unroll
-        for (int ms = 0; ms < 2; ++ms) {
-          accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[0][ms], ones, accb[0], 0, 0, 0);
-          accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[1][ms], ones, accb[1], 0, 0, 0);
-        }
-      } else {
-#pragma unroll
-        for (int ms = 0; ms < 2; ++ms) {
-          accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[2][ms], ones, accb[0], 0, 0, 0);
-          accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[3][ms], ones, accb[1], 0, 0, 0);
-        }
-      }
-    }
+    const bool bias_now = has_bias && T == bias_T;              // (workgroup-uniform)
+    if (bias_now) bias_tile(0);                                 // n-tiles 0..3 are live: wave wk sums tile wk
     __builtin_amdgcn_s_setprio(0);
     CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
     // ---- phase 2: quadrant (k1, n1); fetch dY nh1; refill dY nh0 of step T+2
@@ -226,21 +230,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_v3_kernel(const clipk_wgrad_v3_a
     CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
     __builtin_amdgcn_s_setprio(1);
     quad<0, 1>(acc, yf, xf);
-    if (do_bias && wk >= 2) {                                   // n-tiles 4..7 are live: k-waves 2, 3
-      if (wk == 2) {
-#pragma unroll
-        for (int ms = 0; ms < 2; ++ms) {
-          accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[0][ms], ones, accb[0], 0, 0, 0);
-          accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[1][ms], ones, accb[1], 0, 0, 0);
-        }
-      } else {
-#pragma unroll
-        for (int ms = 0; ms < 2; ++ms) {
-          accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[2][ms], ones, accb[0], 0, 0, 0);
-          accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[3][ms], ones, accb[1], 0, 0, 0);
-        }
-      }
-    }
+    if (bias_now) { bias_tile(1); bias_T += p.ntk; }            // n-tiles 4..7 are live
     __builtin_amdgcn_s_setprio(0);
     CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
   };
@@ -273,14 +263,15 @@ __global__ __launch_bounds__(512, 1) void wgrad_v3_kernel(const clipk_wgrad_v3_a
         if (n < N && k < K) slab[(long)n * K + k] = acc[i][j][r];
       }
     }
-  if (do_bias && li == 0) {
-    // this k-wave summed n-tiles (wk & 1) * 2 + {0, 1} of half wk >> 1
+  if (has_bias && li == 0) {
+    // accb[u]: n-tile wk of half u of this n-wave, summed over this workgroup's turns (possibly none: zeros)
+    float* bs = p.bslab + ((long)split * p.ntk + tk) * N;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = n0 + wn * 128 + (wk >> 1) * 64 + ((wk & 1) * 2 + u) * 16 + 4 * g + r;
-        if (n < N) p.bslab[(long)split * N + n] = accb[u][r];
+        const int n = n0 + wn * 128 + u * 64 + wk * 16 + 4 * g + r;
+        if (n < N) bs[n] = accb[u][r];
       }
   }
 }
