@@ -76,8 +76,20 @@ __device__ __forceinline__ void quad(f32x4 (&acc)[8][4], const bf16x8 (&yf)[4][2
             __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[t][ms], xf[KH][u][ms], acc[NH * 4 + t][KH * 2 + u], 0, 0, 0);
 }
 
-#define CLIPK_BAR() __builtin_amdgcn_s_barrier()
 #define CLIPK_SB() __builtin_amdgcn_sched_barrier(0)
+#ifdef CLIPK_WGRAD_TRACE
+// experiment builds (tools/exp_wgrad_trace.py): cycle stamps after every barrier of steps 8..11, workgroup 0,
+// waves 0 (n-wave group 0) and 4 (group 1) -> where a K-step's time goes
+__device__ unsigned long long* g_wgrad_trace = nullptr;
+#define CLIPK_BAR()                                                                                       \
+  do {                                                                                                    \
+    __builtin_amdgcn_s_barrier();                                                                         \
+    if (tr_on && tr_T >= 8 && tr_T < 12 && tr_i < 16) tr[(tr_T - 8) * 16 + tr_i] = __builtin_readcyclecounter(); \
+    ++tr_i;                                                                                               \
+  } while (0)
+#else
+#define CLIPK_BAR() __builtin_amdgcn_s_barrier()
+#endif
 
 __global__ __launch_bounds__(512, 1) void wgrad_v3_kernel(const clipk_wgrad_v3_args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -94,6 +106,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_v3_kernel(const clipk_wgrad_v3_a
   const int m_beg = split * p.m_per_split;
   int m_end = m_beg + p.m_per_split; m_end = m_end < M ? m_end : M;
   const int nkt = (m_end - m_beg + BMS - 1) / BMS;             // >= 1
+#ifdef CLIPK_WGRAD_TRACE
+  const bool tr_on = bid == 0 && (wid == 0 || wid == 4) && lane == 0 && g_wgrad_trace != nullptr;
+  unsigned long long* tr = g_wgrad_trace + (wid == 4 ? 64 : 0);
+  int tr_T = -1, tr_i = 0;
+#endif
   const bool has_bias = p.bslab != nullptr;
   int bias_T = tk;                                             // next step whose dY rows this workgroup sums
 
@@ -131,7 +148,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_v3_kernel(const clipk_wgrad_v3_a
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 accb[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  f32x4 accb[2][2];                                            // [n half][m half of the step]
+#pragma unroll
+  for (int u = 0; u < 2; ++u) { accb[u][0] = f32x4{0.f, 0.f, 0.f, 0.f}; accb[u][1] = accb[u][0]; }
   bf16x8 ones;
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones[j] = (short)0x3F80;          // bf16 1.0
@@ -152,23 +171,48 @@ __global__ __launch_bounds__(512, 1) void wgrad_v3_kernel(const clipk_wgrad_v3_a
 
   bf16x8 yf[4][2], xf[2][2][2];
 
-  // dY column sums: accb[half] += yf[wk] x ones (wk is wave-uniform: a branch, not an indexed register array)
-  auto bias_tile = [&](int half) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-      if (wk == t) {
-#pragma unroll
-        for (int ms = 0; ms < 2; ++ms) {
-          if (half == 0) accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[t][ms], ones, accb[0], 0, 0, 0);
-          else accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[t][ms], ones, accb[1], 0, 0, 0);
-        }
-      }
+  // dY column sums: accb[half][ms] += yf[wk][ms] x ones.  The tile a wave sums depends on wk; as C++ branches the
+  // accumulators become phi copies around each branch, and hipcc then waits for the matrix pipe to copy them
+  // (s_nop 7 + v_mov, ~200 cycles per phase).  So the four-way choice is ONE asm statement with the accumulators in
+  // place: two independent MFMAs per wave.  s_nop 1 first: `ones` may have been written by a VALU move just before.
+  // Nothing but these MFMAs touches accb until the epilogue, hundreds of instructions after the last one.
+  auto bias_tile = [&](f32x4& a0, f32x4& a1) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "s_cmp_lg_u32 %[wk], 0\n\t"
+        "s_cbranch_scc1 1f\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[a0], %[y00], %[on], %[a0]\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[a1], %[y01], %[on], %[a1]\n\t"
+        "s_branch 4f\n"
+        "1:\n\t"
+        "s_cmp_lg_u32 %[wk], 1\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[a0], %[y10], %[on], %[a0]\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[a1], %[y11], %[on], %[a1]\n\t"
+        "s_branch 4f\n"
+        "2:\n\t"
+        "s_cmp_lg_u32 %[wk], 2\n\t"
+        "s_cbranch_scc1 3f\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[a0], %[y20], %[on], %[a0]\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[a1], %[y21], %[on], %[a1]\n\t"
+        "s_branch 4f\n"
+        "3:\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[a0], %[y30], %[on], %[a0]\n\t"
+        "v_mfma_f32_16x16x32_bf16 %[a1], %[y31], %[on], %[a1]\n"
+        "4:\n\t"
+        : [a0] "+v"(a0), [a1] "+v"(a1)
+        : [wk] "s"(wk), [on] "v"(ones), [y00] "v"(yf[0][0]), [y01] "v"(yf[0][1]), [y10] "v"(yf[1][0]),
+          [y11] "v"(yf[1][1]), [y20] "v"(yf[2][0]), [y21] "v"(yf[2][1]), [y30] "v"(yf[3][0]), [y31] "v"(yf[3][1])
+        : "scc");
   };
 
   // TM 0: steady state; 1: step nkt-2 (only the last half-tile of step nkt-1 left to fetch); 2: last step
   auto step_body = [&](auto mode_c, int T) {
     constexpr int TM = decltype(mode_c)::value;
     const unsigned bo = (T & 1) * BUF_BYTES;
+#ifdef CLIPK_WGRAD_TRACE
+    tr_T = T; tr_i = 0;
+#endif
     // ---- phase 0: quadrant (k0, n0); fetch X kh0 (8 reads, first) + dY nh0 (16 reads); refill dY nh1 of step T+1
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -203,7 +247,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_v3_kernel(const clipk_wgrad_v3_a
     __builtin_amdgcn_s_setprio(1);
     quad<1, 0>(acc, yf, xf);
     const bool bias_now = has_bias && T == bias_T;              // (workgroup-uniform)
-    if (bias_now) bias_tile(0);                                 // n-tiles 0..3 are live: wave wk sums tile wk
+    if (bias_now) bias_tile(accb[0][0], accb[0][1]);            // n-tiles 0..3 are live: wave wk sums tile wk
     __builtin_amdgcn_s_setprio(0);
     CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
     // ---- phase 2: quadrant (k1, n1); fetch dY nh1; refill dY nh0 of step T+2
@@ -230,7 +274,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_v3_kernel(const clipk_wgrad_v3_a
     CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
     __builtin_amdgcn_s_setprio(1);
     quad<0, 1>(acc, yf, xf);
-    if (bias_now) { bias_tile(1); bias_T += p.ntk; }            // n-tiles 4..7 are live
+    if (bias_now) { bias_tile(accb[1][0], accb[1][1]); bias_T += p.ntk; }   // n-tiles 4..7 are live
     __builtin_amdgcn_s_setprio(0);
     CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
   };
@@ -245,10 +289,23 @@ __global__ __launch_bounds__(512, 1) void wgrad_v3_kernel(const clipk_wgrad_v3_a
   }
   CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
   if (wn == 1) CLIPK_BAR();                                     // n = 1 waves run one barrier behind
+#ifdef CLIPK_WGRAD_TRACE
+  // in-kernel clock (MI355X_MICROARCH.md, DVFS item 6): shader cycles and 100 MHz ticks around the main loop
+  unsigned long long tc0 = 0, tr0 = 0;
+  if (tr_on && wid == 0) { tc0 = __builtin_amdgcn_s_memtime(); tr0 = __builtin_amdgcn_s_memrealtime(); }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
   for (int T = 0; T < nkt - 2; ++T) step_body(std::integral_constant<int, 0>{}, T);
   if (nkt > 1) step_body(std::integral_constant<int, 1>{}, nkt - 2);
   step_body(std::integral_constant<int, 2>{}, nkt - 1);
   if (wn == 0) CLIPK_BAR();                                     // re-align
+#ifdef CLIPK_WGRAD_TRACE
+  if (tr_on && wid == 0) {
+    g_wgrad_trace[128] = __builtin_amdgcn_s_memtime() - tc0;
+    g_wgrad_trace[129] = __builtin_amdgcn_s_memrealtime() - tr0;
+    g_wgrad_trace[130] = (unsigned long long)nkt;
+  }
+#endif
 
   // ---- store the f32 partial tile: rows n (4 per lane), cols k (lane&15)
   float* slab = p.slab + (long)split * N * K;
@@ -271,7 +328,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_v3_kernel(const clipk_wgrad_v3_a
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + wn * 128 + u * 64 + wk * 16 + 4 * g + r;
-        if (n < N) bs[n] = accb[u][r];
+        if (n < N) bs[n] = accb[u][0][r] + accb[u][1][r];
       }
   }
 }
@@ -292,6 +349,12 @@ extern "C" void clipk_wgrad_v3_plan(int M, int N, int K, int* ntn, int* ntk, int
   *mps = m;
   *splits = (M + m - 1) / m;
 }
+
+#ifdef CLIPK_WGRAD_TRACE
+extern "C" int clipk_wgrad_v3_set_trace(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_wgrad_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int clipk_wgrad_v3_launch(const clipk_wgrad_v3_args* a, void* stream) {
   static std::atomic<uint64_t> attr_set{0};
