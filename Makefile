@@ -24,6 +24,9 @@ tools/probes/probe_store_vs_dma: tools/probes/probe_store_vs_dma.hip
 # experiment build of the weight-gradient kernel with barrier cycle stamps (tools/exp_wgrad_trace.py)
 tools/probes/libwgrad_trace.so: clip_dplm_amd/csrc/gemm_wgrad_v3.hip clip_dplm_amd/csrc/core.hip clip_dplm_amd/csrc/common.h
 	$(HIPCC) $(HIPFLAGS) -DCLIPK_WGRAD_TRACE -shared -o $@ clip_dplm_amd/csrc/gemm_wgrad_v3.hip clip_dplm_amd/csrc/core.hip
+# ... and its timing ablations (results garbage): make tools/probes/libwgrad_trace_abl3.so
+tools/probes/libwgrad_trace_abl%.so: clip_dplm_amd/csrc/gemm_wgrad_v3.hip clip_dplm_amd/csrc/core.hip clip_dplm_amd/csrc/common.h
+	$(HIPCC) $(HIPFLAGS) -DCLIPK_WGRAD_TRACE -DCLIPK_WGRAD_ABL=$* -shared -o $@ clip_dplm_amd/csrc/gemm_wgrad_v3.hip clip_dplm_amd/csrc/core.hip
 tools/probes/probe_layouts: tools/probes/probe_layouts.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -Wno-unused-value -o $@ $<
 tools/probes/probe_gather: tools/probes/probe_gather.hip

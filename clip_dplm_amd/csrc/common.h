@@ -19,7 +19,7 @@ enum clipk_opt {
   OPT_GEMM_NWG,            // v3: persistent grid size (multiple of 8), 0 = one workgroup per CU
   OPT_GEMM_STAGGER,        // start-up stagger of workgroups (0 = off)
   OPT_EPI_NT,              // 1: non-temporal epilogue stores
-  OPT_WGRAD_KERNEL,        // -1 auto, 2 128x128 kernel, 3 256x256 phase-interleaved kernel
+  OPT_WGRAD_KERNEL,        // -1 auto, 2 128x128 kernel, 3 256x256 kernel (8-phase schedule), 4 256x256 software-pipelined
   OPT_ATTN_WHOLE_FWD,      // -1 auto, 0 off, 1 on: whole-head forward for short heads
   OPT_ATTN_FUSED_BWD,      // -1 auto, 0 off, 1 on: whole-head backward for short heads
   OPT_ATTN_FUSED_WAVES,    // 4 (default) or 8 waves per workgroup in the whole-head backward

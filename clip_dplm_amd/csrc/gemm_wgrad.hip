@@ -246,7 +246,7 @@ Plan make_plan(int M, int N, int K) {
 bool use_v3(int M, int N, int K) {
   const int mode = clipk_opt_get(OPT_WGRAD_KERNEL);
   if (mode == 2) return false;
-  if (mode == 3) return M >= 1024;
+  if (mode == 3 || mode == 4) return M >= 1024;
   return M >= 16384 && N >= 128 && K >= 128;
 }
 

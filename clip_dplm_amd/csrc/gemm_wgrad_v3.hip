@@ -87,10 +87,21 @@ __device__ unsigned long long* g_wgrad_trace = nullptr;
     if (tr_on && tr_T >= 8 && tr_T < 12 && tr_i < 16) tr[(tr_T - 8) * 16 + tr_i] = __builtin_readcyclecounter(); \
     ++tr_i;                                                                                               \
   } while (0)
+#define CLIPK_BAR2() __builtin_amdgcn_s_barrier()
+#define CLIPK_STAMP()                                                                                     \
+  do {                                                                                                    \
+    if (tr_on && tr_T >= 8 && tr_T < 12 && tr_i < 16) tr[(tr_T - 8) * 16 + tr_i] = __builtin_readcyclecounter(); \
+    ++tr_i;                                                                                               \
+  } while (0)
 #else
 #define CLIPK_BAR() __builtin_amdgcn_s_barrier()
+#define CLIPK_BAR2() __builtin_amdgcn_s_barrier()
+#define CLIPK_STAMP() do { } while (0)
 #endif
 
+// SCHED 1: the 8-phase schedule (two wave groups one barrier apart, reads issued right before the barrier of the
+// phase that consumes them).  SCHED 2: software-pipelined schedule, see the main loop below.
+template <int SCHED>
 __global__ __launch_bounds__(512, 1) void wgrad_v3_kernel(const clipk_wgrad_v3_args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -169,143 +180,327 @@ __global__ __launch_bounds__(512, 1) void wgrad_v3_kernel(const clipk_wgrad_v3_a
 #pragma unroll
   for (int u = 0; u < 2; ++u) xa[u] = lds0 + trow * ROWB + (((wk * 2 + u) ^ sw) << 5) + 8 * (li & 3);
 
-  bf16x8 yf[4][2], xf[2][2][2];
+  if constexpr (SCHED == 1) {
+    bf16x8 yf[4][2], xf[2][2][2];
 
-  // dY column sums: accb[half][ms] += yf[wk][ms] x ones.  The tile a wave sums depends on wk; as C++ branches the
-  // accumulators become phi copies around each branch, and hipcc then waits for the matrix pipe to copy them
-  // (s_nop 7 + v_mov, ~200 cycles per phase).  So the four-way choice is ONE asm statement with the accumulators in
-  // place: two independent MFMAs per wave.  s_nop 1 first: `ones` may have been written by a VALU move just before.
-  // Nothing but these MFMAs touches accb until the epilogue, hundreds of instructions after the last one.
-  auto bias_tile = [&](f32x4& a0, f32x4& a1) {
-    asm volatile(
-        "s_nop 1\n\t"
-        "s_cmp_lg_u32 %[wk], 0\n\t"
-        "s_cbranch_scc1 1f\n\t"
-        "v_mfma_f32_16x16x32_bf16 %[a0], %[y00], %[on], %[a0]\n\t"
-        "v_mfma_f32_16x16x32_bf16 %[a1], %[y01], %[on], %[a1]\n\t"
-        "s_branch 4f\n"
-        "1:\n\t"
-        "s_cmp_lg_u32 %[wk], 1\n\t"
-        "s_cbranch_scc1 2f\n\t"
-        "v_mfma_f32_16x16x32_bf16 %[a0], %[y10], %[on], %[a0]\n\t"
-        "v_mfma_f32_16x16x32_bf16 %[a1], %[y11], %[on], %[a1]\n\t"
-        "s_branch 4f\n"
-        "2:\n\t"
-        "s_cmp_lg_u32 %[wk], 2\n\t"
-        "s_cbranch_scc1 3f\n\t"
-        "v_mfma_f32_16x16x32_bf16 %[a0], %[y20], %[on], %[a0]\n\t"
-        "v_mfma_f32_16x16x32_bf16 %[a1], %[y21], %[on], %[a1]\n\t"
-        "s_branch 4f\n"
-        "3:\n\t"
-        "v_mfma_f32_16x16x32_bf16 %[a0], %[y30], %[on], %[a0]\n\t"
-        "v_mfma_f32_16x16x32_bf16 %[a1], %[y31], %[on], %[a1]\n"
-        "4:\n\t"
-        : [a0] "+v"(a0), [a1] "+v"(a1)
-        : [wk] "s"(wk), [on] "v"(ones), [y00] "v"(yf[0][0]), [y01] "v"(yf[0][1]), [y10] "v"(yf[1][0]),
-          [y11] "v"(yf[1][1]), [y20] "v"(yf[2][0]), [y21] "v"(yf[2][1]), [y30] "v"(yf[3][0]), [y31] "v"(yf[3][1])
-        : "scc");
-  };
+    // dY column sums: accb[half][ms] += yf[wk][ms] x ones.  The tile a wave sums depends on wk; as C++ branches the
+    // accumulators become phi copies around each branch, and hipcc then waits for the matrix pipe to copy them
+    // (s_nop 7 + v_mov, ~200 cycles per phase).  So the four-way choice is ONE asm statement with the accumulators in
+    // place: two independent MFMAs per wave.  s_nop 1 first: `ones` may have been written by a VALU move just before.
+    // Nothing but these MFMAs touches accb until the epilogue, hundreds of instructions after the last one.
+    auto bias_tile = [&](f32x4& a0, f32x4& a1) {
+      asm volatile(
+          "s_nop 1\n\t"
+          "s_cmp_lg_u32 %[wk], 0\n\t"
+          "s_cbranch_scc1 1f\n\t"
+          "v_mfma_f32_16x16x32_bf16 %[a0], %[y00], %[on], %[a0]\n\t"
+          "v_mfma_f32_16x16x32_bf16 %[a1], %[y01], %[on], %[a1]\n\t"
+          "s_branch 4f\n"
+          "1:\n\t"
+          "s_cmp_lg_u32 %[wk], 1\n\t"
+          "s_cbranch_scc1 2f\n\t"
+          "v_mfma_f32_16x16x32_bf16 %[a0], %[y10], %[on], %[a0]\n\t"
+          "v_mfma_f32_16x16x32_bf16 %[a1], %[y11], %[on], %[a1]\n\t"
+          "s_branch 4f\n"
+          "2:\n\t"
+          "s_cmp_lg_u32 %[wk], 2\n\t"
+          "s_cbranch_scc1 3f\n\t"
+          "v_mfma_f32_16x16x32_bf16 %[a0], %[y20], %[on], %[a0]\n\t"
+          "v_mfma_f32_16x16x32_bf16 %[a1], %[y21], %[on], %[a1]\n\t"
+          "s_branch 4f\n"
+          "3:\n\t"
+          "v_mfma_f32_16x16x32_bf16 %[a0], %[y30], %[on], %[a0]\n\t"
+          "v_mfma_f32_16x16x32_bf16 %[a1], %[y31], %[on], %[a1]\n"
+          "4:\n\t"
+          : [a0] "+v"(a0), [a1] "+v"(a1)
+          : [wk] "s"(wk), [on] "v"(ones), [y00] "v"(yf[0][0]), [y01] "v"(yf[0][1]), [y10] "v"(yf[1][0]),
+            [y11] "v"(yf[1][1]), [y20] "v"(yf[2][0]), [y21] "v"(yf[2][1]), [y30] "v"(yf[3][0]), [y31] "v"(yf[3][1])
+          : "scc");
+    };
 
-  // TM 0: steady state; 1: step nkt-2 (only the last half-tile of step nkt-1 left to fetch); 2: last step
-  auto step_body = [&](auto mode_c, int T) {
-    constexpr int TM = decltype(mode_c)::value;
-    const unsigned bo = (T & 1) * BUF_BYTES;
-#ifdef CLIPK_WGRAD_TRACE
-    tr_T = T; tr_i = 0;
-#endif
-    // ---- phase 0: quadrant (k0, n0); fetch X kh0 (8 reads, first) + dY nh0 (16 reads); refill dY nh1 of step T+1
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int ms = 0; ms < 2; ++ms)
-        xf[0][u][ms] = ms ? tr_pair<XH0 + 32 * ROWB>(xa[u] + bo) : tr_pair<XH0>(xa[u] + bo);
-    CLIPK_SB();
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int ms = 0; ms < 2; ++ms)
-        yf[t][ms] = ms ? tr_pair<YH0 + 32 * ROWB>(ya[t] + bo) : tr_pair<YH0>(ya[t] + bo);
-    if (TM <= 1) stage(true, 1, T + 1, YH1);
-    asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");         // >= 9 of 24 reads retired: all of X kh0
-    CLIPK_SB(); CLIPK_BAR();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    CLIPK_SB();
-    __builtin_amdgcn_s_setprio(1);
-    quad<0, 0>(acc, yf, xf);
-    __builtin_amdgcn_s_setprio(0);
-    CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
-    // ---- phase 1: quadrant (k1, n0); fetch X kh1; refill X kh0 of step T+2
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int ms = 0; ms < 2; ++ms)
-        xf[1][u][ms] = ms ? tr_pair<XH1 + 32 * ROWB>(xa[u] + bo) : tr_pair<XH1>(xa[u] + bo);
-    if (TM == 0) stage(false, 0, T + 2, XH0);
-    CLIPK_SB(); CLIPK_BAR();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    CLIPK_SB();
-    __builtin_amdgcn_s_setprio(1);
-    quad<1, 0>(acc, yf, xf);
-    const bool bias_now = has_bias && T == bias_T;              // (workgroup-uniform)
-    if (bias_now) bias_tile(accb[0][0], accb[0][1]);            // n-tiles 0..3 are live: wave wk sums tile wk
-    __builtin_amdgcn_s_setprio(0);
-    CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
-    // ---- phase 2: quadrant (k1, n1); fetch dY nh1; refill dY nh0 of step T+2
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int ms = 0; ms < 2; ++ms)
-        yf[t][ms] = ms ? tr_pair<YH1 + 32 * ROWB>(ya[t] + bo) : tr_pair<YH1>(ya[t] + bo);
-    if (TM == 0) stage(true, 0, T + 2, YH0);
-    CLIPK_SB(); CLIPK_BAR();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    CLIPK_SB();
-    __builtin_amdgcn_s_setprio(1);
-    quad<1, 1>(acc, yf, xf);
-    __builtin_amdgcn_s_setprio(0);
-    CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
-    // ---- phase 3: quadrant (k0, n1); nothing to fetch; refill X kh1 of step T+2; step T+1 must be complete
-    if (TM == 0) {
-      stage(false, 1, T + 2, XH1);
+    // TM 0: steady state; 1: step nkt-2 (only the last half-tile of step nkt-1 left to fetch); 2: last step
+    auto step_body = [&](auto mode_c, int T) {
+      constexpr int TM = decltype(mode_c)::value;
+      const unsigned bo = (T & 1) * BUF_BYTES;
+  #ifdef CLIPK_WGRAD_TRACE
+      tr_T = T; tr_i = 0;
+  #endif
+      // ---- phase 0: quadrant (k0, n0); fetch X kh0 (8 reads, first) + dY nh0 (16 reads); refill dY nh1 of step T+1
+  #pragma unroll
+      for (int u = 0; u < 2; ++u)
+  #pragma unroll
+        for (int ms = 0; ms < 2; ++ms)
+          xf[0][u][ms] = ms ? tr_pair<XH0 + 32 * ROWB>(xa[u] + bo) : tr_pair<XH0>(xa[u] + bo);
+      CLIPK_SB();
+  #pragma unroll
+      for (int t = 0; t < 4; ++t)
+  #pragma unroll
+        for (int ms = 0; ms < 2; ++ms)
+          yf[t][ms] = ms ? tr_pair<YH0 + 32 * ROWB>(ya[t] + bo) : tr_pair<YH0>(ya[t] + bo);
+      if (TM <= 1) stage(true, 1, T + 1, YH1);
+      asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");         // >= 9 of 24 reads retired: all of X kh0
+      CLIPK_SB(); CLIPK_BAR();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      CLIPK_SB();
+      __builtin_amdgcn_s_setprio(1);
+      quad<0, 0>(acc, yf, xf);
+      __builtin_amdgcn_s_setprio(0);
+      CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
+      // ---- phase 1: quadrant (k1, n0); fetch X kh1; refill X kh0 of step T+2
+  #pragma unroll
+      for (int u = 0; u < 2; ++u)
+  #pragma unroll
+        for (int ms = 0; ms < 2; ++ms)
+          xf[1][u][ms] = ms ? tr_pair<XH1 + 32 * ROWB>(xa[u] + bo) : tr_pair<XH1>(xa[u] + bo);
+      if (TM == 0) stage(false, 0, T + 2, XH0);
+      CLIPK_SB(); CLIPK_BAR();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      CLIPK_SB();
+      __builtin_amdgcn_s_setprio(1);
+      quad<1, 0>(acc, yf, xf);
+      const bool bias_now = has_bias && T == bias_T;              // (workgroup-uniform)
+      if (bias_now) bias_tile(accb[0][0], accb[0][1]);            // n-tiles 0..3 are live: wave wk sums tile wk
+      __builtin_amdgcn_s_setprio(0);
+      CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
+      // ---- phase 2: quadrant (k1, n1); fetch dY nh1; refill dY nh0 of step T+2
+  #pragma unroll
+      for (int t = 0; t < 4; ++t)
+  #pragma unroll
+        for (int ms = 0; ms < 2; ++ms)
+          yf[t][ms] = ms ? tr_pair<YH1 + 32 * ROWB>(ya[t] + bo) : tr_pair<YH1>(ya[t] + bo);
+      if (TM == 0) stage(true, 0, T + 2, YH0);
+      CLIPK_SB(); CLIPK_BAR();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      CLIPK_SB();
+      __builtin_amdgcn_s_setprio(1);
+      quad<1, 1>(acc, yf, xf);
+      __builtin_amdgcn_s_setprio(0);
+      CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
+      // ---- phase 3: quadrant (k0, n1); nothing to fetch; refill X kh1 of step T+2; step T+1 must be complete
+      if (TM == 0) {
+        stage(false, 1, T + 2, XH1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else if (TM == 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
+      __builtin_amdgcn_s_setprio(1);
+      quad<0, 1>(acc, yf, xf);
+      if (bias_now) { bias_tile(accb[1][0], accb[1][1]); bias_T += p.ntk; }   // n-tiles 4..7 are live
+      __builtin_amdgcn_s_setprio(0);
+      CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
+    };
+
+    // ---- prologue: step 0 complete, three half-tiles of step 1 in flight
+    stage(false, 0, 0, XH0); stage(true, 0, 0, YH0); stage(false, 1, 0, XH1); stage(true, 1, 0, YH1);
+    if (nkt > 1) {
+      stage(false, 0, 1, XH0); stage(true, 0, 1, YH0); stage(false, 1, 1, XH1);
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else if (TM == 1) {
+    } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
-    __builtin_amdgcn_s_setprio(1);
-    quad<0, 1>(acc, yf, xf);
-    if (bias_now) { bias_tile(accb[1][0], accb[1][1]); bias_T += p.ntk; }   // n-tiles 4..7 are live
-    __builtin_amdgcn_s_setprio(0);
-    CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
-  };
-
-  // ---- prologue: step 0 complete, three half-tiles of step 1 in flight
-  stage(false, 0, 0, XH0); stage(true, 0, 0, YH0); stage(false, 1, 0, XH1); stage(true, 1, 0, YH1);
-  if (nkt > 1) {
-    stage(false, 0, 1, XH0); stage(true, 0, 1, YH0); stage(false, 1, 1, XH1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (wn == 1) CLIPK_BAR();                                     // n = 1 waves run one barrier behind
+  #ifdef CLIPK_WGRAD_TRACE
+    // in-kernel clock (MI355X_MICROARCH.md, DVFS item 6): shader cycles and 100 MHz ticks around the main loop
+    unsigned long long tc0 = 0, tr0 = 0;
+    if (tr_on && wid == 0) { tc0 = __builtin_amdgcn_s_memtime(); tr0 = __builtin_amdgcn_s_memrealtime(); }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+  #endif
+    for (int T = 0; T < nkt - 2; ++T) step_body(std::integral_constant<int, 0>{}, T);
+    if (nkt > 1) step_body(std::integral_constant<int, 1>{}, nkt - 2);
+    step_body(std::integral_constant<int, 2>{}, nkt - 1);
+    if (wn == 0) CLIPK_BAR();                                     // re-align
+  #ifdef CLIPK_WGRAD_TRACE
+    if (tr_on && wid == 0) {
+      g_wgrad_trace[128] = __builtin_amdgcn_s_memtime() - tc0;
+      g_wgrad_trace[129] = __builtin_amdgcn_s_memrealtime() - tr0;
+      g_wgrad_trace[130] = (unsigned long long)nkt;
+    }
+  #endif
   } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  CLIPK_SB(); CLIPK_BAR(); CLIPK_SB();
-  if (wn == 1) CLIPK_BAR();                                     // n = 1 waves run one barrier behind
-#ifdef CLIPK_WGRAD_TRACE
-  // in-kernel clock (MI355X_MICROARCH.md, DVFS item 6): shader cycles and 100 MHz ticks around the main loop
-  unsigned long long tc0 = 0, tr0 = 0;
-  if (tr_on && wid == 0) { tc0 = __builtin_amdgcn_s_memtime(); tr0 = __builtin_amdgcn_s_memrealtime(); }
-  __builtin_amdgcn_s_waitcnt(0xC07F);
+    // ================================================================================================
+    // SCHED 2.  Stamps of the 8-phase loop (tools/exp_wgrad_trace.py) show every MFMA block preceded by the full
+    // latency of the LDS reads issued just before its barrier: 256 cycles of MFMAs per ~450-cycle window, the matrix
+    // pipe 57 % busy - the second wave group only issues DMA in that window, it does not compute.  Here every wave
+    // issues the reads of a LATER block before the MFMAs of the current one, without more registers: a K-step is 8
+    // blocks of 8 MFMAs (k half x n quarter), the dY fragments are two QUARTER buffers of 16 registers (a quarter is
+    // read while the previous one is multiplied), both X halves stay resident, and the block order
+    //     (k0,q0) (k1,q0) (k1,q1) (k0,q1) (k0,q2) (k1,q2) (k0,q3) (k1,q3)
+    // ends on k1 after k0, so X k0 of the next step is read during the last block and X k1 during the next first one.
+    //   block : reads issued before its MFMAs          DMA refill (2 pieces)        barrier
+    //     0   : dY q1, X k1
+    //     2   : dY q2                                  dY nh0 of step T+2           alpha (dY nh0, X of T all read)
+    //     3   :                                        X kh0 of T+2
+    //     4   : dY q3                                  X kh1 of T+2
+    //     6   : dY q0 of T+1                           dY nh1 of T+2                beta (dY nh1 of T all read;
+    //     7   : X k0 of T+1                                                               dY nh0, X of T+1 landed)
+    // Two barriers per step instead of eight; each is preceded by the counted vmcnt that makes the half-tiles read
+    // after it complete (alpha: dY nh1 of T; beta: dY nh0 / X kh0 / X kh1 of T+1): per wave the pieces are issued in the
+    // order [nh0, kh0, kh1 | nh1] per step, so "all but the newest 8" is the right count at both.
+    bf16x8 yq[2][2][2], xf[2][2][2];              // yq[buffer][tile in quarter][m half], xf[k half][u][m half]
+    auto read_yq = [&](auto q_c, unsigned bo) {   // quarter q (tiles 2 (q & 1) + {0, 1} of half q >> 1) -> yq[q & 1]
+      constexpr int q = decltype(q_c)::value;
+      constexpr int REG = (q >> 1) ? YH1 : YH0;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        yq[q & 1][t][0] = tr_pair<REG>(ya[(q & 1) * 2 + t] + bo);
+        yq[q & 1][t][1] = tr_pair<REG + 32 * ROWB>(ya[(q & 1) * 2 + t] + bo);
+      }
+    };
+    auto read_x = [&](auto kh_c, unsigned bo) {
+      constexpr int kh = decltype(kh_c)::value;
+      constexpr int REG = kh ? XH1 : XH0;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        xf[kh][u][0] = tr_pair<REG>(xa[u] + bo);
+        xf[kh][u][1] = tr_pair<REG + 32 * ROWB>(xa[u] + bo);
+      }
+    };
+    auto blk = [&](auto kh_c, auto q_c) {         // 8 MFMAs: 2 n-tiles x 2 k-tiles x 2 m-halves
+      constexpr int kh = decltype(kh_c)::value, q = decltype(q_c)::value;
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            acc[q * 2 + t][kh * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yq[q & 1][t][ms], xf[kh][u][ms],
+                                                                                 acc[q * 2 + t][kh * 2 + u], 0, 0, 0);
+    };
+    // dY column sums: wave wk sums n-tile wk of each half = tile wk & 1 of quarter 2 half + (wk >> 1): waves 0, 1 take
+    // part in quarters 0 and 2, waves 2, 3 in quarters 1 and 3.  One asm statement, accumulators in place (see SCHED 1).
+    const int b_odd = wk >> 1, b_sel = wk & 1;
+    auto bias_mfma = [](int odd, int sel, int qo, f32x4& a0, f32x4& a1, const bf16x8& on, const bf16x8& y00,
+                        const bf16x8& y01, const bf16x8& y10, const bf16x8& y11) {
+      asm volatile(
+          "s_nop 1\n\t"
+          "s_cmp_lg_u32 %[odd], %[qo]\n\t"
+          "s_cbranch_scc1 2f\n\t"
+          "s_cmp_lg_u32 %[sel], 0\n\t"
+          "s_cbranch_scc1 1f\n\t"
+          "v_mfma_f32_16x16x32_bf16 %[a0], %[y00], %[on], %[a0]\n\t"
+          "v_mfma_f32_16x16x32_bf16 %[a1], %[y01], %[on], %[a1]\n\t"
+          "s_branch 2f\n"
+          "1:\n\t"
+          "v_mfma_f32_16x16x32_bf16 %[a0], %[y10], %[on], %[a0]\n\t"
+          "v_mfma_f32_16x16x32_bf16 %[a1], %[y11], %[on], %[a1]\n"
+          "2:\n\t"
+          : [a0] "+v"(a0), [a1] "+v"(a1)
+          : [odd] "s"(odd), [sel] "s"(sel), [qo] "s"(qo), [on] "v"(on), [y00] "v"(y00), [y01] "v"(y01),
+            [y10] "v"(y10), [y11] "v"(y11)
+          : "scc");
+    };
+#define CLIPK_BIAS_Q(q, a0, a1) \
+  bias_mfma(b_odd, b_sel, (q) & 1, a0, a1, ones, yq[(q) & 1][0][0], yq[(q) & 1][0][1], yq[(q) & 1][1][0], yq[(q) & 1][1][1])
+#if defined(CLIPK_WGRAD_TRACE) && defined(CLIPK_WGRAD_ABL)
+    // timing ablations of the experiment build (results are garbage): 1 no LDS-DMA in the loop, 2 no LDS reads in the
+    // loop, 4 no barriers in the loop
+#define CLIPK_ABL_DMA(x) do { if (!(CLIPK_WGRAD_ABL & 1)) { x; } } while (0)
+#define CLIPK_ABL_RD(x) do { if (!(CLIPK_WGRAD_ABL & 2)) { x; } } while (0)
+#define CLIPK_ABL_BAR(x) do { if (!(CLIPK_WGRAD_ABL & 4)) { x; } } while (0)
+#else
+#define CLIPK_ABL_DMA(x) do { x; } while (0)
+#define CLIPK_ABL_RD(x) do { x; } while (0)
+#define CLIPK_ABL_BAR(x) do { x; } while (0)
 #endif
-  for (int T = 0; T < nkt - 2; ++T) step_body(std::integral_constant<int, 0>{}, T);
-  if (nkt > 1) step_body(std::integral_constant<int, 1>{}, nkt - 2);
-  step_body(std::integral_constant<int, 2>{}, nkt - 1);
-  if (wn == 0) CLIPK_BAR();                                     // re-align
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+#define CLIPK_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+    // TM 0: steady state (refills for step T+2); 1: step nkt-2 (nothing left to fetch); 2: last step
+    auto step2 = [&](auto mode_c, int T) {
+      constexpr int TM = decltype(mode_c)::value;
+      const unsigned bo = (T & 1) * BUF_BYTES, bn = ((T + 1) & 1) * BUF_BYTES;
+      const bool bias_now = has_bias && T == bias_T;              // (workgroup-uniform)
 #ifdef CLIPK_WGRAD_TRACE
-  if (tr_on && wid == 0) {
-    g_wgrad_trace[128] = __builtin_amdgcn_s_memtime() - tc0;
-    g_wgrad_trace[129] = __builtin_amdgcn_s_memrealtime() - tr0;
-    g_wgrad_trace[130] = (unsigned long long)nkt;
-  }
+      tr_T = T; tr_i = 0;
 #endif
+      // ---- block 0 (k0, q0): needs dY q0 + X k0 (read during blocks 6 / 7 of the previous step)
+      CLIPK_LGKM0(); CLIPK_SB(); CLIPK_STAMP();
+      CLIPK_ABL_RD(read_yq(I1{}, bo); read_x(I1{}, bo));
+      CLIPK_SB();
+      blk(I0{}, I0{});
+      if (bias_now) CLIPK_BIAS_Q(0, accb[0][0], accb[0][1]);
+      CLIPK_SB();
+      // ---- block 1 (k1, q0)
+      CLIPK_LGKM0(); CLIPK_SB(); CLIPK_STAMP();
+      blk(I1{}, I0{});
+      CLIPK_SB();
+      // ---- block 2 (k1, q1): barrier alpha
+      if (TM == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      CLIPK_SB(); CLIPK_ABL_BAR(CLIPK_BAR2()); CLIPK_SB(); CLIPK_STAMP();
+      CLIPK_ABL_RD(read_yq(I2{}, bo));
+      if (TM == 0) CLIPK_ABL_DMA(stage(true, 0, T + 2, YH0));
+      CLIPK_SB();
+      blk(I1{}, I1{});
+      if (bias_now) CLIPK_BIAS_Q(1, accb[0][0], accb[0][1]);
+      CLIPK_SB();
+      // ---- block 3 (k0, q1)
+      CLIPK_STAMP();
+      if (TM == 0) CLIPK_ABL_DMA(stage(false, 0, T + 2, XH0));
+      CLIPK_SB();
+      blk(I0{}, I1{});
+      CLIPK_SB();
+      // ---- block 4 (k0, q2)
+      CLIPK_LGKM0(); CLIPK_SB(); CLIPK_STAMP();
+      CLIPK_ABL_RD(read_yq(I3{}, bo));
+      if (TM == 0) CLIPK_ABL_DMA(stage(false, 1, T + 2, XH1));
+      CLIPK_SB();
+      blk(I0{}, I2{});
+      if (bias_now) CLIPK_BIAS_Q(2, accb[1][0], accb[1][1]);
+      CLIPK_SB();
+      // ---- block 5 (k1, q2)
+      CLIPK_STAMP();
+      blk(I1{}, I2{});
+      CLIPK_SB();
+      // ---- block 6 (k0, q3): barrier beta
+      CLIPK_LGKM0();
+      if (TM == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (TM == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      CLIPK_SB(); CLIPK_ABL_BAR(CLIPK_BAR2()); CLIPK_SB(); CLIPK_STAMP();
+      if (TM != 2) CLIPK_ABL_RD(read_yq(I0{}, bn));
+      if (TM == 0) CLIPK_ABL_DMA(stage(true, 1, T + 2, YH1));
+      CLIPK_SB();
+      blk(I0{}, I3{});
+      if (bias_now) CLIPK_BIAS_Q(3, accb[1][0], accb[1][1]);
+      CLIPK_SB();
+      // ---- block 7 (k1, q3)
+      CLIPK_STAMP();
+      if (TM != 2) CLIPK_ABL_RD(read_x(I0{}, bn));
+      CLIPK_SB();
+      blk(I1{}, I3{});
+      if (bias_now) bias_T += p.ntk;
+      CLIPK_SB();
+    };
+
+    // ---- prologue: steps 0 and 1 requested in the steady-state piece order, step 0 complete, its first reads issued
+    stage(true, 0, 0, YH0); stage(false, 0, 0, XH0); stage(false, 1, 0, XH1); stage(true, 1, 0, YH1);
+    if (nkt > 1) {
+      stage(true, 0, 1, YH0); stage(false, 0, 1, XH0); stage(false, 1, 1, XH1); stage(true, 1, 1, YH1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    CLIPK_SB(); CLIPK_BAR2(); CLIPK_SB();
+    read_yq(I0{}, 0u); read_x(I0{}, 0u);
+#ifdef CLIPK_WGRAD_TRACE
+    unsigned long long tc0 = 0, tr0 = 0;
+    if (tr_on && wid == 0) { tc0 = __builtin_amdgcn_s_memtime(); tr0 = __builtin_amdgcn_s_memrealtime(); }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+    for (int T = 0; T < nkt - 2; ++T) step2(std::integral_constant<int, 0>{}, T);
+    if (nkt > 1) step2(std::integral_constant<int, 1>{}, nkt - 2);
+    step2(std::integral_constant<int, 2>{}, nkt - 1);
+#ifdef CLIPK_WGRAD_TRACE
+    if (tr_on && wid == 0) {
+      g_wgrad_trace[128] = __builtin_amdgcn_s_memtime() - tc0;
+      g_wgrad_trace[129] = __builtin_amdgcn_s_memrealtime() - tr0;
+      g_wgrad_trace[130] = (unsigned long long)nkt;
+    }
+#endif
+  }
 
   // ---- store the f32 partial tile: rows n (4 per lane), cols k (lane&15)
   float* slab = p.slab + (long)split * N * K;
@@ -359,9 +554,19 @@ extern "C" int clipk_wgrad_v3_set_trace(void* buf) {
 extern "C" int clipk_wgrad_v3_launch(const clipk_wgrad_v3_args* a, void* stream) {
   static std::atomic<uint64_t> attr_set{0};
   clipk_once_per_device(attr_set, [&] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_v3_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_v3_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_v3_kernel<2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   });
-  hipLaunchKernelGGL(wgrad_v3_kernel, dim3(a->ntn * a->ntk * a->splits), dim3(512), LDS_BYTES, (hipStream_t)stream, *a);
+  const dim3 grid(a->ntn * a->ntk * a->splits);
+  // option wgrad_kernel = 4: the software-pipelined schedule; 3 (and auto): the 8-phase one, which is 4 % faster -
+  // the stamps / ablations of tools/exp_wgrad_trace.py show both bounded by the 64 LDS-DMA pieces per step (64 KiB
+  // through the CU's 64 B/clk vector-memory path: 1250 of ~3700 cycles that the issuing waves cannot hide), not by
+  // LDS-read latency, which schedule 2 removes
+  if (clipk_opt_get(OPT_WGRAD_KERNEL) == 4)
+    hipLaunchKernelGGL(wgrad_v3_kernel<2>, grid, dim3(512), LDS_BYTES, (hipStream_t)stream, *a);
+  else
+    hipLaunchKernelGGL(wgrad_v3_kernel<1>, grid, dim3(512), LDS_BYTES, (hipStream_t)stream, *a);
   return clipk_check_launch();
 }

@@ -133,13 +133,15 @@ def test_gemm_nt_specialised_epilogues(dev, kopt, kernel, M, N, K):
     assert torch.allclose(big[:M, :N].float(), ref + bias, **tol)
 
 
-@pytest.mark.parametrize("kernel", ["v2", "v3"])
+@pytest.mark.parametrize("kernel", ["v2", "v3", "v3p"])
 @pytest.mark.parametrize("M,N,K", [(512, 128, 128), (4096, 1440, 480), (1000, 360, 120), (8192, 480, 1920),
-                                   (300, 8, 16), (16384, 768, 768), (20000, 1440, 480), (1100, 264, 520)])
+                                   (300, 8, 16), (16384, 768, 768), (20000, 1440, 480), (1100, 264, 520),
+                                   (1024, 2048, 768), (66000, 480, 480)])
 def test_gemm_wgrad(dev, kopt, kernel, M, N, K):
-    """128x128 kernel and the 256x256 phase-interleaved kernel (option wgrad_kernel = 3 takes every M >= 1024): ragged
-    N / K edges, a ragged last 64-row step (M = 20000, 1100), one- and two-step splits."""
-    kopt("wgrad_kernel", 3 if kernel == "v3" else 2)
+    """128x128 kernel and the 256x256 kernel in both of its schedules (option wgrad_kernel = 3: 8-phase, 4: software
+    pipelined; both take every M >= 1024): ragged N / K edges, a ragged last 64-row step (M = 20000, 1100, 66000), one-,
+    two- and three-step splits, bias turns over 1 / 2 / 3 k-tile workgroups."""
+    kopt("wgrad_kernel", {"v2": 2, "v3": 3, "v3p": 4}[kernel])
     ops = _ops()
     dy = _rand((M, N), dev, 8, 0.1, dtype=torch.bfloat16)
     x = _rand((M, K), dev, 9, dtype=torch.bfloat16)

@@ -8,7 +8,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tools")]
 import bench_kernels as bk  # noqa: E402
 from clip_dplm_amd import ops  # noqa: E402
 
-ops.set_option("wgrad_kernel", 3)
+ops.set_option("wgrad_kernel", int(os.environ.get("WGRAD_KERNEL", "3")))
 for name, N, K in (("esm out", 480, 480), ("esm fc1", 1920, 480), ("rna fc1", 2048, 768)):
     for M in (32768, 65536, 131072, 262144):
         dy, x = bk.rnd((M, N), scale=0.1), bk.rnd((M, K))

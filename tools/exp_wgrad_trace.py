@@ -13,7 +13,7 @@ import sys
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.path.join(ROOT, "tools", "probes", "libwgrad_trace.so"))
+lib = C.CDLL(os.path.join(ROOT, "tools", "probes", os.environ.get("TRACE_LIB", "libwgrad_trace.so")))
 
 
 class Args(C.Structure):
@@ -23,6 +23,8 @@ class Args(C.Structure):
 
 
 N, K, M = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (1920, 480, 262144)
+SCHED = int(sys.argv[4]) if len(sys.argv) > 4 else 3          # 3: 8-phase schedule (stamps after its 8 barriers per
+lib.clipk_set_option(b"wgrad_kernel", SCHED)                  # step), 4: software-pipelined (stamps at its 8 blocks)
 dev = torch.device("cuda:0")
 dy = (torch.randn(M, N, device=dev) * 0.1).to(torch.bfloat16)
 x = torch.randn(M, K, device=dev).to(torch.bfloat16)
@@ -40,7 +42,7 @@ for _ in range(int(os.environ.get('TRACE_LAUNCHES', '3000'))):   # >= 2 s back t
     assert lib.clipk_wgrad_v3_launch(C.byref(a), None) == 0
 torch.cuda.synchronize()
 t = trace.cpu().tolist()
-print(f"N={N} K={K} M={M}: tiles {ntn.value}x{ntk.value}, {splits.value} splits of {mps.value} rows "
+print(f"schedule {SCHED}, N={N} K={K} M={M}: tiles {ntn.value}x{ntk.value}, {splits.value} splits of {mps.value} rows "
       f"({mps.value // 64} steps); ideal MFMA block = 16 x 16 = 256 cycles, 8 blocks per step = 2048")
 cyc, ticks, nkt = t[128], t[129], t[130]
 print(f"main loop of workgroup 0: {cyc} shader cycles in {ticks} ticks of 100 MHz = {cyc / ticks * 0.1:.3f} GHz in-kernel "
