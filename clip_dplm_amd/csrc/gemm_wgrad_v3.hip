@@ -153,6 +153,17 @@ __global__ __launch_bounds__(512, 1) void wgrad_v3_kernel(const clipk_wgrad_v3_a
       __builtin_amdgcn_raw_ptr_buffer_load_lds(d, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16,
                                                (int)(is_y ? yv[i] : xv[i]), 0, 0, 0);
   };
+  // one of the wave's two pieces of a half-tile (the software-pipelined schedule spreads them: one per MFMA block)
+  auto stage1 = [&](bool is_y, int half, int T, int region, int i) {
+    const long mt = (long)m_beg + (long)T * BMS;
+    const unsigned short* base = is_y ? p.dY + mt * p.lddy + (n0 + half * 64) : p.X + mt * p.ldx + (k0 + half * 32);
+    const long left = ((is_y ? y_end : x_end) - base) * 2;
+    const int bytes = left > 0 ? (int)(left < 0x7fffffffL ? left : 0x7fffffffL) : 0;
+    const auto d = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+    char* dst = smem + (T & 1) * BUF_BYTES + region + wid * 2048 + i * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(d, (__attribute__((address_space(3))) void*)dst, 16,
+                                             (int)(is_y ? (i ? yv[1] : yv[0]) : (i ? xv[1] : xv[0])), 0, 0, 0);
+  };
 
   f32x4 acc[8][4];          // [n-tile i][k-tile j]: rows n = 4g+r, col k = lane&15
 #pragma unroll
@@ -328,16 +339,14 @@ __global__ __launch_bounds__(512, 1) void wgrad_v3_kernel(const clipk_wgrad_v3_a
     // read while the previous one is multiplied), both X halves stay resident, and the block order
     //     (k0,q0) (k1,q0) (k1,q1) (k0,q1) (k0,q2) (k1,q2) (k0,q3) (k1,q3)
     // ends on k1 after k0, so X k0 of the next step is read during the last block and X k1 during the next first one.
-    //   block : reads issued before its MFMAs          DMA refill (2 pieces)        barrier
+    //   block : reads issued before its MFMAs          barrier
     //     0   : dY q1, X k1
-    //     2   : dY q2                                  dY nh0 of step T+2           alpha (dY nh0, X of T all read)
-    //     3   :                                        X kh0 of T+2
-    //     4   : dY q3                                  X kh1 of T+2
-    //     6   : dY q0 of T+1                           dY nh1 of T+2                beta (dY nh1 of T all read;
-    //     7   : X k0 of T+1                                                               dY nh0, X of T+1 landed)
+    //     2   : dY q2                                  alpha (dY nh0 and X of step T all read)
+    //     4   : dY q3
+    //     6   : dY q0 of T+1                           beta (dY nh1 of T all read; dY nh0, X of T+1 landed)
+    //     7   : X k0 of T+1
     // Two barriers per step instead of eight; each is preceded by the counted vmcnt that makes the half-tiles read
-    // after it complete (alpha: dY nh1 of T; beta: dY nh0 / X kh0 / X kh1 of T+1): per wave the pieces are issued in the
-    // order [nh0, kh0, kh1 | nh1] per step, so "all but the newest 8" is the right count at both.
+    // after it complete (alpha: dY nh1 of T; beta: dY nh0 / X kh0 / X kh1 of T+1).  The LDS-DMA pieces: see step2.
     bf16x8 yq[2][2][2], xf[2][2][2];              // yq[buffer][tile in quarter][m half], xf[k half][u][m half]
     auto read_yq = [&](auto q_c, unsigned bo) {   // quarter q (tiles 2 (q & 1) + {0, 1} of half q >> 1) -> yq[q & 1]
       constexpr int q = decltype(q_c)::value;
@@ -357,16 +366,18 @@ __global__ __launch_bounds__(512, 1) void wgrad_v3_kernel(const clipk_wgrad_v3_a
         xf[kh][u][1] = tr_pair<REG + 32 * ROWB>(xa[u] + bo);
       }
     };
-    auto blk = [&](auto kh_c, auto q_c) {         // 8 MFMAs: 2 n-tiles x 2 k-tiles x 2 m-halves
+    auto blk = [&](auto kh_c, auto q_c, auto&& mid) {   // 8 MFMAs: 2 n-tiles x 2 k-tiles x 2 m-halves; `mid` between the halves
       constexpr int kh = decltype(kh_c)::value, q = decltype(q_c)::value;
 #pragma unroll
-      for (int ms = 0; ms < 2; ++ms)
+      for (int ms = 0; ms < 2; ++ms) {
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
           for (int t = 0; t < 2; ++t)
             acc[q * 2 + t][kh * 2 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yq[q & 1][t][ms], xf[kh][u][ms],
                                                                                  acc[q * 2 + t][kh * 2 + u], 0, 0, 0);
+        if (ms == 0) { CLIPK_SB(); mid(); CLIPK_SB(); }
+      }
     };
     // dY column sums: wave wk sums n-tile wk of each half = tile wk & 1 of quarter 2 half + (wk >> 1): waves 0, 1 take
     // part in quarters 0 and 2, waves 2, 3 in quarters 1 and 3.  One asm statement, accumulators in place (see SCHED 1).
@@ -408,11 +419,18 @@ __global__ __launch_bounds__(512, 1) void wgrad_v3_kernel(const clipk_wgrad_v3_a
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
 #define CLIPK_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-    // TM 0: steady state (refills for step T+2); 1: step nkt-2 (nothing left to fetch); 2: last step
+    // TM 0: steady state (refills for step T+2); 1: step nkt-2 (only dY nh1 of the last step left); 2: last step.
+    // LDS-DMA: ONE piece per block, between the block's two MFMA halves (a burst of pieces from all eight waves queues
+    // up in the CU's vector-memory path and every issuing wave waits for it): per wave and step, in issue order,
+    //     blocks 0, 1: dY nh1 of T+1 (slot free since beta of T-1) | blocks 2..5: dY nh0, X kh0 of T+2 (free since alpha)
+    //     blocks 6, 7: X kh1 of T+2
+    // so before beta "all but the newest 6" covers dY nh0 / X of T+1, before alpha "all but the newest 8" dY nh1 of T.
     auto step2 = [&](auto mode_c, int T) {
       constexpr int TM = decltype(mode_c)::value;
       const unsigned bo = (T & 1) * BUF_BYTES, bn = ((T + 1) & 1) * BUF_BYTES;
       const bool bias_now = has_bias && T == bias_T;              // (workgroup-uniform)
+      const bool y1_next = TM != 2 && T >= 1;                     // (step 1's dY nh1 comes with the prologue)
+      auto none = [] {};
 #ifdef CLIPK_WGRAD_TRACE
       tr_T = T; tr_i = 0;
 #endif
@@ -420,59 +438,55 @@ __global__ __launch_bounds__(512, 1) void wgrad_v3_kernel(const clipk_wgrad_v3_a
       CLIPK_LGKM0(); CLIPK_SB(); CLIPK_STAMP();
       CLIPK_ABL_RD(read_yq(I1{}, bo); read_x(I1{}, bo));
       CLIPK_SB();
-      blk(I0{}, I0{});
+      blk(I0{}, I0{}, [&] { if (y1_next) CLIPK_ABL_DMA(stage1(true, 1, T + 1, YH1, 0)); });
       if (bias_now) CLIPK_BIAS_Q(0, accb[0][0], accb[0][1]);
       CLIPK_SB();
       // ---- block 1 (k1, q0)
       CLIPK_LGKM0(); CLIPK_SB(); CLIPK_STAMP();
-      blk(I1{}, I0{});
+      blk(I1{}, I0{}, [&] { if (y1_next) CLIPK_ABL_DMA(stage1(true, 1, T + 1, YH1, 1)); });
       CLIPK_SB();
       // ---- block 2 (k1, q1): barrier alpha
       if (TM == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       CLIPK_SB(); CLIPK_ABL_BAR(CLIPK_BAR2()); CLIPK_SB(); CLIPK_STAMP();
       CLIPK_ABL_RD(read_yq(I2{}, bo));
-      if (TM == 0) CLIPK_ABL_DMA(stage(true, 0, T + 2, YH0));
       CLIPK_SB();
-      blk(I1{}, I1{});
+      blk(I1{}, I1{}, [&] { if (TM == 0) CLIPK_ABL_DMA(stage1(true, 0, T + 2, YH0, 0)); });
       if (bias_now) CLIPK_BIAS_Q(1, accb[0][0], accb[0][1]);
       CLIPK_SB();
       // ---- block 3 (k0, q1)
       CLIPK_STAMP();
-      if (TM == 0) CLIPK_ABL_DMA(stage(false, 0, T + 2, XH0));
-      CLIPK_SB();
-      blk(I0{}, I1{});
+      blk(I0{}, I1{}, [&] { if (TM == 0) CLIPK_ABL_DMA(stage1(true, 0, T + 2, YH0, 1)); });
       CLIPK_SB();
       // ---- block 4 (k0, q2)
       CLIPK_LGKM0(); CLIPK_SB(); CLIPK_STAMP();
       CLIPK_ABL_RD(read_yq(I3{}, bo));
-      if (TM == 0) CLIPK_ABL_DMA(stage(false, 1, T + 2, XH1));
       CLIPK_SB();
-      blk(I0{}, I2{});
+      blk(I0{}, I2{}, [&] { if (TM == 0) CLIPK_ABL_DMA(stage1(false, 0, T + 2, XH0, 0)); });
       if (bias_now) CLIPK_BIAS_Q(2, accb[1][0], accb[1][1]);
       CLIPK_SB();
       // ---- block 5 (k1, q2)
       CLIPK_STAMP();
-      blk(I1{}, I2{});
+      blk(I1{}, I2{}, [&] { if (TM == 0) CLIPK_ABL_DMA(stage1(false, 0, T + 2, XH0, 1)); });
       CLIPK_SB();
       // ---- block 6 (k0, q3): barrier beta
       CLIPK_LGKM0();
-      if (TM == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      if (TM == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else if (TM == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       CLIPK_SB(); CLIPK_ABL_BAR(CLIPK_BAR2()); CLIPK_SB(); CLIPK_STAMP();
       if (TM != 2) CLIPK_ABL_RD(read_yq(I0{}, bn));
-      if (TM == 0) CLIPK_ABL_DMA(stage(true, 1, T + 2, YH1));
       CLIPK_SB();
-      blk(I0{}, I3{});
+      blk(I0{}, I3{}, [&] { if (TM == 0) CLIPK_ABL_DMA(stage1(false, 1, T + 2, XH1, 0)); });
       if (bias_now) CLIPK_BIAS_Q(3, accb[1][0], accb[1][1]);
       CLIPK_SB();
       // ---- block 7 (k1, q3)
       CLIPK_STAMP();
       if (TM != 2) CLIPK_ABL_RD(read_x(I0{}, bn));
       CLIPK_SB();
-      blk(I1{}, I3{});
+      blk(I1{}, I3{}, [&] { if (TM == 0) CLIPK_ABL_DMA(stage1(false, 1, T + 2, XH1, 1)); });
       if (bias_now) bias_T += p.ntk;
       CLIPK_SB();
+      (void)none;
     };
 
     // ---- prologue: steps 0 and 1 requested in the steady-state piece order, step 0 complete, its first reads issued
@@ -560,13 +574,12 @@ extern "C" int clipk_wgrad_v3_launch(const clipk_wgrad_v3_args* a, void* stream)
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   });
   const dim3 grid(a->ntn * a->ntk * a->splits);
-  // option wgrad_kernel = 4: the software-pipelined schedule; 3 (and auto): the 8-phase one, which is 4 % faster -
-  // the stamps / ablations of tools/exp_wgrad_trace.py show both bounded by the 64 LDS-DMA pieces per step (64 KiB
-  // through the CU's 64 B/clk vector-memory path: 1250 of ~3700 cycles that the issuing waves cannot hide), not by
-  // LDS-read latency, which schedule 2 removes
-  if (clipk_opt_get(OPT_WGRAD_KERNEL) == 4)
-    hipLaunchKernelGGL(wgrad_v3_kernel<2>, grid, dim3(512), LDS_BYTES, (hipStream_t)stream, *a);
-  else
+  // option wgrad_kernel = 3: the 8-phase schedule; 4 (and auto): the software-pipelined one.  In cycles the second is
+  // 8 % ahead (3326 vs 3602 per step, matrix pipe 0.62 vs 0.57 busy), in wall time 1-2 %: the chip answers the
+  // denser MFMA stream with a lower clock (1.82 vs 1.95 GHz in-kernel)
+  if (clipk_opt_get(OPT_WGRAD_KERNEL) == 3)
     hipLaunchKernelGGL(wgrad_v3_kernel<1>, grid, dim3(512), LDS_BYTES, (hipStream_t)stream, *a);
+  else
+    hipLaunchKernelGGL(wgrad_v3_kernel<2>, grid, dim3(512), LDS_BYTES, (hipStream_t)stream, *a);
   return clipk_check_launch();
 }
