@@ -100,6 +100,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 3          # CLIPK_ABI_VERSION of the library these signatures / the GemmArgs layout were written for
 
 
 def load() -> C.CDLL:
@@ -112,6 +113,10 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found: the HIP extension is mandatory (there is no CPU fallback). "
             "Build it with `make` or `python -c 'import __graft_entry__ as g; g.build()'`.")
     lib = C.CDLL(LIB_PATH)
+    lib.clipk_version.restype = C.c_int
+    got = lib.clipk_version()
+    if got != ABI_VERSION:               # a stale in-tree build: argument structs would be misread
+        raise ClipkError(f"{LIB_PATH} has ABI version {got}, this binding expects {ABI_VERSION}: rebuild it (`make`)")
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
         fn.restype = res

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/clipk.h but not exported"
         assert n in _ffi.SIGNATURES, f"{n} has no ctypes signature"
     assert lib.clipk_arch() == b"gfx950"
-    assert lib.clipk_version() >= 1
+    assert lib.clipk_version() == _ffi.ABI_VERSION
     assert b"unsupported" in lib.clipk_status_string(-2)
 
 
