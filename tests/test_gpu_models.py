@@ -221,6 +221,8 @@ def test_protein_rna_clip_vs_oracle(dev):
     er = clip_ref.l2_normalize(clip_ref.projection_head(encoder_ref.pool(hr, rmask.bool(), "mean"), sd, "rna_projection"))
     ep = clip_ref.l2_normalize(clip_ref.projection_head(encoder_ref.pool(hp, pmask.bool(), "mean"), sd, "protein_projection"))
     ref = clip_ref.clip_loss_symmetric((er @ ep.t()) * sd["logit_scale"].exp())
+    print(f"protein_rna_clip (96-wide toy): loss_gpu={loss.item():.6f} loss_oracle={ref.item():.6f} "
+          f"|diff|={abs(loss.item() - ref.item()):.2e}")
     assert abs(loss.item() - ref.item()) < 1e-3, (loss.item(), ref.item())
     loss.backward()
     gn = sum((p.grad.float() ** 2).sum() for p in m.parameters() if p.grad is not None).sqrt().item()
