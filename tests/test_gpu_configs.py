@@ -130,11 +130,12 @@ def test_c2_full_size_properties_at_the_metric_batch(dev):
 
 
 # ----------------------------------------------------------------------------------------------------- config 3
-@pytest.mark.parametrize("rank", [0, 3, 7])
-def test_c3_simce_rank_block_vs_f64(dev, rank):
-    """One rank's share of the B_g = 4096 InfoNCE: 512 local rows against 4096 gathered keys, P = 512."""
+@pytest.mark.parametrize("rank,Bl", [(0, 512), (3, 512), (7, 512), (5, 1024)])
+def test_c3_simce_rank_block_vs_f64(dev, rank, Bl):
+    """One rank's share of the global-batch InfoNCE: B_l local rows against the 8 * B_l gathered keys, P = 512: config
+    3 (512 x 4096) and the shape of bench.py --gpus 8 at the metric batch (1024 x 8192)."""
     from clip_dplm_amd import ops
-    Bl, W, P, scale = 512, 8, 512, 14.2849
+    W, P, scale = 8, 512, 14.2849
     Bg = Bl * W
     g = torch.Generator().manual_seed(31)
     a = F.normalize(torch.randn(Bg, P, generator=g), dim=-1).to(dev)
