@@ -498,7 +498,7 @@ def _post_layer_fwd(x, xb, p, meta, dr=None):
     return y, yb, (xb, qkv, ctx, lse, s1, x1b, m1, r1, g, u, s2, m2, r2)
 
 
-def _post_layer_bwd(dy, p, saved, meta, dr=None):
+def _post_layer_bwd(dy, p, saved, meta, dr=None, need_dx=True):
     B, L, H, D, mask, act, eps, qs, seq = meta
     da, d1, df, d2 = (None,) * 4 if dr is None else tuple((dr[0], sd) for sd in dr[1:])
     xb, qkv, ctx, lse, s1, x1b, m1, r1, g, u, s2, m2, r2 = saved
@@ -525,7 +525,9 @@ def _post_layer_bwd(dy, p, saved, meta, dr=None):
         dqkv = ops.attn_varlen_bwd(qkv, ctx, dctx, lse, seq[0], seq[1], H, D, rope=None, q_scale=qs, dropout=da)
     else:
         dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, H, D, key_mask=mask, rope=None, q_scale=qs, dropout=da)
-    if lowp:
+    if not need_dx:                                   # first layer of a stack fed with features that need no gradient
+        dx = None                                     # (the RNA tower of ProteinRNACLIP): its input dgrad is never used
+    elif lowp:
         dx = ops.gemm_nt(dqkv, p["in"].wtb, residual=ds1b)
     else:
         dx = ops.gemm_nt(dqkv, p["in"].wtb, residual=ds1, out_dtype=torch.float32)
@@ -577,14 +579,15 @@ class PostLNStackFn(torch.autograd.Function):
         for i in reversed(range(nl)):
             drop = ctx.drop
             dx, gr = _post_layer_bwd(dx, ctx.layers[i], ctx.saved[i], meta,
-                                     None if drop is None else (drop[0],) + tuple(drop[1][i]))
+                                     None if drop is None else (drop[0],) + tuple(drop[1][i]),
+                                     need_dx=i > 0 or ctx.needs_input_grad[1])
             ctx.saved[i] = None
             for j, k in enumerate(_POST_KEYS):
                 grads[2 + 12 * i + j] = gr[k]
         ctx.layers = ctx.saved = None
         _join_side(*grads)
         _bucket_done(module, grads)
-        if ctx.needs_input_grad[1] and dx.dtype != torch.float32:
+        if ctx.needs_input_grad[1] and dx is not None and dx.dtype != torch.float32:
             dx = ops.to_f32(dx.contiguous())
         return (None, dx if ctx.needs_input_grad[1] else None, None, None, None, None, None, *grads)
 
