@@ -89,6 +89,86 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwd p) {
   }
 }
 
+// LayerNorm + masked mean over the L rows of each sample in one pass (the encoders' final LayerNorm followed by the
+// pooling of configuration_hybrid_clip.py:109 use_mean_pooling / tf_clip_codes (1).ipynb:1188): the normalised rows
+// are never written (2 x rows x cols x 4 B less per tower and step: one write here, one read by the pooling kernel).
+// One workgroup per sample; wave w takes rows w, w + 4, ...; the four partial sums are combined in wave order, so a
+// sample's pooled row does not depend on where it sits in the batch.  mean / rstd per row are kept for the backward.
+struct LnPool {
+  const void* x; long ldx;        // f32 or bf16 (XBF16)
+  const float* gamma; const float* beta; float eps;
+  const unsigned char* mask;      // [B * L], 1 = valid, or null
+  float* pooled; float* mean; float* rstd; float* inv_len;
+  int L, cols;
+};
+
+template <int VPL, bool XBF16>
+__global__ __launch_bounds__(256) void ln_pool_fwd_kernel(const LnPool p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sm = reinterpret_cast<float*>(smem);                    // [4][cols] partial sums, then [4] counts
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int b = blockIdx.x;
+  const int nch = p.cols >> 2;
+  f32x4 g[VPL], be[VPL], acc[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    const int c = lane + 64 * v;
+    g[v] = f32x4{0.f, 0.f, 0.f, 0.f}; be[v] = g[v]; acc[v] = g[v];
+    if (c < nch) {
+      g[v] = *reinterpret_cast<const f32x4*>(p.gamma + 4 * c);
+      be[v] = *reinterpret_cast<const f32x4*>(p.beta + 4 * c);
+    }
+  }
+  const float inv_n = 1.0f / (float)p.cols;
+  int cnt = 0;
+  for (int l = wid; l < p.L; l += 4) {
+    const long row = (long)b * p.L + l;
+    f32x4 x[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int c = lane + 64 * v;
+      x[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < nch) x[v] = load4<XBF16>(p.x, row * p.ldx + 4 * c);
+      s += (x[v][0] + x[v][1]) + (x[v][2] + x[v][3]);
+    }
+    const float mean = wave_sum(s) * inv_n;                      // same statistics arithmetic as ln_fwd_kernel
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int c = lane + 64 * v;
+      if (c < nch) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = x[v][e] - mean; q += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) * inv_n + p.eps);
+    if (lane == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
+    const bool ok = !p.mask || p.mask[row];                      // wave-uniform
+    if (ok) {
+      ++cnt;
+#pragma unroll
+      for (int v = 0; v < VPL; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[v][e] += (x[v][e] - mean) * rstd * g[v][e] + be[v][e];
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    const int c = lane + 64 * v;
+    if (c < nch) *reinterpret_cast<f32x4*>(sm + wid * p.cols + 4 * c) = acc[v];
+  }
+  if (lane == 0) sm[4 * p.cols + wid] = (float)cnt;
+  __syncthreads();
+  const float n = (sm[4 * p.cols] + sm[4 * p.cols + 1]) + (sm[4 * p.cols + 2] + sm[4 * p.cols + 3]);
+  const float inv = n > 0.f ? 1.0f / n : 0.f;
+  if (threadIdx.x == 0) p.inv_len[b] = inv;
+  for (int i = threadIdx.x; i < p.cols; i += blockDim.x) {
+    const float a = ((sm[i] + sm[p.cols + i]) + sm[2 * p.cols + i]) + sm[3 * p.cols + i];
+    p.pooled[(long)b * p.cols + i] = a * inv;
+  }
+}
+
 struct LnBwd {
   const void* dy; long lddy;
   const void* x; long ldx;
@@ -100,9 +180,12 @@ struct LnBwd {
   // d(residual sum)), the f32 output stays the residual-path gradient.  Index = row * cols + col.  thr 0 = off.
   unsigned drop_thr, drop_seed; float drop_scale;
   int add_bf16;     // dx_add holds bf16 instead of f32
+  // POOL instantiation (LayerNorm followed by a masked mean over the L rows of each sample): dy is the gradient of the
+  // POOLED row, f32 [rows / pool_L][cols]; row r receives dy[r / pool_L] * (valid(r) ? inv_len[r / pool_L] : 0)
+  const float* inv_len; const unsigned char* pool_mask; int pool_L;
 };
 
-template <int VPL, bool DYBF16, bool XBF16, bool ADD16 = false>
+template <int VPL, bool DYBF16, bool XBF16, bool ADD16 = false, bool POOL = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -124,6 +207,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
     const float mean = p.mean[row], rstd = p.rstd[row];
     f32x4 xh[VPL], gy[VPL], addv[VPL];
     float s1 = 0.f, s2 = 0.f;
+    long dyrow = row;
+    float pw = 1.f;
+    if constexpr (POOL) {
+      dyrow = row / p.pool_L;
+      pw = (!p.pool_mask || p.pool_mask[row]) ? p.inv_len[dyrow] : 0.f;
+    }
     // the residual-path gradient is only needed after the row reductions: issue its load with the others, so the
     // row costs one memory round trip instead of two
 #pragma unroll
@@ -138,7 +227,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
       xh[v] = f32x4{0.f, 0.f, 0.f, 0.f}; gy[v] = xh[v];
       if (c < nch) {
         const f32x4 xv = load4<XBF16>(p.x, (long)row * p.ldx + 4 * c);
-        f32x4 dyv = load4<DYBF16>(p.dy, (long)row * p.lddy + 4 * c);
+        f32x4 dyv = load4<DYBF16>(p.dy, dyrow * p.lddy + 4 * c);
+        if constexpr (POOL) dyv = dyv * pw;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float xhat = (xv[e] - mean) * rstd;
@@ -300,12 +390,12 @@ int ln_blocks_cap(int rows, int cap) {
 int ln_blocks(int rows, int cols) { return ln_blocks_cap(rows, cols <= 512 ? 1024 : (cols <= 1024 ? 768 : 512)); }
 int ln_blocks_fwd(int rows) { return ln_blocks_cap(rows, 2048); }
 
-template <int VPL, bool DYBF16, bool XBF16, bool ADD16 = false>
+template <int VPL, bool DYBF16, bool XBF16, bool ADD16 = false, bool POOL = false>
 void launch_ln_bwd(const LnBwd& p, int blocks, size_t lds, hipStream_t st) {
   if (lds > 65536)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_kernel<VPL, DYBF16, XBF16, ADD16>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_kernel<VPL, DYBF16, XBF16, ADD16, POOL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((ln_bwd_kernel<VPL, DYBF16, XBF16, ADD16>), dim3(blocks), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((ln_bwd_kernel<VPL, DYBF16, XBF16, ADD16, POOL>), dim3(blocks), dim3(256), lds, st, p);
 }
 
 }  // namespace
@@ -354,7 +444,8 @@ extern "C" int clipk_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, c
   const int blocks = ln_blocks(rows, cols);
   if (workspace_bytes < (size_t)blocks * 2 * cols * sizeof(float)) return CLIPK_ERR_BAD_ARG;
   LnBwd p{dy, (long)lddy, x, (long)ldx, gamma, beta, mean, rstd, act, dx_add, dx_f32, dx_bf16, (long)lddx,
-          (float*)workspace, rows, cols, 0u, drop_seed, 1.0f, (dx_add && dx_add_dtype == CLIPK_BF16) ? 1 : 0};
+          (float*)workspace, rows, cols, 0u, drop_seed, 1.0f, (dx_add && dx_add_dtype == CLIPK_BF16) ? 1 : 0,
+          nullptr, nullptr, 1};
   if (drop_p > 0.f && drop_p < 1.f) {
     const double t = (double)drop_p * 4294967296.0;
     p.drop_thr = t < 1.0 ? 1u : (t >= 4294967295.0 ? 4294967295u : (unsigned)t);
@@ -374,6 +465,61 @@ extern "C" int clipk_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, c
       launch_ln_bwd<V, false, true>(p, blocks, lds, st);                                                          \
     else                                                                                                          \
       launch_ln_bwd<V, false, false>(p, blocks, lds, st);                                                         \
+  } while (0)
+  LN_DISPATCH_VPL(cols, CALL);
+#undef CALL
+  int rc = clipk_check_launch();
+  if (rc) return rc;
+  if (dgamma || dbeta) {
+    hipLaunchKernelGGL(colreduce_kernel, dim3((2 * cols + 15) / 16), dim3(256), 0, st, (const float*)workspace,
+                       blocks, 2 * cols, dgamma, dbeta, cols, accumulate);
+    rc = clipk_check_launch();
+  }
+  return rc;
+}
+
+extern "C" int clipk_layernorm_meanpool_fwd(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta, float eps,
+                                           const uint8_t* mask, int B, int L, int cols, float* pooled, float* mean,
+                                           float* rstd, float* inv_len, void* stream) {
+  if (!x || !gamma || !beta || !pooled || !mean || !rstd || !inv_len || B <= 0 || L <= 0 || cols <= 0) return CLIPK_ERR_BAD_ARG;
+  if ((cols & 3) || (ldx & 3)) return CLIPK_ERR_UNSUPPORTED;
+  if (!aligned16(x) || !aligned16(gamma) || !aligned16(beta)) return CLIPK_ERR_BAD_ARG;
+  LnPool p{x, (long)ldx, gamma, beta, eps, mask, pooled, mean, rstd, inv_len, L, cols};
+  const size_t lds = ((size_t)4 * cols + 4) * sizeof(float);
+  if (lds > 65536) return CLIPK_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+#define CALL(V)                                                                                          \
+  do {                                                                                                   \
+    if (x_dtype == CLIPK_BF16) hipLaunchKernelGGL((ln_pool_fwd_kernel<V, true>), dim3(B), dim3(256), lds, st, p);  \
+    else hipLaunchKernelGGL((ln_pool_fwd_kernel<V, false>), dim3(B), dim3(256), lds, st, p);             \
+  } while (0)
+  LN_DISPATCH_VPL(cols, CALL);
+#undef CALL
+  return clipk_check_launch();
+}
+
+extern "C" int clipk_layernorm_meanpool_bwd(const float* dpooled, const float* inv_len, const uint8_t* mask, int B, int L,
+                                           const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* mean,
+                                           const float* rstd, float* dx_f32, void* dx_bf16, int64_t lddx, float* dgamma,
+                                           float* dbeta, int accumulate, int cols, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+  if (!dpooled || !inv_len || !x || !gamma || !mean || !rstd || B <= 0 || L <= 0 || cols <= 0 || !workspace)
+    return CLIPK_ERR_BAD_ARG;
+  if (!dx_f32 && !dx_bf16) return CLIPK_ERR_BAD_ARG;
+  if ((cols & 3) || (ldx & 3) || (lddx & 3)) return CLIPK_ERR_UNSUPPORTED;
+  const long rows_l = (long)B * L;
+  if (rows_l > 0x7fffffffL) return CLIPK_ERR_UNSUPPORTED;
+  const int rows = (int)rows_l;
+  const int blocks = ln_blocks(rows, cols);
+  if (workspace_bytes < (size_t)blocks * 2 * cols * sizeof(float)) return CLIPK_ERR_BAD_ARG;
+  LnBwd p{dpooled, (long)cols, x, (long)ldx, gamma, nullptr, mean, rstd, CLIPK_ACT_NONE, nullptr, dx_f32, dx_bf16,
+          (long)lddx, (float*)workspace, rows, cols, 0u, 0u, 1.0f, 0, inv_len, mask, L};
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)4 * 2 * cols * sizeof(float);
+#define CALL(V)                                                                          \
+  do {                                                                                   \
+    if (x_dtype == CLIPK_BF16) launch_ln_bwd<V, false, true, false, true>(p, blocks, lds, st);   \
+    else launch_ln_bwd<V, false, false, false, true>(p, blocks, lds, st);                \
   } while (0)
   LN_DISPATCH_VPL(cols, CALL);
 #undef CALL

@@ -71,9 +71,18 @@ def _fused_views(parts):
     return data, grad
 
 
-def _ln_bwd(dy, x, w, b, mean, rstd, **kw):
+def _ln_bwd(dy, x, w, b, mean, rstd, pool=None, **kw):
     """ops.layernorm_bwd whose dgamma / dbeta go straight into w.grad / b.grad when those buffers exist (then the
-    returned parameter grads are None, as in _wgrad)."""
+    returned parameter grads are None, as in _wgrad).  pool = (inv_len, B, L, mask_u8): dy is the gradient of the
+    mean-pooled rows [B, cols] (backward of ops.layernorm_meanpool_fwd)."""
+    if pool is not None:
+        inv_len, B, L, mask_u8 = pool
+        m = mask_u8.view(-1) if mask_u8 is not None else None
+        if DIRECT_PARAM_GRADS and _direct_ok(w) and _direct_ok(b):
+            dx, dxb, _, _ = ops.layernorm_meanpool_bwd(dy, inv_len, x, w, mean, rstd, B, L, mask=m, dgamma=w.grad,
+                                                       dbeta=b.grad, accumulate=True, **kw)
+            return dx, dxb, None, None
+        return ops.layernorm_meanpool_bwd(dy, inv_len, x, w, mean, rstd, B, L, mask=m, **kw)
     if DIRECT_PARAM_GRADS and _direct_ok(w) and _direct_ok(b):
         dx, dxb, _, _ = ops.layernorm_bwd(dy, x, w, None, mean, rstd, dgamma=w.grad, dbeta=b.grad, accumulate=True, **kw)
         return dx, dxb, None, None
@@ -217,10 +226,11 @@ _ESM_KEYS = ["ln1_w", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b", "ln2_w", "ln2
 
 
 class EsmStackFn(torch.autograd.Function):
-    """ids -> final-LayerNorm hidden states [B*L, d] (f32)."""
+    """ids -> final-LayerNorm hidden states [B*L, d] (f32); pool = True: -> their masked mean per sequence [B, d], the
+    final LayerNorm and the pooling in one pass (clipk_layernorm_meanpool_*: the normalised rows are never written)."""
 
     @staticmethod
-    def forward(ctx, module, ids, mask_u8, row_scale, seq, *flat):
+    def forward(ctx, module, ids, mask_u8, row_scale, seq, pool, *flat):
         nl = module.num_layers
         table, fin_w, fin_b = flat[0], flat[1], flat[2]
         B, L = ids.shape                                    # packed batches come as [T, 1] with seq = (cu, max_len)
@@ -243,7 +253,13 @@ class EsmStackFn(torch.autograd.Function):
             x, s = _esm_layer_fwd(x, p, meta, keep=need_bwd)
             layers.append(p)
             saved.append(s if need_bwd else None)
-        y, _, mf, rf = ops.layernorm_fwd(x, fin_w, fin_b, module.eps, want_f32=True)
+        ctx.pool = None
+        if pool:
+            y, mf, rf, inv_len = ops.layernorm_meanpool_fwd(x, fin_w, fin_b, module.eps, B, L,
+                                                            mask_u8.view(-1) if mask_u8 is not None else None)
+            ctx.pool = (inv_len, B, L)
+        else:
+            y, _, mf, rf = ops.layernorm_fwd(x, fin_w, fin_b, module.eps, want_f32=True)
         ctx.module, ctx.meta, ctx.layers, ctx.saved = module, meta, layers, saved
         ctx.fin = (x, fin_w, fin_b, mf, rf)
         ctx.ids, ctx.row_scale = ids, row_scale
@@ -260,7 +276,8 @@ class EsmStackFn(torch.autograd.Function):
         nl = module.num_layers
         grads: List[Optional[torch.Tensor]] = [None] * (3 + 12 * nl)
         lowp = ESM_BF16_GRAD_STREAM
-        dx, dxb, grads[1], grads[2] = _ln_bwd(dy.contiguous(), x, fin_w, fin_b, mf, rf, want_f32=not lowp, want_bf16=True)
+        dx, dxb, grads[1], grads[2] = _ln_bwd(dy.contiguous(), x, fin_w, fin_b, mf, rf, want_f32=not lowp, want_bf16=True,
+                                              pool=None if ctx.pool is None else ctx.pool + (meta[4],))
         for i in reversed(range(nl)):
             # the last layer processed (i = 0) hands an f32 gradient to the embedding backward
             dx, dxb, gr = _esm_layer_bwd(dx, dxb, ctx.layers[i], ctx.saved[i], meta, need_dx_bf16=i > 0,
@@ -268,7 +285,7 @@ class EsmStackFn(torch.autograd.Function):
             ctx.saved[i] = None                                     # free this layer's activations now
             for j, k in enumerate(_ESM_KEYS):
                 grads[3 + 12 * i + j] = gr[k]
-        if ctx.needs_input_grad[5]:
+        if ctx.needs_input_grad[6]:
             mask_u8 = meta[4]
             table = ctx.table
             direct = DIRECT_PARAM_GRADS and _direct_ok(table)       # the kernel accumulates: straight into table.grad
@@ -280,7 +297,7 @@ class EsmStackFn(torch.autograd.Function):
         ctx.layers = ctx.saved = ctx.table = None
         _join_side(*grads)
         _bucket_done(module, grads)
-        return (None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, *grads)
 
 
 class _EsmSelf(nn.Module):
@@ -416,7 +433,12 @@ class ESM2Encoder(nn.Module):
                      lyr.output.dense.weight, lyr.output.dense.bias]
         return flat
 
-    def forward(self, input_ids, attention_mask=None):
+    def forward_pooled(self, input_ids, attention_mask=None):
+        """Masked mean over the tokens of forward()'s last_hidden_state, [B, d]: same values as pooling the returned
+        states, with the final LayerNorm and the mean in one kernel (nothing of size [B, L, d] is written)."""
+        return self.forward(input_ids, attention_mask, _pool=True)
+
+    def forward(self, input_ids, attention_mask=None, _pool=False):
         B, L = input_ids.shape
         mask_u8 = None
         row_scale = None
@@ -428,8 +450,8 @@ class ESM2Encoder(nn.Module):
                 torch.full((B,), float(L), device=input_ids.device)
             ratio = (input_ids == self.mask_token_id).sum(-1).float() / src_len
             row_scale = ((1 - 0.15 * 0.8) / (1 - ratio)).contiguous()
-        y = EsmStackFn.apply(self, input_ids.contiguous(), mask_u8, row_scale, None, *self._flat_params())
-        return y.view(B, L, self.hidden_size)
+        y = EsmStackFn.apply(self, input_ids.contiguous(), mask_u8, row_scale, None, bool(_pool), *self._flat_params())
+        return y if _pool else y.view(B, L, self.hidden_size)
 
     def forward_packed(self, input_ids, cu_seqlens, max_len: int):
         """Packed variable-length batch: input_ids int64 [T] = the sequences back to back, cu_seqlens
@@ -445,7 +467,7 @@ class ESM2Encoder(nn.Module):
                 0, seg, (input_ids == self.mask_token_id).float())
             row_scale = ((1 - 0.15 * 0.8) / (1 - nmask / lens.float()))[seg].contiguous()
         y = EsmStackFn.apply(self, input_ids.reshape(T, 1).contiguous(), None, row_scale,
-                             (cu_seqlens.contiguous(), int(max_len)), *self._flat_params())
+                             (cu_seqlens.contiguous(), int(max_len)), False, *self._flat_params())
         return y
 
 
@@ -539,10 +561,11 @@ _POST_KEYS = ["in_w", "in_b", "out_w", "out_b", "n1_w", "n1_b", "fc1_w", "fc1_b"
 
 
 class PostLNStackFn(torch.autograd.Function):
-    """x f32 [B*L, E] -> final-LayerNorm output f32 [B*L, E]."""
+    """x f32 [B*L, E] -> final-LayerNorm output f32 [B*L, E]; pool = True: -> its masked mean per sequence [B, E]
+    (final LayerNorm + pooling in one pass, as EsmStackFn)."""
 
     @staticmethod
-    def forward(ctx, module, x, mask_u8, B, L, seq, drop, *flat):
+    def forward(ctx, module, x, mask_u8, B, L, seq, drop, pool, *flat):
         nl = module.num_layers
         E, H = module.embed_dim, module.nhead
         D = module.head_dim_padded
@@ -560,7 +583,13 @@ class PostLNStackFn(torch.autograd.Function):
             x, xb, s = _post_layer_fwd(x, xb, p, meta, None if drop is None else (drop[0],) + tuple(drop[1][i]))
             layers.append(p)
             saved.append(s if need_bwd else None)
-        y, _, mf, rf = ops.layernorm_fwd(x, fin_w, fin_b, module.final_eps, want_f32=True)
+        ctx.pool = None
+        if pool:
+            y, mf, rf, inv_len = ops.layernorm_meanpool_fwd(x, fin_w, fin_b, module.final_eps, B, L,
+                                                            mask_u8.view(-1) if mask_u8 is not None else None)
+            ctx.pool = (inv_len, B, L, mask_u8)
+        else:
+            y, _, mf, rf = ops.layernorm_fwd(x, fin_w, fin_b, module.final_eps, want_f32=True)
         ctx.module, ctx.meta, ctx.layers, ctx.saved = module, meta, layers, saved
         ctx.fin = (x, fin_w, fin_b, mf, rf)
         ctx.drop = drop
@@ -575,7 +604,7 @@ class PostLNStackFn(torch.autograd.Function):
         x, fin_w, fin_b, mf, rf = ctx.fin
         nl = module.num_layers
         grads: List[Optional[torch.Tensor]] = [None] * (2 + 12 * nl)
-        dx, _, grads[0], grads[1] = _ln_bwd(dy.contiguous(), x, fin_w, fin_b, mf, rf, want_f32=True)
+        dx, _, grads[0], grads[1] = _ln_bwd(dy.contiguous(), x, fin_w, fin_b, mf, rf, want_f32=True, pool=ctx.pool)
         for i in reversed(range(nl)):
             drop = ctx.drop
             dx, gr = _post_layer_bwd(dx, ctx.layers[i], ctx.saved[i], meta,
@@ -589,7 +618,7 @@ class PostLNStackFn(torch.autograd.Function):
         _bucket_done(module, grads)
         if ctx.needs_input_grad[1] and dx is not None and dx.dtype != torch.float32:
             dx = ops.to_f32(dx.contiguous())
-        return (None, dx if ctx.needs_input_grad[1] else None, None, None, None, None, None, *grads)
+        return (None, dx if ctx.needs_input_grad[1] else None, None, None, None, None, None, None, *grads)
 
 
 class _MHAParams(nn.Module):
@@ -665,14 +694,18 @@ class TransformerSeqEncoder(nn.Module):
                      l.linear2.weight, l.linear2.bias, l.norm2.weight, l.norm2.bias]
         return flat
 
-    def forward(self, x, src_key_padding_mask=None):
+    def forward_pooled(self, x, src_key_padding_mask=None):
+        """Masked mean over the positions of forward()'s output, [B, E]: final LayerNorm + mean in one kernel."""
+        return self.forward(x, src_key_padding_mask, _pool=True)
+
+    def forward(self, x, src_key_padding_mask=None, _pool=False):
         B, L, E = x.shape
         mask_u8 = None
         if src_key_padding_mask is not None:
             mask_u8 = (~src_key_padding_mask.bool()).to(torch.uint8).contiguous()      # kernels take 1 = valid
-        y = PostLNStackFn.apply(self, x.reshape(B * L, E), mask_u8, B, L, None, self._draw_dropout(),
+        y = PostLNStackFn.apply(self, x.reshape(B * L, E), mask_u8, B, L, None, self._draw_dropout(), bool(_pool),
                                 *self._flat_params())
-        return y.view(B, L, E)
+        return y if _pool else y.view(B, L, E)
 
     def _draw_dropout(self):
         """None (eval mode / p = 0) or (p, [[seed_attn, seed_drop1, seed_ffn, seed_drop2] per layer]): 32-bit seeds from
@@ -689,7 +722,7 @@ class TransformerSeqEncoder(nn.Module):
         T, E = x.shape
         B = cu_seqlens.numel() - 1
         return PostLNStackFn.apply(self, x, None, B, int(max_len), (cu_seqlens.contiguous(), int(max_len)),
-                                   self._draw_dropout(), *self._flat_params())
+                                   self._draw_dropout(), False, *self._flat_params())
 
 
 class PoolFn(torch.autograd.Function):

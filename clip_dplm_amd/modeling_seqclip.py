@@ -9,6 +9,8 @@
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional
 
 import numpy as np
@@ -70,6 +72,11 @@ class RNARBPCLIPModel(nn.Module):
         return rna_embed, rbp_embed, loss
 
 
+# mean pooling straight out of the encoders' final LayerNorm (clipk_layernorm_meanpool_*): nothing of size [B, L, d] is
+# written for the pooling.  CLIPK_FUSED_POOL=0 keeps the two-kernel path (LayerNorm, then pool) for A/B runs.
+FUSED_MEAN_POOL = os.environ.get("CLIPK_FUSED_POOL", "1") != "0"
+
+
 class ProteinRNACLIP(nn.Module):
     """BASELINE configs 2-4: protein ids -> ESM-2, RNA features -> 6-layer post-LN transformer; masked-mean
     pooling (`use_mean_pooling`), ProjectionHead (hidden 2P), L2 normalise, exp(logit_scale) similarity,
@@ -101,10 +108,15 @@ class ProteinRNACLIP(nn.Module):
                 p.requires_grad_(False)
 
     def _embed_rna(self, rna_values, rna_mask):
-        hr = self.rna_model(rna_values, src_key_padding_mask=None if rna_mask is None else ~rna_mask.bool())
+        kpm = None if rna_mask is None else ~rna_mask.bool()
+        if self.pooling == "mean" and FUSED_MEAN_POOL:       # final LayerNorm + masked mean in one kernel
+            return KF.l2_normalize(self.rna_projection(self.rna_model.forward_pooled(rna_values, kpm)))
+        hr = self.rna_model(rna_values, src_key_padding_mask=kpm)
         return KF.l2_normalize(self.rna_projection(pool(hr, rna_mask, self.pooling)))
 
     def _embed_protein(self, protein_ids, protein_mask):
+        if self.pooling == "mean" and FUSED_MEAN_POOL:
+            return KF.l2_normalize(self.protein_projection(self.protein_model.forward_pooled(protein_ids, protein_mask)))
         hp = self.protein_model(protein_ids, attention_mask=protein_mask)
         return KF.l2_normalize(self.protein_projection(pool(hp, protein_mask, self.pooling)))
 

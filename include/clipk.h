@@ -222,6 +222,21 @@ int clipk_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, const void* 
                         float* dgamma, float* dbeta, int accumulate,
                         int rows, int cols, float drop_p, uint32_t drop_seed, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Final LayerNorm of an encoder + masked mean over the L token rows of each sample in one pass: pooled[b] =
+ * mean_{l valid} LN(x[b, l]) (the pooling of run1/configuration_hybrid_clip.py:109,148 `use_mean_pooling`, fair-esm
+ * mean over residues current/tf_clip_codes (1).ipynb:1188, behind the encoders' last LayerNorm modeling_esm.py:552-553 /
+ * rna_clip_codes.ipynb:1923).  The normalised rows are never written.  x f32 or bf16 [B*L, cols], mask u8 [B*L] (1 = valid) or
+ * NULL; outputs pooled f32 [B, cols], mean / rstd f32 [B*L] (for the backward), inv_len f32 [B] = 1 / #valid (0 if none).
+ * Backward: row r gets dy = dpooled[r / L] * (valid(r) ? inv_len[r / L] : 0) and goes through the LayerNorm backward
+ * (outputs / workspace / dgamma / dbeta as clipk_layernorm_bwd, workspace size clipk_layernorm_bwd_workspace(B*L, cols)). */
+int clipk_layernorm_meanpool_fwd(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta, float eps,
+                                 const uint8_t* mask, int B, int L, int cols, float* pooled, float* mean, float* rstd,
+                                 float* inv_len, void* stream);
+int clipk_layernorm_meanpool_bwd(const float* dpooled, const float* inv_len, const uint8_t* mask, int B, int L,
+                                 const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* mean, const float* rstd,
+                                 float* dx_f32, void* dx_bf16, int64_t lddx, float* dgamma, float* dbeta, int accumulate,
+                                 int cols, void* workspace, size_t workspace_bytes, void* stream);
+
 /* F.normalize(x, dim=-1) with eps=1e-12 (old/clip.py:63-64): y = x / max(||x||, eps); f32. */
 int clipk_l2norm_fwd(const float* x, float* y, float* norm, int rows, int cols, float eps, void* stream);
 int clipk_l2norm_bwd(const float* dy, const float* y, const float* norm, float* dx,

@@ -748,6 +748,46 @@ def test_gemm_nt_output_over_2gib_is_cut_into_slabs(dev):
         assert torch.allclose(g[lo:lo + 256].float(), F.gelu(ref), rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("xdt", ["f32", "bf16"])
+@pytest.mark.parametrize("B,L,cols,masked", [(5, 37, 480, True), (3, 256, 768, False), (4, 64, 1280, True), (2, 9, 64, True)])
+def test_layernorm_meanpool_equals_layernorm_then_pool(dev, B, L, cols, masked, xdt):
+    """clipk_layernorm_meanpool_{fwd,bwd}: the encoders' final LayerNorm + masked mean in one pass against the two
+    separate kernels (statistics bit for bit; sums to f32 rounding: another summation order), ragged masks and a sample
+    with no valid row (pooled 0, no gradient)."""
+    ops = _ops()
+    x = _rand((B * L, cols), dev, 101, 1.5) + 0.3
+    if xdt == "bf16":                                           # post-LN stacks hand the last layer's bf16 output over
+        x = x.to(torch.bfloat16)
+    g, b = _rand((cols,), dev, 102) * 0.2 + 1.0, _rand((cols,), dev, 103, 0.1)
+    mask = None
+    if masked:
+        lens = torch.randint(1, L + 1, (B,), generator=torch.Generator().manual_seed(5))
+        lens[0] = L
+        if B > 2:
+            lens[2] = 0                                         # nothing valid
+        mask = (torch.arange(L)[None] < lens[:, None]).to(torch.uint8).to(dev).contiguous()
+    pooled, mean, rstd, inv_len = ops.layernorm_meanpool_fwd(x, g, b, 1e-5, B, L, mask=None if mask is None else mask.view(-1))
+    y, _, m2, r2 = ops.layernorm_fwd(x, g, b, 1e-5)
+    assert torch.equal(mean, m2) and torch.equal(rstd, r2)
+    ref = ops.pool_fwd(y, B, L, mask=mask, mode=1)
+    assert torch.allclose(pooled, ref, rtol=1e-5, atol=1e-6), (pooled - ref).abs().max()
+    if masked and B > 2:
+        assert (pooled[2] == 0).all() and inv_len[2].item() == 0.0
+    dp = _rand((B, cols), dev, 104)
+    dy = ops.pool_bwd(dp, B, L, mask=mask, mode=1)
+    rx, rxb, rg, rb = ops.layernorm_bwd(dy, x, g, None, m2, r2, want_f32=True, want_bf16=True)
+    dx, dxb, dg, db = ops.layernorm_meanpool_bwd(dp, inv_len, x, g, mean, rstd, B, L,
+                                                 mask=None if mask is None else mask.view(-1), want_f32=True, want_bf16=True)
+    assert torch.allclose(dx, rx, rtol=1e-5, atol=1e-7), (dx - rx).abs().max()
+    assert torch.allclose(dxb.float(), rxb.float(), rtol=1e-2, atol=1e-6)
+    assert torch.allclose(dg, rg, rtol=1e-4, atol=1e-5) and torch.allclose(db, rb, rtol=1e-4, atol=1e-5)
+    acc_g = torch.ones_like(dg)
+    acc_b = torch.ones_like(db)
+    ops.layernorm_meanpool_bwd(dp, inv_len, x, g, mean, rstd, B, L, mask=None if mask is None else mask.view(-1),
+                               dgamma=acc_g, dbeta=acc_b, accumulate=True)
+    assert torch.allclose(acc_g, dg + 1, rtol=1e-5, atol=1e-6) and torch.allclose(acc_b, db + 1, rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("kernel,M", [("v2", 1000), ("v3", 2048 + 24)])
 @pytest.mark.parametrize("H,D", [(3, 64), (4, 32), (8, 16)])
 def test_gemm_nt_rope_epilogue(dev, kopt, kernel, M, H, D):
