@@ -71,7 +71,7 @@ SIGNATURES = {
     "clipk_layernorm_bwd": (_i, [_vp, _i, _i64, _vp, _i, _i64, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i64,
                                  _vp, _vp, _i, _i, _i, _f, C.c_uint32, _vp, _sz, _vp]),
     "clipk_layernorm_meanpool_fwd": (_i, [_vp, _i, _i64, _vp, _vp, _f, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "clipk_layernorm_meanpool_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
+    "clipk_layernorm_meanpool_bwd": (_i, [_vp, _vp, _i, _i, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
                                           _i, _i, _vp, _sz, _vp]),
     "clipk_l2norm_fwd": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
     "clipk_l2norm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),

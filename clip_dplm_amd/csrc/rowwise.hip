@@ -98,7 +98,7 @@ struct LnPool {
   const void* x; long ldx;        // f32 or bf16 (XBF16)
   const float* gamma; const float* beta; float eps;
   const unsigned char* mask;      // [B * L], 1 = valid, or null
-  float* pooled; float* mean; float* rstd; float* inv_len;
+  float* pooled; float* mean; float* rstd; float* wrow;   // wrow [B * L]: the row's weight in its mean, 1 / #valid or 0
   int L, cols;
 };
 
@@ -162,7 +162,10 @@ __global__ __launch_bounds__(256) void ln_pool_fwd_kernel(const LnPool p) {
   __syncthreads();
   const float n = (sm[4 * p.cols] + sm[4 * p.cols + 1]) + (sm[4 * p.cols + 2] + sm[4 * p.cols + 3]);
   const float inv = n > 0.f ? 1.0f / n : 0.f;
-  if (threadIdx.x == 0) p.inv_len[b] = inv;
+  for (int l = threadIdx.x; l < p.L; l += blockDim.x) {
+    const long row = (long)b * p.L + l;
+    p.wrow[row] = (!p.mask || p.mask[row]) ? inv : 0.f;          // what the backward multiplies the pooled gradient by
+  }
   for (int i = threadIdx.x; i < p.cols; i += blockDim.x) {
     const float a = ((sm[i] + sm[p.cols + i]) + sm[2 * p.cols + i]) + sm[3 * p.cols + i];
     p.pooled[(long)b * p.cols + i] = a * inv;
@@ -181,8 +184,9 @@ struct LnBwd {
   unsigned drop_thr, drop_seed; float drop_scale;
   int add_bf16;     // dx_add holds bf16 instead of f32
   // POOL instantiation (LayerNorm followed by a masked mean over the L rows of each sample): dy is the gradient of the
-  // POOLED row, f32 [rows / pool_L][cols]; row r receives dy[r / pool_L] * (valid(r) ? inv_len[r / pool_L] : 0)
-  const float* inv_len; const unsigned char* pool_mask; int pool_L;
+  // POOLED row, f32 [rows / pool_L][cols]; row r receives dy[r / pool_L] * wrow[r] (1 / #valid rows of its sample, or 0:
+  // written by ln_pool_fwd_kernel next to mean / rstd, so that the row's scalars are three independent loads)
+  const float* wrow; int pool_L;
 };
 
 template <int VPL, bool DYBF16, bool XBF16, bool ADD16 = false, bool POOL = false>
@@ -211,15 +215,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
     float pw = 1.f;
     if constexpr (POOL) {
       dyrow = row / p.pool_L;
-      pw = (!p.pool_mask || p.pool_mask[row]) ? p.inv_len[dyrow] : 0.f;
+      pw = p.wrow[row];
     }
     // the residual-path gradient is only needed after the row reductions: issue its load with the others, so the
     // row costs one memory round trip instead of two
-#pragma unroll
+    u32x2 addp[VPL];                            // ADD16: the residual-path gradient stays packed bf16 until it is added
+#pragma unroll                                  // (2 instead of 4 registers per chunk: 100 -> 96 VGPRs at VPL 2 = 5 waves / SIMD)
     for (int v = 0; v < VPL; ++v) {
       const int c = lane + 64 * v;
       addv[v] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (p.dx_add && c < nch) addv[v] = load4<ADD16>(p.dx_add, (long)row * p.lddx + 4 * c);   // f32, or bf16 (ADD16)
+      addp[v] = u32x2{0u, 0u};
+      if constexpr (!POOL) {                    // (the pooled form has no residual-path gradient: 16 registers at VPL 4,
+        if (p.dx_add && c < nch) {              //  the difference between 2 and 3 waves per SIMD)
+          if constexpr (ADD16)
+            addp[v] = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(p.dx_add) + (long)row * p.lddx + 4 * c);
+          else
+            addv[v] = load4<false>(p.dx_add, (long)row * p.lddx + 4 * c);
+        }
+      }
     }
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
@@ -250,7 +263,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
         f32x4 dx;
 #pragma unroll
         for (int e = 0; e < 4; ++e) dx[e] = rstd * (gy[v][e] - c1 - xh[v][e] * c2);
-        dx += addv[v];
+        if constexpr (!POOL) {
+          if constexpr (ADD16)
+            dx += f32x4{bf16_to_f32((unsigned short)(addp[v][0] & 0xffffu)), bf16_to_f32((unsigned short)(addp[v][0] >> 16)),
+                        bf16_to_f32((unsigned short)(addp[v][1] & 0xffffu)), bf16_to_f32((unsigned short)(addp[v][1] >> 16))};
+          else
+            dx += addv[v];
+        }
         if (p.dx_f32) *reinterpret_cast<f32x4*>(p.dx_f32 + (long)row * p.lddx + 4 * c) = dx;
         if (p.dx_bf16) {
           if (p.drop_thr) {
@@ -386,8 +405,9 @@ int ln_blocks_cap(int rows, int cap) {
   if (b < 1) b = 1;
   return b;
 }
-// backward: as many blocks as are resident at once (~80 VGPRs at VPL 2, ~140 at VPL 4), never a second round
-int ln_blocks(int rows, int cols) { return ln_blocks_cap(rows, cols <= 512 ? 1024 : (cols <= 1024 ? 768 : 512)); }
+// backward: as many blocks as are resident at once (96 VGPRs at VPL 2 = 5 waves per SIMD, ~160 at VPL 4 = 3), never a
+// second round
+int ln_blocks(int rows, int cols) { return ln_blocks_cap(rows, cols <= 512 ? 1280 : (cols <= 1024 ? 768 : 512)); }
 int ln_blocks_fwd(int rows) { return ln_blocks_cap(rows, 2048); }
 
 template <int VPL, bool DYBF16, bool XBF16, bool ADD16 = false, bool POOL = false>
@@ -445,7 +465,7 @@ extern "C" int clipk_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, c
   if (workspace_bytes < (size_t)blocks * 2 * cols * sizeof(float)) return CLIPK_ERR_BAD_ARG;
   LnBwd p{dy, (long)lddy, x, (long)ldx, gamma, beta, mean, rstd, act, dx_add, dx_f32, dx_bf16, (long)lddx,
           (float*)workspace, rows, cols, 0u, drop_seed, 1.0f, (dx_add && dx_add_dtype == CLIPK_BF16) ? 1 : 0,
-          nullptr, nullptr, 1};
+          nullptr, 1};
   if (drop_p > 0.f && drop_p < 1.f) {
     const double t = (double)drop_p * 4294967296.0;
     p.drop_thr = t < 1.0 ? 1u : (t >= 4294967295.0 ? 4294967295u : (unsigned)t);
@@ -480,11 +500,11 @@ extern "C" int clipk_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, c
 
 extern "C" int clipk_layernorm_meanpool_fwd(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta, float eps,
                                            const uint8_t* mask, int B, int L, int cols, float* pooled, float* mean,
-                                           float* rstd, float* inv_len, void* stream) {
-  if (!x || !gamma || !beta || !pooled || !mean || !rstd || !inv_len || B <= 0 || L <= 0 || cols <= 0) return CLIPK_ERR_BAD_ARG;
+                                           float* rstd, float* row_weight, void* stream) {
+  if (!x || !gamma || !beta || !pooled || !mean || !rstd || !row_weight || B <= 0 || L <= 0 || cols <= 0) return CLIPK_ERR_BAD_ARG;
   if ((cols & 3) || (ldx & 3)) return CLIPK_ERR_UNSUPPORTED;
   if (!aligned16(x) || !aligned16(gamma) || !aligned16(beta)) return CLIPK_ERR_BAD_ARG;
-  LnPool p{x, (long)ldx, gamma, beta, eps, mask, pooled, mean, rstd, inv_len, L, cols};
+  LnPool p{x, (long)ldx, gamma, beta, eps, mask, pooled, mean, rstd, row_weight, L, cols};
   const size_t lds = ((size_t)4 * cols + 4) * sizeof(float);
   if (lds > 65536) return CLIPK_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
@@ -498,12 +518,12 @@ extern "C" int clipk_layernorm_meanpool_fwd(const void* x, int x_dtype, int64_t 
   return clipk_check_launch();
 }
 
-extern "C" int clipk_layernorm_meanpool_bwd(const float* dpooled, const float* inv_len, const uint8_t* mask, int B, int L,
+extern "C" int clipk_layernorm_meanpool_bwd(const float* dpooled, const float* row_weight, int B, int L,
                                            const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* mean,
                                            const float* rstd, float* dx_f32, void* dx_bf16, int64_t lddx, float* dgamma,
                                            float* dbeta, int accumulate, int cols, void* workspace,
                                            size_t workspace_bytes, void* stream) {
-  if (!dpooled || !inv_len || !x || !gamma || !mean || !rstd || B <= 0 || L <= 0 || cols <= 0 || !workspace)
+  if (!dpooled || !row_weight || !x || !gamma || !mean || !rstd || B <= 0 || L <= 0 || cols <= 0 || !workspace)
     return CLIPK_ERR_BAD_ARG;
   if (!dx_f32 && !dx_bf16) return CLIPK_ERR_BAD_ARG;
   if ((cols & 3) || (ldx & 3) || (lddx & 3)) return CLIPK_ERR_UNSUPPORTED;
@@ -513,7 +533,7 @@ extern "C" int clipk_layernorm_meanpool_bwd(const float* dpooled, const float* i
   const int blocks = ln_blocks(rows, cols);
   if (workspace_bytes < (size_t)blocks * 2 * cols * sizeof(float)) return CLIPK_ERR_BAD_ARG;
   LnBwd p{dpooled, (long)cols, x, (long)ldx, gamma, nullptr, mean, rstd, CLIPK_ACT_NONE, nullptr, dx_f32, dx_bf16,
-          (long)lddx, (float*)workspace, rows, cols, 0u, 0u, 1.0f, 0, inv_len, mask, L};
+          (long)lddx, (float*)workspace, rows, cols, 0u, 0u, 1.0f, 0, row_weight, L};
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = (size_t)4 * 2 * cols * sizeof(float);
 #define CALL(V)                                                                          \

@@ -73,16 +73,15 @@ def _fused_views(parts):
 
 def _ln_bwd(dy, x, w, b, mean, rstd, pool=None, **kw):
     """ops.layernorm_bwd whose dgamma / dbeta go straight into w.grad / b.grad when those buffers exist (then the
-    returned parameter grads are None, as in _wgrad).  pool = (inv_len, B, L, mask_u8): dy is the gradient of the
-    mean-pooled rows [B, cols] (backward of ops.layernorm_meanpool_fwd)."""
+    returned parameter grads are None, as in _wgrad).  pool = (row_weight, B, L): dy is the gradient of the mean-pooled
+    rows [B, cols] (backward of ops.layernorm_meanpool_fwd)."""
     if pool is not None:
-        inv_len, B, L, mask_u8 = pool
-        m = mask_u8.view(-1) if mask_u8 is not None else None
+        wrow, B, L = pool
         if DIRECT_PARAM_GRADS and _direct_ok(w) and _direct_ok(b):
-            dx, dxb, _, _ = ops.layernorm_meanpool_bwd(dy, inv_len, x, w, mean, rstd, B, L, mask=m, dgamma=w.grad,
-                                                       dbeta=b.grad, accumulate=True, **kw)
+            dx, dxb, _, _ = ops.layernorm_meanpool_bwd(dy, wrow, x, w, mean, rstd, B, L, dgamma=w.grad, dbeta=b.grad,
+                                                       accumulate=True, **kw)
             return dx, dxb, None, None
-        return ops.layernorm_meanpool_bwd(dy, inv_len, x, w, mean, rstd, B, L, mask=m, **kw)
+        return ops.layernorm_meanpool_bwd(dy, wrow, x, w, mean, rstd, B, L, **kw)
     if DIRECT_PARAM_GRADS and _direct_ok(w) and _direct_ok(b):
         dx, dxb, _, _ = ops.layernorm_bwd(dy, x, w, None, mean, rstd, dgamma=w.grad, dbeta=b.grad, accumulate=True, **kw)
         return dx, dxb, None, None
@@ -255,9 +254,9 @@ class EsmStackFn(torch.autograd.Function):
             saved.append(s if need_bwd else None)
         ctx.pool = None
         if pool:
-            y, mf, rf, inv_len = ops.layernorm_meanpool_fwd(x, fin_w, fin_b, module.eps, B, L,
+            y, mf, rf, wrow = ops.layernorm_meanpool_fwd(x, fin_w, fin_b, module.eps, B, L,
                                                             mask_u8.view(-1) if mask_u8 is not None else None)
-            ctx.pool = (inv_len, B, L)
+            ctx.pool = (wrow, B, L)
         else:
             y, _, mf, rf = ops.layernorm_fwd(x, fin_w, fin_b, module.eps, want_f32=True)
         ctx.module, ctx.meta, ctx.layers, ctx.saved = module, meta, layers, saved
@@ -277,7 +276,7 @@ class EsmStackFn(torch.autograd.Function):
         grads: List[Optional[torch.Tensor]] = [None] * (3 + 12 * nl)
         lowp = ESM_BF16_GRAD_STREAM
         dx, dxb, grads[1], grads[2] = _ln_bwd(dy.contiguous(), x, fin_w, fin_b, mf, rf, want_f32=not lowp, want_bf16=True,
-                                              pool=None if ctx.pool is None else ctx.pool + (meta[4],))
+                                              pool=ctx.pool)
         for i in reversed(range(nl)):
             # the last layer processed (i = 0) hands an f32 gradient to the embedding backward
             dx, dxb, gr = _esm_layer_bwd(dx, dxb, ctx.layers[i], ctx.saved[i], meta, need_dx_bf16=i > 0,
@@ -585,9 +584,9 @@ class PostLNStackFn(torch.autograd.Function):
             saved.append(s if need_bwd else None)
         ctx.pool = None
         if pool:
-            y, mf, rf, inv_len = ops.layernorm_meanpool_fwd(x, fin_w, fin_b, module.final_eps, B, L,
+            y, mf, rf, wrow = ops.layernorm_meanpool_fwd(x, fin_w, fin_b, module.final_eps, B, L,
                                                             mask_u8.view(-1) if mask_u8 is not None else None)
-            ctx.pool = (inv_len, B, L, mask_u8)
+            ctx.pool = (wrow, B, L)
         else:
             y, _, mf, rf = ops.layernorm_fwd(x, fin_w, fin_b, module.final_eps, want_f32=True)
         ctx.module, ctx.meta, ctx.layers, ctx.saved = module, meta, layers, saved

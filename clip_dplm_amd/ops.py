@@ -402,26 +402,27 @@ def layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=None, dx_add=None, want_f3
 
 def layernorm_meanpool_fwd(x, gamma, beta, eps, B, L, mask=None):
     """pooled[b] = mean over the valid rows l of LayerNorm(x[b * L + l]) in one pass (the normalised rows are never
-    written).  x f32 [B*L, cols]; mask u8 [B*L] (1 = valid) or None.  Returns pooled [B, cols], mean, rstd [B*L], inv_len [B]."""
+    written).  x f32 / bf16 [B*L, cols]; mask u8 [B*L] (1 = valid) or None.  Returns pooled [B, cols], mean, rstd [B*L] and
+    row_weight [B*L] (each row's weight in its sample's mean: what the backward needs)."""
     _need_cuda(x, gamma, beta, mask)
     rows, cols = x.shape
     assert rows == B * L and x.dtype in (torch.float32, torch.bfloat16) and x.stride(1) == 1
     pooled = torch.empty((B, cols), dtype=torch.float32, device=x.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-    inv_len = torch.empty(B, dtype=torch.float32, device=x.device)
+    wrow = torch.empty(rows, dtype=torch.float32, device=x.device)
     check(_timed("layernorm_fwd", rows * cols * x.element_size(),
                  lambda: _lib().clipk_layernorm_meanpool_fwd(x.data_ptr(), _dt(x), x.stride(0), gamma.data_ptr(), beta.data_ptr(),
                                                              float(eps), ptr(mask), B, L, cols, pooled.data_ptr(),
-                                                             mean.data_ptr(), rstd.data_ptr(), inv_len.data_ptr(),
+                                                             mean.data_ptr(), rstd.data_ptr(), wrow.data_ptr(),
                                                              _stream())), "clipk_layernorm_meanpool_fwd")
-    return pooled, mean, rstd, inv_len
+    return pooled, mean, rstd, wrow
 
 
-def layernorm_meanpool_bwd(dpooled, inv_len, x, gamma, mean, rstd, B, L, mask=None, want_f32=True, want_bf16=False,
+def layernorm_meanpool_bwd(dpooled, row_weight, x, gamma, mean, rstd, B, L, want_f32=True, want_bf16=False,
                            dgamma=None, dbeta=None, accumulate=False):
     """Backward of layernorm_meanpool_fwd: dx f32 and / or bf16 [B*L, cols], dgamma, dbeta."""
-    _need_cuda(dpooled, inv_len, x, gamma, mean, rstd, mask)
+    _need_cuda(dpooled, row_weight, x, gamma, mean, rstd)
     rows, cols = x.shape
     assert rows == B * L and dpooled.shape == (B, cols) and dpooled.dtype == torch.float32 and dpooled.is_contiguous()
     dx32 = torch.empty((rows, cols), dtype=torch.float32, device=x.device) if want_f32 else None
@@ -434,7 +435,7 @@ def layernorm_meanpool_bwd(dpooled, inv_len, x, gamma, mean, rstd, B, L, mask=No
     ws = workspace(lib.clipk_layernorm_bwd_workspace(rows, cols), x.device, "ln")
     nb = rows * cols * (x.element_size() + (4 if want_f32 else 0) + (2 if want_bf16 else 0))
     check(_timed("layernorm_bwd", nb,
-                 lambda: lib.clipk_layernorm_meanpool_bwd(dpooled.data_ptr(), inv_len.data_ptr(), ptr(mask), B, L,
+                 lambda: lib.clipk_layernorm_meanpool_bwd(dpooled.data_ptr(), row_weight.data_ptr(), B, L,
                                                           x.data_ptr(), _dt(x), x.stride(0), gamma.data_ptr(), mean.data_ptr(),
                                                           rstd.data_ptr(), ptr(dx32), ptr(dx16), cols, ptr(dgamma),
                                                           ptr(dbeta), int(accumulate), cols, ws.data_ptr(), ws.numel(),

@@ -226,13 +226,14 @@ int clipk_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, const void* 
  * mean_{l valid} LN(x[b, l]) (the pooling of run1/configuration_hybrid_clip.py:109,148 `use_mean_pooling`, fair-esm
  * mean over residues current/tf_clip_codes (1).ipynb:1188, behind the encoders' last LayerNorm modeling_esm.py:552-553 /
  * rna_clip_codes.ipynb:1923).  The normalised rows are never written.  x f32 or bf16 [B*L, cols], mask u8 [B*L] (1 = valid) or
- * NULL; outputs pooled f32 [B, cols], mean / rstd f32 [B*L] (for the backward), inv_len f32 [B] = 1 / #valid (0 if none).
- * Backward: row r gets dy = dpooled[r / L] * (valid(r) ? inv_len[r / L] : 0) and goes through the LayerNorm backward
+ * NULL; outputs pooled f32 [B, cols], mean / rstd f32 [B*L] (for the backward), row_weight f32 [B*L] = the row's weight in
+ * its sample's mean (1 / #valid rows, 0 for a masked row or an empty sample).
+ * Backward: row r gets dy = dpooled[r / L] * row_weight[r] and goes through the LayerNorm backward
  * (outputs / workspace / dgamma / dbeta as clipk_layernorm_bwd, workspace size clipk_layernorm_bwd_workspace(B*L, cols)). */
 int clipk_layernorm_meanpool_fwd(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta, float eps,
                                  const uint8_t* mask, int B, int L, int cols, float* pooled, float* mean, float* rstd,
-                                 float* inv_len, void* stream);
-int clipk_layernorm_meanpool_bwd(const float* dpooled, const float* inv_len, const uint8_t* mask, int B, int L,
+                                 float* row_weight, void* stream);
+int clipk_layernorm_meanpool_bwd(const float* dpooled, const float* row_weight, int B, int L,
                                  const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* mean, const float* rstd,
                                  float* dx_f32, void* dx_bf16, int64_t lddx, float* dgamma, float* dbeta, int accumulate,
                                  int cols, void* workspace, size_t workspace_bytes, void* stream);

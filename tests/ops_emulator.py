@@ -236,14 +236,12 @@ def layernorm_meanpool_fwd(x, gamma, beta, eps, B, L, mask=None):
     n = m.view(B, L).sum(1)
     inv = torch.where(n > 0, 1.0 / n.clamp_min(1.0), torch.zeros_like(n))
     pooled = (y * m[:, None]).view(B, L, -1).sum(1) * inv[:, None]
-    return pooled, mean, rstd, inv
+    return pooled, mean, rstd, m * inv.repeat_interleave(L)
 
 
-def layernorm_meanpool_bwd(dpooled, inv_len, x, gamma, mean, rstd, B, L, mask=None, want_f32=True, want_bf16=False,
+def layernorm_meanpool_bwd(dpooled, row_weight, x, gamma, mean, rstd, B, L, want_f32=True, want_bf16=False,
                            dgamma=None, dbeta=None, accumulate=False):
-    m = torch.ones(B * L) if mask is None else mask.view(-1).float()
-    w = m * inv_len.repeat_interleave(L)
-    dy = dpooled.repeat_interleave(L, 0) * w[:, None]
+    dy = dpooled.repeat_interleave(L, 0) * row_weight[:, None]
     return layernorm_bwd(dy, x, gamma, None, mean, rstd, want_f32=want_f32, want_bf16=want_bf16, dgamma=dgamma,
                          dbeta=dbeta, accumulate=accumulate)
 

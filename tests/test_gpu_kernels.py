@@ -766,25 +766,23 @@ def test_layernorm_meanpool_equals_layernorm_then_pool(dev, B, L, cols, masked, 
         if B > 2:
             lens[2] = 0                                         # nothing valid
         mask = (torch.arange(L)[None] < lens[:, None]).to(torch.uint8).to(dev).contiguous()
-    pooled, mean, rstd, inv_len = ops.layernorm_meanpool_fwd(x, g, b, 1e-5, B, L, mask=None if mask is None else mask.view(-1))
+    pooled, mean, rstd, wrow = ops.layernorm_meanpool_fwd(x, g, b, 1e-5, B, L, mask=None if mask is None else mask.view(-1))
     y, _, m2, r2 = ops.layernorm_fwd(x, g, b, 1e-5)
     assert torch.equal(mean, m2) and torch.equal(rstd, r2)
     ref = ops.pool_fwd(y, B, L, mask=mask, mode=1)
     assert torch.allclose(pooled, ref, rtol=1e-5, atol=1e-6), (pooled - ref).abs().max()
     if masked and B > 2:
-        assert (pooled[2] == 0).all() and inv_len[2].item() == 0.0
+        assert (pooled[2] == 0).all() and (wrow.view(B, L)[2] == 0).all()
     dp = _rand((B, cols), dev, 104)
     dy = ops.pool_bwd(dp, B, L, mask=mask, mode=1)
     rx, rxb, rg, rb = ops.layernorm_bwd(dy, x, g, None, m2, r2, want_f32=True, want_bf16=True)
-    dx, dxb, dg, db = ops.layernorm_meanpool_bwd(dp, inv_len, x, g, mean, rstd, B, L,
-                                                 mask=None if mask is None else mask.view(-1), want_f32=True, want_bf16=True)
+    dx, dxb, dg, db = ops.layernorm_meanpool_bwd(dp, wrow, x, g, mean, rstd, B, L, want_f32=True, want_bf16=True)
     assert torch.allclose(dx, rx, rtol=1e-5, atol=1e-7), (dx - rx).abs().max()
     assert torch.allclose(dxb.float(), rxb.float(), rtol=1e-2, atol=1e-6)
     assert torch.allclose(dg, rg, rtol=1e-4, atol=1e-5) and torch.allclose(db, rb, rtol=1e-4, atol=1e-5)
     acc_g = torch.ones_like(dg)
     acc_b = torch.ones_like(db)
-    ops.layernorm_meanpool_bwd(dp, inv_len, x, g, mean, rstd, B, L, mask=None if mask is None else mask.view(-1),
-                               dgamma=acc_g, dbeta=acc_b, accumulate=True)
+    ops.layernorm_meanpool_bwd(dp, wrow, x, g, mean, rstd, B, L, dgamma=acc_g, dbeta=acc_b, accumulate=True)
     assert torch.allclose(acc_g, dg + 1, rtol=1e-5, atol=1e-6) and torch.allclose(acc_b, db + 1, rtol=1e-5, atol=1e-6)
 
 
