@@ -88,7 +88,8 @@ SIGNATURES = {
     "clipk_rope_qk": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "clipk_attn_fwd_rot": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "clipk_attn_varlen_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, C.c_uint32, _vp]),
-    "clipk_attn_varlen_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, C.c_uint32,
+    "clipk_attn_varlen_fwd_rot": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "clipk_attn_varlen_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _f, C.c_uint32,
                                    _vp]),
     "clipk_embed_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "clipk_embed_bwd_workspace": (_sz, [_i, _i, _i, _i]),

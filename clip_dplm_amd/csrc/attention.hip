@@ -992,7 +992,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
   float* img = reinterpret_cast<float*>(dst_all + 4 * 4096);   // dQ image [256][D + 4] f32
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
-  const int L = p.L, H = p.H;
+  const int H = p.H;                                      // (the sequence length L is per head: packed batches)
   float* lse_l = img + LQ * ILD;                          // [256], already times log2(e); +inf past the end
   float* dl_l = lse_l + LQ;                               // [256]
   const long tokstride = 3L * H * D, ostride = (long)H * D;
@@ -1005,12 +1005,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
   auto issue = [&](int w, Regs& R) {
     int blk_, h_, b_;
     work_item_at(w, 1, H, p.B, blk_, h_, b_);
+    int L = p.L;
+    long row0_ = seq_rows(p, b_, L);                       // packed batch: this sequence's first row and length
+    if (L <= 0) { L = 1; row0_ = row0_ > 0 ? row0_ - 1 : 0; }   // empty sequence: in-range dummy row, never used
     const int t = tid + opaque_zero();
     const int ci = t & 3, r0 = t >> 2;
     // uniform bases (SGPR pairs) + 32-bit element offsets: one VGPR per address
-    const unsigned short* qb = p.qkv + (long)b_ * L * tokstride + (long)h_ * D;
-    const unsigned short* dob = p.dout + (long)b_ * L * ostride + (long)h_ * D;
-    const unsigned short* ob = p.out + (long)b_ * L * ostride + (long)h_ * D;
+    const unsigned short* qb = p.qkv + row0_ * tokstride + (long)h_ * D;
+    const unsigned short* dob = p.dout + row0_ * ostride + (long)h_ * D;
+    const unsigned short* ob = p.out + row0_ * ostride + (long)h_ * D;
     const unsigned int HD = (unsigned int)(H * D);
     // no branch around the loads (a lane whose chunk is the zero pad re-reads the last real chunk and drops it at
     // staging time): loads under a divergent branch make every later s_waitcnt assume they may not have been issued
@@ -1025,12 +1028,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
       R.d[ps] = *reinterpret_cast<const u32x4*>(dob + oo);
       R.o[ps] = *reinterpret_cast<const u32x4*>(ob + oo);
     }
-    R.lse = p.lse[((long)b_ * H + h_) * L + (t < L ? t : L - 1)];
+    R.lse = p.lse[stat_at(p, b_, h_, H, L, row0_, t < L ? t : L - 1)];
     const int lane_ = t & 63, wid_ = t >> 6;
 #pragma unroll
     for (int kt = 0; kt < KTW; ++kt) {
       const int key = wid_ * KW + kt * 16 + (lane_ & 15);
-      R.km[kt] = p.key_mask ? p.key_mask[(long)b_ * L + (key < L ? key : L - 1)] : (unsigned char)1;
+      R.km[kt] = p.key_mask ? p.key_mask[row0_ + (key < L ? key : L - 1)] : (unsigned char)1;
     }
   };
 
@@ -1059,6 +1062,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
   for (; w < nheads; w += gridDim.x) {
     int blk, h, b;
     work_item_at(w, 1, H, p.B, blk, h, b);
+    int L = p.L;
+    const long row0 = seq_rows(p, b, L);
+    if (L <= 0) {                                          // (workgroup-uniform) empty sequence of a packed batch
+      issue(w + (int)gridDim.x < nheads ? w + (int)gridDim.x : w, R);
+      continue;
+    }
     const int tq = tid + opaque_zero();
     const int ci = tq & 3, r0 = tq >> 2;
     // ---- K / V rows to LDS, lse and delta = rowsum(dO * O) to their arrays, dQ image to zero
@@ -1084,7 +1093,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
       if (ci == 0) {
         const bool ok = row < L;
         dl_l[row] = ok ? -acc : 0.f;                       // NEGATED: the dP accumulators start from it
-        if (ok) p.delta[((long)b * H + h) * L + row] = acc;
+        if (ok) p.delta[stat_at(p, b, h, H, L, row0, row)] = acc;
       }
     }
     if (tid < LQ)
@@ -1123,7 +1132,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
 #pragma unroll 1
     for (int step = 0; step < LQ / 32; ++step) {
       const int j = (step + wid) & (LQ / 32 - 1);
-      if (j * 32 < L) {                                     // wave-uniform
+      if (j * 32 < L && wid * KW < L) {                     // wave-uniform: a query block and keys of this wave exist
         const char* qt_ = qtile + j * 32 * 64;
         const char* dt_ = dotile + j * 32 * 64;
         // one 16-query tile at a time: its P and dS leave the f32 accumulators as packed bf16 (2 + 2 registers per
@@ -1233,7 +1242,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
         }
     __syncthreads();
     if (tq < L) {
-      unsigned short* dqrow = p.dqkv + (long)b * L * tokstride + (long)h * D + (unsigned int)tq * (unsigned int)tokstride;
+      unsigned short* dqrow = p.dqkv + row0 * tokstride + (long)h * D + (unsigned int)tq * (unsigned int)tokstride;
       store_grad_row<ROPE, D>(img + tq * ILD, dqrow, T, p.scale);            // q_scale: once per element, here
       store_grad_row<ROPE, D>(img2 + tq * ILD, dqrow + H * D, T, p.scale);
 #pragma unroll
@@ -1264,16 +1273,19 @@ __global__ __launch_bounds__(256, ROT ? 3 : 4) void attn_fwd_whole32_kernel(cons
   char* qtile = smem + 2 * LQ * 64 + 256;                 // ROT only: [256][64 B]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
-  const int L = p.L, H = p.H;
+  const int H = p.H;
   int blk, h, b;
   work_item(1, H, p.B, blk, h, b);
+  int L = p.L;
+  const long row0 = seq_rows(p, b, L);                     // packed batch: this sequence's rows [row0, row0 + L)
+  if (L <= 0) return;                                      // (workgroup-uniform)
   const float c2 = p.scale * LOG2E;
   u32x4 qfr[2][2];
   {
     // four lanes per token row, one 16-byte chunk each (the pad chunk re-reads the last real one and is dropped)
     const int ci = tid & 3, r0 = tid >> 2;
     const unsigned int HD = (unsigned int)(H * D), cc = 8u * (ci < cpr ? ci : cpr - 1);
-    const unsigned short* qb = p.qkv + (long)b * L * 3 * HD + (long)h * D;
+    const unsigned short* qb = p.qkv + row0 * 3 * (long)HD + (long)h * D;
     u32x4 ck[4], cv[4];
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
@@ -1297,7 +1309,7 @@ __global__ __launch_bounds__(256, ROT ? 3 : 4) void attn_fwd_whole32_kernel(cons
           qfr[qh][qt] = *reinterpret_cast<const u32x4*>(qb + ((unsigned int)row * 3u * HD + 8u * (g < cpr ? g : cpr - 1)));
         }
     }
-    mask_l[tid] = (tid < L && (!p.key_mask || p.key_mask[(long)b * L + tid])) ? 1 : 0;
+    mask_l[tid] = (tid < L && (!p.key_mask || p.key_mask[row0 + tid])) ? 1 : 0;
     const bool pad = cpr < 4 && ci >= cpr;
     const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -1418,8 +1430,8 @@ __global__ __launch_bounds__(256, ROT ? 3 : 4) void attn_fwd_whole32_kernel(cons
       const float inv = lt > 0.f ? 1.0f / lt : 0.f;
       const int q = q0 + wid * 32 + qt * 16 + li;
       if (q < L) {
-        if (g == 0) p.lse[((long)b * H + h) * L + q] = lt > 0.f ? m_run[qt] * p.scale + logf(lt) : -INFINITY;
-        unsigned short* orow = p.out + ((long)b * L + q) * ((long)H * D) + (long)h * D;
+        if (g == 0) p.lse[stat_at(p, b, h, H, L, row0, q)] = lt > 0.f ? m_run[qt] * p.scale + logf(lt) : -INFINITY;
+        unsigned short* orow = p.out + (row0 + q) * ((long)H * D) + (long)h * D;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
           const int d = dt * 16 + 4 * g;
@@ -1471,7 +1483,7 @@ template <int DP, int DR, int DX>
 int launch_fwd(const AP& p, hipStream_t st) {
   if constexpr (DP == 32 && DR == 0) {
     // short heads whose rows need no rotation: whole-head kernel (option attn_whole_fwd = 0: the general one)
-    if (!p.cu && !p.drop_thr && whole_fwd_applies(p.L, p.D)) {
+    if (!p.drop_thr && whole_fwd_applies(p.L, p.D)) {        // (packed batches too: per-sequence rows from cu_seqlens)
       switch (p.D) {
         case 16: launch_fwd_whole<16, false>(p, st); break;
         case 24: launch_fwd_whole<24, false>(p, st); break;
@@ -1528,7 +1540,8 @@ int launch_bwd(const AP& p, hipStream_t st) {
     // keeps the two-kernel path (tests compare the two)
     const bool fused_on = clipk_opt_get(OPT_ATTN_FUSED_BWD) != 0;
     // q / k must arrive rotated (clipk_rope_qk) or unrotated-by-design: the chunk-per-lane staging cannot rotate
-    if (!p.cu && !p.drop_thr && fused_on && p.L > 128 && p.L <= FUSED_LMAX && p.D >= 16 && (DR == 0 || p.pre_rot)) {
+    // (packed batches too: the kernel takes each head's rows and length from cu_seqlens; p.L = the longest sequence)
+    if (!p.drop_thr && fused_on && p.L > 128 && p.L <= FUSED_LMAX && p.D >= 16 && (DR == 0 || p.pre_rot)) {
       switch (p.D) {
         case 16: launch_fused<(DR > 0), 16>(p, st); break;
         case 24: launch_fused<(DR > 0), 24>(p, st); break;
@@ -1740,10 +1753,35 @@ extern "C" int clipk_attn_varlen_fwd(const void* qkv, const int* cu_seqlens, con
   ATTN_DISPATCH(launch_fwd, D, rope, p, (hipStream_t)stream);
 }
 
+// clipk_attn_fwd_rot for a packed batch: q / k of every sequence rotated IN PLACE (positions count from the sequence's
+// first row) by the whole-head kernel while it stages them; only where that kernel applies (D in {16, 24, 32},
+// 128 < max_len <= 256) - CLIPK_ERR_UNSUPPORTED otherwise (callers then use clipk_attn_varlen_fwd, which rotates at
+// every staging and leaves qkv alone).  Backward: clipk_attn_varlen_bwd(..., prerotated = 1).
+extern "C" int clipk_attn_varlen_fwd_rot(void* qkv, const int* cu_seqlens, const float* rope_cos, const float* rope_sin,
+                                         void* out, float* lse, int B, int T, int max_len, int H, int D, float q_scale,
+                                         void* stream) {
+  if (!rope_cos || !rope_sin) return CLIPK_ERR_BAD_ARG;
+  int rc = check_common(qkv, B, max_len, H, D, true);
+  if (rc) return rc;
+  if (!cu_seqlens || T <= 0 || max_len > T || !out || !lse || !aligned16(out)) return CLIPK_ERR_BAD_ARG;
+  if (!whole_fwd_applies(max_len, D)) return CLIPK_ERR_UNSUPPORTED;
+  AP p{};
+  p.qkv = (const unsigned short*)qkv; p.key_mask = nullptr; p.cosT = rope_cos; p.sinT = rope_sin;
+  p.out = (unsigned short*)out; p.lse = lse; p.B = B; p.L = max_len; p.H = H; p.D = D; p.scale = q_scale;
+  p.cu = cu_seqlens; p.T = T;
+  hipStream_t st = (hipStream_t)stream;
+  switch (D) {
+    case 16: launch_fwd_whole<16, true>(p, st); break;
+    case 24: launch_fwd_whole<24, true>(p, st); break;
+    default: launch_fwd_whole<32, true>(p, st); break;
+  }
+  return clipk_check_launch();
+}
+
 extern "C" int clipk_attn_varlen_bwd(const void* qkv, const int* cu_seqlens, const float* rope_cos, const float* rope_sin,
                                      const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
-                                     int B, int T, int max_len, int H, int D, float q_scale, float dropout_p,
-                                     uint32_t dropout_seed, void* stream) {
+                                     int B, int T, int max_len, int H, int D, float q_scale, int prerotated,
+                                     float dropout_p, uint32_t dropout_seed, void* stream) {
   if ((rope_cos == nullptr) != (rope_sin == nullptr)) return CLIPK_ERR_BAD_ARG;
   const bool rope = rope_cos != nullptr;
   int rc = check_common(qkv, B, max_len, H, D, rope);
@@ -1756,7 +1794,7 @@ extern "C" int clipk_attn_varlen_bwd(const void* qkv, const int* cu_seqlens, con
   p.dout = (const unsigned short*)dout; p.delta = delta; p.dqkv = (unsigned short*)dqkv;
   p.B = B; p.L = max_len; p.H = H; p.D = D; p.scale = q_scale;
   p.cu = cu_seqlens; p.T = T;
-  p.pre_rot = 0;
+  p.pre_rot = (rope && prerotated) ? 1 : 0;
   rc = set_dropout(p, dropout_p, dropout_seed);
   if (rc) return rc;
   ATTN_DISPATCH(launch_bwd, D, rope, p, (hipStream_t)stream);

@@ -148,6 +148,13 @@ class _Lin:
 # =================================================================================================
 # ESM-2 (pre-LN) stack
 # =================================================================================================
+def _varlen_prerot(meta):
+    """Packed batch whose sequences all fit the whole-head attention kernels: q / k are rotated in place by the forward
+    kernel (clipk_attn_varlen_fwd_rot) and the backward runs one kernel per (sequence, head)."""
+    B, L, H, D, mask, rope, eps, seq = meta
+    return PREROTATE_QK and seq is not None and rope is not None and ops.varlen_whole_head_applies(seq[1], D)
+
+
 def _esm_layer_fwd(x, p, meta, keep=True):
     """x: f32 [T,d].  p: dict of this layer's tensors.  Returns y f32 [T,d] and the saved activations."""
     B, L, H, D, mask, rope, eps, seq = meta
@@ -160,7 +167,9 @@ def _esm_layer_fwd(x, p, meta, keep=True):
         x2 = ops.gemm_nt(ctx, p["out"].wb, bias=p["out"].b, residual=x, out_dtype=torch.float32)
         return _esm_layer_ffn_fwd(x, x2, p, eps, keep, (h1, m1, r1, qkv, ctx, lse))
     qkv = ops.gemm_nt(h1, p["qkv"].wb, bias=p["qkv"].b)
-    if seq is not None:                                    # packed variable-length batch: rows [cu[b], cu[b+1])
+    if seq is not None and _varlen_prerot(meta):           # packed batch of short sequences: whole-head kernel, q / k
+        ctx, lse = ops.attn_varlen_fwd_rot_(qkv, seq[0], seq[1], H, D, rope, q_scale=D ** -0.5)   # rotated in place
+    elif seq is not None:                                  # packed variable-length batch: rows [cu[b], cu[b+1])
         ctx, lse = ops.attn_varlen_fwd(qkv, seq[0], seq[1], H, D, rope=rope, q_scale=D ** -0.5)
     elif PREROTATE_QK and rope is not None:
         # RoPE once, in place: the attention kernels would otherwise rotate every K row 5x and every Q row 4x per
@@ -209,7 +218,8 @@ def _esm_layer_bwd(dy, dyb, p, saved, meta, need_dx_bf16, need_dx_f32=True):
     dctx = ops.gemm_nt(dx2b, p["out"].wtb)
     gr["out_w"], gr["out_b"] = _wgrad(dx2b, ctx, p["out"])
     if seq is not None:
-        dqkv = ops.attn_varlen_bwd(qkv, ctx, dctx, lse, seq[0], seq[1], H, D, rope=rope, q_scale=D ** -0.5)
+        dqkv = ops.attn_varlen_bwd(qkv, ctx, dctx, lse, seq[0], seq[1], H, D, rope=rope, q_scale=D ** -0.5,
+                                   prerotated=_varlen_prerot(meta))
     else:
         dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, H, D, key_mask=mask, rope=rope, q_scale=D ** -0.5,
                             prerotated=PREROTATE_QK and rope is not None)

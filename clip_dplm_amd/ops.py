@@ -593,7 +593,32 @@ def attn_varlen_fwd(qkv, cu_seqlens, max_len, H, D, rope=None, q_scale=1.0, drop
     return out, lse
 
 
-def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_len, H, D, rope=None, q_scale=1.0, dropout=None):
+def attn_varlen_fwd_rot_(qkv, cu_seqlens, max_len, H, D, rope, q_scale=1.0):
+    """attn_fwd_rot_ for a packed batch (whole-head kernel, D in {16, 24, 32}, 128 < max_len <= 256): q / k of `qkv`
+    are rotated in place; backward: attn_varlen_bwd(..., prerotated=True)."""
+    _need_cuda(qkv, cu_seqlens)
+    T = qkv.shape[0]
+    B = cu_seqlens.numel() - 1
+    assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous() and qkv.shape == (T, 3 * H * D)
+    assert cu_seqlens.dtype == torch.int32 and cu_seqlens.is_contiguous()
+    out = torch.empty((T, H * D), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((H, T), dtype=torch.float32, device=qkv.device)
+    cos, sin = rope
+    check(_timed("attn_fwd", 0.0,
+                 lambda: _lib().clipk_attn_varlen_fwd_rot(qkv.data_ptr(), cu_seqlens.data_ptr(), cos.data_ptr(),
+                                                          sin.data_ptr(), out.data_ptr(), lse.data_ptr(), B, T,
+                                                          int(max_len), H, D, float(q_scale), _stream())),
+          "clipk_attn_varlen_fwd_rot")
+    return out, lse
+
+
+def varlen_whole_head_applies(max_len: int, D: int) -> bool:
+    """Shapes clipk_attn_varlen_fwd_rot accepts (the whole-head short-sequence kernels)."""
+    return D in (16, 24, 32) and 128 < int(max_len) <= 256
+
+
+def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_len, H, D, rope=None, q_scale=1.0, dropout=None,
+                    prerotated=False):
     _need_cuda(qkv, out, dout, lse, cu_seqlens)
     T = qkv.shape[0]
     B = cu_seqlens.numel() - 1
@@ -604,7 +629,8 @@ def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_len, H, D, rope=None, q
                  lambda: _lib().clipk_attn_varlen_bwd(qkv.data_ptr(), cu_seqlens.data_ptr(), ptr(cos), ptr(sin),
                                                       out.data_ptr(), dout.data_ptr(), lse.data_ptr(), delta.data_ptr(),
                                                       dqkv.data_ptr(), B, T, int(max_len), H, D, float(q_scale),
-                                                      *_drop(dropout), _stream())), "clipk_attn_varlen_bwd")
+                                                      int(bool(prerotated)), *_drop(dropout), _stream())),
+          "clipk_attn_varlen_bwd")
     return dqkv
 
 

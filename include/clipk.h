@@ -327,10 +327,16 @@ int clipk_pool_varlen_bwd(const float* dy, const int* cu_seqlens, float* dx, int
 int clipk_attn_varlen_fwd(const void* qkv, const int* cu_seqlens, const float* rope_cos, const float* rope_sin,
                           void* out, float* lse, int B, int T, int max_len, int H, int D, float q_scale, float dropout_p,
                           uint32_t dropout_seed, void* stream);
+/* clipk_attn_fwd_rot for a packed batch: rotates q / k of every sequence IN PLACE (positions count from the sequence's
+ * first row) while the whole-head kernel stages them, for D in {16, 24, 32} and 128 < max_len <= 256 only
+ * (CLIPK_ERR_UNSUPPORTED otherwise: use clipk_attn_varlen_fwd, which leaves qkv alone).  Its backward is
+ * clipk_attn_varlen_bwd(..., prerotated = 1): one whole-head kernel per (sequence, head) instead of the general pair. */
+int clipk_attn_varlen_fwd_rot(void* qkv, const int* cu_seqlens, const float* rope_cos, const float* rope_sin,
+                              void* out, float* lse, int B, int T, int max_len, int H, int D, float q_scale, void* stream);
 int clipk_attn_varlen_bwd(const void* qkv, const int* cu_seqlens, const float* rope_cos, const float* rope_sin,
                           const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
-                          int B, int T, int max_len, int H, int D, float q_scale, float dropout_p, uint32_t dropout_seed,
-                          void* stream);
+                          int B, int T, int max_len, int H, int D, float q_scale, int prerotated, float dropout_p,
+                          uint32_t dropout_seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimiser step on flat f32 buffers: AdamW (decoupled weight decay, torch.optim.AdamW semantics,

@@ -370,13 +370,24 @@ def attn_varlen_fwd(qkv, cu_seqlens, max_len, H, D, rope=None, q_scale=1.0, drop
     return torch.cat(outs, 0), torch.cat(lses, 1)
 
 
-def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_len, H, D, rope=None, q_scale=1.0, dropout=None):
+def varlen_whole_head_applies(max_len, D):
+    return D in (16, 24, 32) and 128 < int(max_len) <= 256
+
+
+def attn_varlen_fwd_rot_(qkv, cu_seqlens, max_len, H, D, rope, q_scale=1.0):
+    for a, b in _segments(cu_seqlens):                     # rotate every sequence's q / k in place, positions from 0
+        qkv[a:b] = _rope_qk(qkv[a:b].float(), 1, b - a, H, D, (rope[0][: b - a], rope[1][: b - a])).to(BF)
+    return attn_varlen_fwd(qkv, cu_seqlens, max_len, H, D, rope=None, q_scale=q_scale)
+
+
+def attn_varlen_bwd(qkv, out, dout, lse, cu_seqlens, max_len, H, D, rope=None, q_scale=1.0, dropout=None,
+                    prerotated=False):
     gs = []
     for a, b in _segments(cu_seqlens):
         r = None if rope is None else (rope[0][: b - a], rope[1][: b - a])
         gs.append(attn_bwd(qkv[a:b].contiguous(), out[a:b].contiguous(), dout[a:b].contiguous(),
                            lse[:, a:b].reshape(1, H, b - a).contiguous(), 1, b - a, H, D, rope=r, q_scale=q_scale,
-                           dropout=dropout, row0=a, Lstride=max_len))
+                           prerotated=prerotated, dropout=dropout, row0=a, Lstride=max_len))
     return torch.cat(gs, 0)
 
 

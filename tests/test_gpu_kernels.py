@@ -677,6 +677,48 @@ def test_attention_varlen_equals_padded_with_mask(dev, H, D, use_rope, lens):
     assert (gk.float() - gr).abs().max().item() < 8e-3 * max(1.0, gr.abs().max().item())
 
 
+@pytest.mark.parametrize("H,D,lens", [(20, 24, [256, 200, 37, 129, 1, 64]), (4, 32, [130, 255, 3]), (6, 16, [256, 256, 17])])
+def test_attention_varlen_whole_head_kernels(dev, kopt, H, D, lens):
+    """Packed batches of short sequences through the whole-head kernels: clipk_attn_varlen_fwd_rot (q / k rotated in
+    place while staged, positions per sequence) + clipk_attn_varlen_bwd(prerotated = 1) (one fused kernel per
+    (sequence, head)) against the general varlen kernels that rotate at staging; then the same without RoPE, where the
+    dispatcher picks the whole-head kernels by itself (options attn_whole_fwd / attn_fused_bwd = 0: the general ones)."""
+    ops = _ops()
+    B, Lm, T = len(lens), max(lens), sum(lens)
+    g = torch.Generator().manual_seed(T + D)
+    qkv = (torch.randn(T, 3 * H * D, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    dout = (torch.randn(T, H * D, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    cu = torch.zeros(B + 1, dtype=torch.int32)
+    cu[1:] = torch.cumsum(torch.tensor(lens), 0)
+    cu = cu.to(dev)
+    rope = _rope_tables(Lm, D, dev)
+    qs = D ** -0.5
+    o_ref, lse_ref = ops.attn_varlen_fwd(qkv, cu, Lm, H, D, rope=rope, q_scale=qs)
+    g_ref = ops.attn_varlen_bwd(qkv, o_ref, dout, lse_ref, cu, Lm, H, D, rope=rope, q_scale=qs)
+    qr = qkv.clone()
+    o, lse = ops.attn_varlen_fwd_rot_(qr, cu, Lm, H, D, rope, q_scale=qs)
+    # q / k rotated in place, per sequence from position 0; v untouched
+    off = 0
+    for l in lens:
+        exp = ops.rope_qk_(qkv[off:off + l].clone().contiguous(), 1, l, H, D, (rope[0][:l].contiguous(), rope[1][:l].contiguous()))
+        assert torch.equal(qr[off:off + l], exp)
+        off += l
+    assert torch.allclose(o.float(), o_ref.float(), rtol=0, atol=8e-3), (o.float() - o_ref.float()).abs().max()
+    assert torch.allclose(lse, lse_ref, rtol=0, atol=5e-3), (lse - lse_ref).abs().max()
+    gk = ops.attn_varlen_bwd(qr, o, dout, lse, cu, Lm, H, D, rope=rope, q_scale=qs, prerotated=True)
+    assert torch.isfinite(gk.float()).all()
+    assert (gk.float() - g_ref.float()).abs().max().item() < 1.5e-2 * max(1.0, g_ref.float().abs().max().item())
+    # no RoPE: same packed batch, whole-head kernels (default dispatch) vs general kernels
+    o1, l1 = ops.attn_varlen_fwd(qkv, cu, Lm, H, D, rope=None, q_scale=qs)
+    g1 = ops.attn_varlen_bwd(qkv, o1, dout, l1, cu, Lm, H, D, rope=None, q_scale=qs)
+    kopt("attn_whole_fwd", 0)
+    kopt("attn_fused_bwd", 0)
+    o0, l0 = ops.attn_varlen_fwd(qkv, cu, Lm, H, D, rope=None, q_scale=qs)
+    g0 = ops.attn_varlen_bwd(qkv, o0, dout, l0, cu, Lm, H, D, rope=None, q_scale=qs)
+    assert torch.equal(o1, o0) and torch.equal(l1, l0)          # the whole-head forward is bit-identical to the general one
+    assert (g1.float() - g0.float()).abs().max().item() < 8e-3 * max(1.0, g0.float().abs().max().item())
+
+
 def test_pool_varlen(dev):
     ops = _ops()
     lens = [5, 1, 300, 64]
