@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as KF
+from . import ops
 from .encoders import ESM2Encoder, ESM2_SHAPES, TransformerSeqEncoder, pool, pool_packed
 from .loss import clip_loss
 from .modeling_clip import KLayerNorm, KLinear, OptimizedProjectionHead, ProjectionHead
@@ -109,13 +110,14 @@ class ProteinRNACLIP(nn.Module):
 
     def _embed_rna(self, rna_values, rna_mask):
         kpm = None if rna_mask is None else ~rna_mask.bool()
-        if self.pooling == "mean" and FUSED_MEAN_POOL:       # final LayerNorm + masked mean in one kernel
+        if self.pooling == "mean" and FUSED_MEAN_POOL and ops.meanpool_fused_supported(rna_values.shape[-1]):
+            # final LayerNorm + masked mean in one kernel
             return KF.l2_normalize(self.rna_projection(self.rna_model.forward_pooled(rna_values, kpm)))
         hr = self.rna_model(rna_values, src_key_padding_mask=kpm)
         return KF.l2_normalize(self.rna_projection(pool(hr, rna_mask, self.pooling)))
 
     def _embed_protein(self, protein_ids, protein_mask):
-        if self.pooling == "mean" and FUSED_MEAN_POOL:
+        if self.pooling == "mean" and FUSED_MEAN_POOL and ops.meanpool_fused_supported(self.protein_model.hidden_size):
             return KF.l2_normalize(self.protein_projection(self.protein_model.forward_pooled(protein_ids, protein_mask)))
         hp = self.protein_model(protein_ids, attention_mask=protein_mask)
         return KF.l2_normalize(self.protein_projection(pool(hp, protein_mask, self.pooling)))

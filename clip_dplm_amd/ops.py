@@ -400,6 +400,11 @@ def layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=None, dx_add=None, want_f3
     return dx32, dx16, dgamma, dbeta
 
 
+def meanpool_fused_supported(cols: int) -> bool:
+    """Row widths clipk_layernorm_meanpool_fwd takes (its four partial rows must fit 64 KiB of LDS)."""
+    return cols % 4 == 0 and (4 * cols + 4) * 4 <= 65536
+
+
 def layernorm_meanpool_fwd(x, gamma, beta, eps, B, L, mask=None):
     """pooled[b] = mean over the valid rows l of LayerNorm(x[b * L + l]) in one pass (the normalised rows are never
     written).  x f32 / bf16 [B*L, cols]; mask u8 [B*L] (1 = valid) or None.  Returns pooled [B, cols], mean, rstd [B*L] and

@@ -230,6 +230,10 @@ def layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=None, dx_add=None, want_f3
     return (dx if want_f32 else None), dxb, dg, db
 
 
+def meanpool_fused_supported(cols):
+    return cols % 4 == 0 and (4 * cols + 4) * 4 <= 65536
+
+
 def layernorm_meanpool_fwd(x, gamma, beta, eps, B, L, mask=None):
     y, _, mean, rstd = layernorm_fwd(x, gamma, beta, eps)
     m = torch.ones(B * L) if mask is None else mask.view(-1).float()
