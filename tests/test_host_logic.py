@@ -309,3 +309,49 @@ def test_cosine_schedule_and_early_stopping_match_the_reference_loop():
     for loss, ret, stop in seq:
         assert es(loss) is ret and es.early_stop is stop
     assert es.best_loss == 0.9 and es.counter == 2
+
+
+def test_forward_pooled_equals_pooling_the_hidden_states(monkeypatch):
+    """Host wiring of the fused final-LayerNorm + mean pooling (forward_pooled, the `pool` flag of the two stack
+    Functions, the POOL backward): same pooled rows and the same parameter / input gradients as pooling forward()'s
+    [B, L, d] output, with ragged masks; the kernels are emulated (tests/ops_emulator.py)."""
+    import ops_emulator
+    ops_emulator.install(monkeypatch)
+    import clip_dplm_amd as K
+    from clip_dplm_amd.encoders import ESM2_SHAPES, pool
+    ESM2_SHAPES["test_tiny"] = (2, 96, 4, 384)
+    torch.manual_seed(0)
+    B, L = 5, 12
+    lens = torch.tensor([12, 7, 1, 12, 9])
+    mask = (torch.arange(L)[None] < lens[:, None]).long()
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(B, 96, generator=g)
+
+    enc = K.ESM2Encoder(num_layers=2, hidden_size=96, num_heads=4, intermediate_size=384).eval()
+    ids = torch.randint(4, 24, (B, L), generator=g)
+    ref = pool(enc(ids, attention_mask=mask), mask, "mean")
+    (ref * w).sum().backward()
+    gref = {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}
+    enc.zero_grad()
+    got = enc.forward_pooled(ids, attention_mask=mask)
+    (got * w).sum().backward()
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-6)
+    for n, p in enc.named_parameters():
+        if n in gref:
+            assert torch.allclose(p.grad, gref[n], rtol=1e-3, atol=1e-5), n
+
+    rna = K.TransformerSeqEncoder(embed_dim=64, num_layers=1, nhead=8, dim_feedforward=128).eval()
+    x = torch.randn(B, L, 64, generator=g).requires_grad_(True)
+    w2 = torch.randn(B, 64, generator=g)
+    ref = pool(rna(x, src_key_padding_mask=~mask.bool()), mask, "mean")
+    (ref * w2).sum().backward()
+    gx, gref = x.grad.clone(), {n: p.grad.clone() for n, p in rna.named_parameters() if p.grad is not None}
+    x.grad = None
+    rna.zero_grad()
+    got = rna.forward_pooled(x, src_key_padding_mask=~mask.bool())
+    (got * w2).sum().backward()
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(x.grad, gx, rtol=1e-2, atol=1e-4)          # (bf16 gradient streams inside the emulated stack)
+    for n, p in rna.named_parameters():
+        if n in gref:
+            assert torch.allclose(p.grad, gref[n], rtol=1e-2, atol=1e-4), n
