@@ -5,6 +5,8 @@ in include/clipk.h).  There is no CPU fallback: every forward needs device tenso
 """
 from .configuration_hybrid_clip import HybridCLIPConfig, ModelArchitectureConfig, SubConfig, TrainingConfig
 from .encoders import ESM2Encoder, ESM2_SHAPES, TransformerSeqEncoder, pool
+from .esm_integration import (BiologicalDataType, ESMConfig, ESMIntegration, ESMOutput, GeneProjection,
+                              ProteinProjection, create_esm_integration, get_embeddings_batch)
 from .loss import clip_loss
 from .modeling_clip import (CLIPEncoder, DiffMapProteinCLIP, DiffMapProteinCLIPModule, OptimizedCLIPModule,
                             OptimizedProjectionHead, ProjectionHead, RNAProteinCLIP, RNAProteinCLIPModule,
@@ -23,5 +25,6 @@ __all__ = [
     "ContrastiveModel", "CellStateEncoder", "PerturbationEncoder", "TransformerEncoder",
     "ESM2Encoder", "ESM2_SHAPES", "TransformerSeqEncoder", "pool", "clip_loss", "FlatParams", "FusedAdamW",
     "cosine_annealing_lr", "CosineAnnealingLR", "EarlyStopping", "train_epoch", "evaluate_model", "save_checkpoint",
-    "load_checkpoint",
+    "load_checkpoint", "ESMConfig", "ESMIntegration", "ESMOutput", "BiologicalDataType", "ProteinProjection",
+    "GeneProjection", "create_esm_integration", "get_embeddings_batch",
 ]

@@ -228,6 +228,7 @@ static int gemm_nt_one(const clipk_gemm_args* a, void* stream);
 extern "C" int clipk_gemm_nt(const clipk_gemm_args* a, void* stream) {
   if (!a || !a->A || !a->B || !a->C) return CLIPK_ERR_BAD_ARG;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return CLIPK_ERR_BAD_ARG;
+  if (!(a->drop_p >= 0.f) || a->drop_p >= 1.f) return CLIPK_ERR_BAD_ARG;      // nn.Dropout(p = 1) zeroes: not a mask
   const long c_elt = a->c_dtype == CLIPK_F32 ? 4 : 2, r_elt = a->r_dtype == CLIPK_F32 ? 4 : 2;
   long row_bytes = a->ldc * c_elt;
   if (a->out_preact && a->ldp * 2 > row_bytes) row_bytes = a->ldp * 2;

@@ -459,6 +459,7 @@ extern "C" int clipk_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, c
                                    void* workspace, size_t workspace_bytes, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || rows <= 0 || cols <= 0 || !workspace) return CLIPK_ERR_BAD_ARG;
   if (act != CLIPK_ACT_NONE && !beta) return CLIPK_ERR_BAD_ARG;
+  if (!(drop_p >= 0.f) || drop_p >= 1.f) return CLIPK_ERR_BAD_ARG;
   if ((cols & 3) || (ldx & 3) || (lddy & 3) || (lddx & 3)) return CLIPK_ERR_UNSUPPORTED;
   if (dx_add && dx_add_dtype == CLIPK_BF16 && !(dy_dtype == CLIPK_BF16 && x_dtype == CLIPK_F32)) return CLIPK_ERR_UNSUPPORTED;
   const int blocks = ln_blocks(rows, cols);

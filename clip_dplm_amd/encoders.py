@@ -126,12 +126,24 @@ def _join_side(*tensors):
                 t.record_stream(cur)
 
 
+def _bucket_begin(module):
+    """A forward of the stack that will be differentiated: one more backward has to finish before the stack's gradient
+    bucket is final (micro-batches, a stack applied twice in one forward, several backward() calls per optimiser step).
+    A bucket that a sharded FusedAdamW has already sent in this step is taken back (`_grad_bucket_begin`)."""
+    module._bucket_pending = getattr(module, "_bucket_pending", 0) + 1
+    cb = getattr(module, "_grad_bucket_begin", None)
+    if cb is not None:
+        cb()
+
+
 def _bucket_done(module, grads):
     """End of a stack's backward: with every parameter gradient written straight into the flat .grad buffer (all
-    returned grads None) the stack's gradient bucket is final, and a sharded FusedAdamW may start its reduce-scatter on
-    a side stream under the rest of the backward (optim.FusedAdamW._reduce_bucket)."""
+    returned grads None) and no other backward of this stack outstanding, the stack's gradient bucket is final, and a
+    sharded FusedAdamW may start its reduce-scatter on a side stream under the rest of the backward
+    (optim.FusedAdamW._reduce_bucket)."""
+    module._bucket_pending = max(0, getattr(module, "_bucket_pending", 0) - 1)
     cb = getattr(module, "_grad_bucket_done", None)
-    if cb is not None and all(g is None for g in grads):
+    if cb is not None and module._bucket_pending == 0 and all(g is None for g in grads):
         cb()
 
 
@@ -251,6 +263,8 @@ class EsmStackFn(torch.autograd.Function):
                           mask_token_id=module.mask_token_id if module.token_dropout else -1)
         layers, saved = [], []
         need_bwd = any(ctx.needs_input_grad)        # frozen encoder (3_esm_integration.py:83-84): keep no activations
+        if need_bwd:
+            _bucket_begin(module)
         for i in range(nl):
             t = flat[3 + 12 * i: 3 + 12 * (i + 1)]
             caches = module.layer_caches[i]
@@ -356,6 +370,8 @@ ESM2_SHAPES = {                      # (layers, hidden, heads, ffn) — SURVEY A
     "esm2_t12_35M_UR50D": (12, 480, 20, 1920),
     "esm2_t30_150M_UR50D": (30, 640, 20, 2560),
     "esm2_t33_650M_UR50D": (33, 1280, 20, 5120),
+    "esm2_t36_3B_UR50D": (36, 2560, 40, 10240),         # the other two names triple_flow/1_config.py:177-181 accepts
+    "esm2_t48_15B_UR50D": (48, 5120, 40, 20480),
 }
 
 
@@ -584,6 +600,8 @@ class PostLNStackFn(torch.autograd.Function):
         fin_w, fin_b = flat[0], flat[1]
         layers, saved = [], []
         need_bwd = any(ctx.needs_input_grad)
+        if need_bwd:
+            _bucket_begin(module)
         for i in range(nl):
             t = flat[2 + 12 * i: 2 + 12 * (i + 1)]
             c = module.layer_caches[i]
@@ -671,6 +689,8 @@ class TransformerSeqEncoder(nn.Module):
         # attention kernels / GEMM epilogues from a per-call seed (torch's CPU generator: torch.manual_seed applies);
         # the backward recomputes the masks, nothing is stored.  Eval mode and p = 0 are the parity setting.
         self.dropout = float(dropout)
+        if not 0.0 <= self.dropout < 1.0:
+            raise ValueError(f"dropout must be in [0, 1), got {dropout} (the kernels' masks scale by 1 / (1 - p))")
         self.activation, self.eps = activation, layer_norm_eps
         self.final_eps = layer_norm_eps if final_eps is None else final_eps
         self.layers = nn.ModuleList([_PostLayerParams(embed_dim, dim_feedforward, layer_norm_eps)

@@ -11,8 +11,9 @@ ESM-2 alphabet replaces AutoTokenizer.
 """
 from __future__ import annotations
 
+from dataclasses import dataclass
 from enum import Enum
-from typing import List, Optional
+from typing import List, Optional, Union
 
 import torch
 import torch.nn as nn
@@ -26,14 +27,76 @@ ESM2_ALPHABET = ["<cls>", "<pad>", "<eos>", "<unk>", "L", "A", "G", "V", "S", "E
 _TOK = {t: i for i, t in enumerate(ESM2_ALPHABET)}
 
 
-class BiologicalDataType(Enum):          # triple_flow/1_config.py (only the two members the path reads)
-    PROTEIN_SEQUENCE = "protein"
-    GENE_SEQUENCE = "gene"
+class BiologicalDataType(Enum):          # triple_flow/1_config.py:57-68, same members and values
+    GENE_EXPRESSION = "gene_expression"
+    PROTEIN_SEQUENCE = "protein_sequence"
+    PERTURBATION = "perturbation"
+    PSEUDOTIME = "pseudotime"
+    CONNECTIVITY = "connectivity"
+    GENE_SEQUENCE = "gene_sequence"      # extension: a readable name for "anything that is not a protein sequence"
+                                         # (get_embeddings :124-127 sends every other member to the gene projection)
+
+
+@dataclass
+class ESMConfig:
+    """triple_flow/1_config.py:153-183, same fields and defaults.  `model_name` selects an ESM-2 SHAPE from
+    clip_dplm_amd.ESM2_SHAPES (a superset of the reference's three whitelisted names: BASELINE's ESM-2-35M is not in
+    that whitelist); nothing is fetched by name.  `num_attention_heads`, `dropout` and
+    `use_sequence_context` are declared by the reference and read by nothing on the path (kept for construction
+    compatibility)."""
+    model_name: str = "esm2_t33_650M_UR50D"
+    esm_dim: int = 1280
+    protein_dim: int = 512
+    gene_dim: int = 512
+    num_attention_heads: int = 8
+    dropout: float = 0.1
+    use_sequence_context: bool = True
+    max_sequence_length: int = 1024
+    tokenizer_path: Optional[str] = None
+
+    def validate_model(self):
+        """Same error as the reference (:175-183) for a name without a known shape."""
+        if self.model_name not in ESM2_SHAPES:
+            raise ValueError(f"Invalid ESM model: {self.model_name}")
+
+
+_SPECIALS = [t for t in ESM2_ALPHABET if len(t) > 1]
+
+
+def _encode(seq: str) -> List[int]:
+    """EsmTokenizer's splitting (checked against transformers.EsmTokenizer built from this alphabet,
+    tools/make_golden.py gen_esm_integration): vocabulary tokens are matched greedily wherever they occur ('<mask>' in
+    the text is the mask token), whitespace separates and is dropped, and every maximal run of other characters
+    becomes ONE <unk>."""
+    out, i, n, in_unk = [], 0, len(seq), False
+    while i < n:
+        c = seq[i]
+        if c.isspace():
+            in_unk = False
+            i += 1
+            continue
+        if c == "<":
+            hit = next((t for t in _SPECIALS if seq.startswith(t, i)), None)
+            if hit is not None:
+                out.append(_TOK[hit])
+                i += len(hit)
+                in_unk = False
+                continue
+        if c in _TOK:
+            out.append(_TOK[c])
+            in_unk = False
+        elif not in_unk:
+            out.append(_TOK["<unk>"])
+            in_unk = True
+        i += 1
+    return out
 
 
 def tokenize(sequences: List[str], max_length: int = 1024):
-    """<cls> + residues + <eos>, padded with <pad>; truncation like tokenizer(..., truncation=True, max_length)."""
-    rows = [[0] + [_TOK.get(c, 3) for c in s[: max_length - 2]] + [2] for s in sequences]
+    """tokenizer(sequences, padding=True, truncation=True, max_length=...) of 3_esm_integration.py:104-110: <cls> +
+    tokens + <eos>, the TOKENS cut to max_length - 2, rows padded with <pad> to the longest.  Returns (ids, mask)."""
+    keep = max(int(max_length) - 2, 0)
+    rows = [[0] + _encode(s)[:keep] + [2] for s in sequences]
     L = max(len(r) for r in rows)
     ids = torch.full((len(rows), L), 1, dtype=torch.long)
     mask = torch.zeros((len(rows), L), dtype=torch.long)
@@ -119,37 +182,78 @@ class GeneProjection(nn.Module):
         return p[6](p[5](p[4](h)))
 
 
-class ESMOutput:
-    def __init__(self, embeddings, attention_weights=None):
-        self.embeddings, self.attention_weights = embeddings, attention_weights
+@dataclass
+class ESMOutput:                         # 3_esm_integration.py:39-43
+    embeddings: torch.Tensor
+    attention_weights: Optional[torch.Tensor] = None
 
 
 class ESMIntegration(nn.Module):
-    """3_esm_integration.py:45-135 with an explicit-shape ESM-2 backbone (frozen, like :83-84)."""
+    """3_esm_integration.py:45-135: frozen ESM-2 (:83-84) + the two per-token projections, same constructor
+    (`ESMIntegration(config: ESMConfig)`), attributes (`config`, `model`, `protein_projection`, `gene_projection`,
+    `cache`) and `get_embeddings` behaviour — including its cache, which is keyed on the sequences only (:100-102: a
+    second call with the same sequences and another data_type returns the first call's result).
 
-    def __init__(self, model_name: str = "esm2_t33_650M_UR50D", protein_dim: int = 512, gene_dim: int = 512,
-                 max_sequence_length: int = 1024, esm_state_dict=None):
+    Differences forced by the environment: the backbone is built from the explicit shape `config.model_name` names and
+    initialised randomly (`AutoModel.from_pretrained(<name>)` of :77 is a network fetch); `esm_state_dict` (an
+    `EsmModel.state_dict()`, e.g. loaded by the caller from a local checkpoint) fills it.  The tokenizer is the built-in
+    33-token ESM-2 alphabet (`tokenize`).  `ESMIntegration("esm2_t12_35M_UR50D", protein_dim=...)` — the keyword form of
+    earlier rounds — is still accepted and builds the ESMConfig itself."""
+
+    def __init__(self, config: Union[ESMConfig, str, None] = None, esm_state_dict=None, **kwargs):
         super().__init__()
-        self.model = ESM2Encoder.from_name(model_name)
+        if config is None or isinstance(config, str):
+            name = config if config is not None else kwargs.pop("model_name", ESMConfig.model_name)
+            kwargs.setdefault("esm_dim", ESM2_SHAPES[name][1] if name in ESM2_SHAPES else ESMConfig.esm_dim)
+            config = ESMConfig(model_name=name, **kwargs)
+        elif kwargs:
+            raise TypeError(f"unexpected keyword arguments next to an ESMConfig: {sorted(kwargs)}")
+        config.validate_model()
+        self.config = config
+        hidden = ESM2_SHAPES[config.model_name][1]
+        if hidden != config.esm_dim:
+            raise ValueError(f"config.esm_dim = {config.esm_dim} but {config.model_name} has hidden size {hidden}")
+        self._setup_esm(esm_state_dict)
+        self.protein_projection = ProteinProjection(esm_dim=config.esm_dim, output_dim=config.protein_dim)
+        self.gene_projection = GeneProjection(esm_dim=config.esm_dim, output_dim=config.gene_dim)
+        self.cache = {}
+
+    def _setup_esm(self, esm_state_dict=None) -> None:
+        self.model = ESM2Encoder.from_name(self.config.model_name)
         if esm_state_dict is not None:
             self.model.load_state_dict(esm_state_dict, strict=False)
         for p in self.model.parameters():
             p.requires_grad = False
-        esm_dim = ESM2_SHAPES[model_name][1]
-        self.protein_projection = ProteinProjection(esm_dim, protein_dim)
-        self.gene_projection = GeneProjection(esm_dim, gene_dim)
-        self.max_sequence_length = max_sequence_length
-        self.cache = {}
+
+    @property
+    def max_sequence_length(self) -> int:
+        return self.config.max_sequence_length
 
     @torch.no_grad()
     def get_embeddings(self, sequences: List[str], data_type: BiologicalDataType) -> ESMOutput:
         key = str(hash(tuple(sequences)))
         if key in self.cache:
             return self.cache[key]
-        ids, mask = tokenize(sequences, self.max_sequence_length)
+        ids, mask = tokenize(sequences, self.config.max_sequence_length)
         dev = next(self.model.parameters()).device
         h = self.model(ids.to(dev), attention_mask=mask.to(dev))
         proj = self.protein_projection if data_type == BiologicalDataType.PROTEIN_SEQUENCE else self.gene_projection
-        out = ESMOutput(proj(h), None)
+        out = ESMOutput(embeddings=proj(h), attention_weights=None)       # outputs.attentions is None at :129 too
         self.cache[key] = out
         return out
+
+
+def create_esm_integration(model_name: str = "esm2_t33_650M_UR50D", esm_state_dict=None, **kwargs) -> ESMIntegration:
+    """3_esm_integration.py:215-228: ESMConfig(model_name=..., **kwargs) -> ESMIntegration."""
+    return ESMIntegration(ESMConfig(model_name=model_name, **kwargs), esm_state_dict=esm_state_dict)
+
+
+def get_embeddings_batch(sequences: List[str], esm_model: ESMIntegration, data_type: BiologicalDataType,
+                         batch_size: int = 32) -> torch.Tensor:
+    """3_esm_integration.py:231-245: get_embeddings over slices of `batch_size` sequences, concatenated along dim 0.
+    As in the reference every slice is padded to ITS longest sequence, so the slices must tokenise to one length for the
+    concatenation to be defined (torch.cat raises otherwise, there and here)."""
+    embeddings = []
+    for i in range(0, len(sequences), batch_size):
+        embeddings.append(esm_model.get_embeddings(sequences[i:i + batch_size], data_type).embeddings)
+    return torch.cat(embeddings, dim=0)

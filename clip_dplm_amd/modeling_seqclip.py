@@ -49,8 +49,9 @@ class RNARBPCLIPModel(nn.Module):
 
     def __init__(self, rna_dim=120, rbp_dim=1280, projection_dim=512, dropout: float = 0.1):
         super().__init__()
-        # `dropout` is the notebook's nn.TransformerEncoderLayer default (0.1); the encoder stacks raise in training
-        # mode while it is > 0 (see TransformerSeqEncoder): pass dropout=0.0 to train on the HIP path.
+        # `dropout` is the notebook's nn.TransformerEncoderLayer default (0.1): in train() mode the post-LN stack
+        # applies it at the layer's four sites with counter-based masks (TransformerSeqEncoder); parity
+        # and benchmark runs use eval() or dropout=0.0.
         self.rna_encoder = RNARBPCLIPEncoder(rna_dim, dropout=dropout)
         self.rbp_encoder = RNARBPCLIPEncoder(rbp_dim, dropout=dropout)
         self.rna_projection = RNARBPCLIPProjectionHead(rna_dim, projection_dim)
@@ -86,10 +87,11 @@ class ProteinRNACLIP(nn.Module):
     def __init__(self, esm: str = "esm2_t12_35M_UR50D", rna_dim: int = 768, rna_layers: int = 6, rna_heads: int = 8,
                  rna_ffn: int = 2048, rna_act: str = "gelu", projection_dim: int = 512,
                  logit_scale_init_value: float = 2.6592, layer_norm_eps: float = 1e-12, pooling: str = "mean",
-                 initializer_range: float = 0.02, freeze_protein_encoder: bool = False):
+                 initializer_range: float = 0.02, freeze_protein_encoder: bool = False, rna_dropout: float = 0.0):
         super().__init__()
         self.protein_model = ESM2Encoder.from_name(esm, initializer_range=initializer_range)
-        self.rna_model = TransformerSeqEncoder(rna_dim, rna_layers, rna_heads, rna_ffn, rna_act, layer_norm_eps)
+        self.rna_model = TransformerSeqEncoder(rna_dim, rna_layers, rna_heads, rna_ffn, rna_act, layer_norm_eps,
+                                               dropout=rna_dropout)
         for m in self.rna_model.modules():
             if isinstance(m, nn.Linear):
                 nn.init.normal_(m.weight, 0.0, initializer_range)
@@ -107,6 +109,31 @@ class ProteinRNACLIP(nn.Module):
         if freeze_protein_encoder:                       # triple_flow/3_esm_integration.py:83-84
             for p in self.protein_model.parameters():
                 p.requires_grad_(False)
+
+    @classmethod
+    def from_config(cls, config, esm: str = "esm2_t12_35M_UR50D", architecture: str = "transformer",
+                    freeze_protein_encoder: bool = False, **overrides):
+        """Build the model a `HybridCLIPConfig` describes (run1/configuration_hybrid_clip.py:93-166): the RNA tower is
+        `config.architectures[architecture]` (a `ModelArchitectureConfig`, :68-79; the "transformer" default of
+        :153-157 is BASELINE's 6 x 768 / 8 heads / 2048 / gelu / eps 1e-12), the heads project to
+        `config.projection_dim`, the temperature starts at `config.logit_scale_init_value` and `config.use_mean_pooling`
+        (:109, declared and never read by the reference, App. A-18) selects masked-mean pooling, else position 0.  The
+        protein tower is the ESM-2 shape `esm` (the config has no ESM section).  `arch.dropout` (0.1) is
+        nn.TransformerEncoderLayer's dropout and acts in train() mode only."""
+        arch = config.architectures[architecture]
+        if arch.type != "transformer":
+            raise ValueError(f"architectures[{architecture!r}].type = {arch.type!r}: the sequence tower is a transformer "
+                             f"(the 'mlp' family is RNAProteinCLIPModule / DiffMapProteinCLIPModule)")
+        kw = dict(esm=esm, rna_dim=arch.hidden_size, rna_layers=arch.num_layers, rna_heads=arch.attention_heads or 8,
+                  rna_ffn=arch.intermediate_size or 4 * arch.hidden_size, rna_act=arch.hidden_act,
+                  projection_dim=config.projection_dim, logit_scale_init_value=config.logit_scale_init_value,
+                  layer_norm_eps=arch.layer_norm_eps, pooling="mean" if config.use_mean_pooling else "first",
+                  initializer_range=arch.initializer_range, freeze_protein_encoder=freeze_protein_encoder,
+                  rna_dropout=arch.dropout)
+        kw.update(overrides)
+        model = cls(**kw)
+        model.config = config
+        return model
 
     def _embed_rna(self, rna_values, rna_mask):
         kpm = None if rna_mask is None else ~rna_mask.bool()

@@ -122,7 +122,9 @@ class FusedAdamW:
         self.rank = dist.get_rank(group) if group is not None else 0
         # parameter order of module.parameters() (what torch.optim.AdamW(model.parameters()) would index): the flat
         # buffer may store them in another order (fused qkv groups, buckets)
-        self.param_order = [p for p in module.parameters() if p.requires_grad]
+        # - frozen ones included, as torch.optim.AdamW(model.parameters()) does (triple_flow/5_training.py:128 over a
+        # model whose ESM parameters are frozen, 3_esm_integration.py:83-84); they get an index and never any state
+        self.param_order = list(module.parameters())
         self.flat = FlatParams(module, self.world)
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
@@ -150,10 +152,24 @@ class FusedAdamW:
             for b, (_, _, root) in enumerate(self.flat.buckets):
                 if root is not None:
                     root._grad_bucket_done = (lambda b=b: self._reduce_bucket(b))
+                    root._grad_bucket_begin = (lambda b=b: self._retract_bucket(b))
 
     def zero_grad(self):
         self.flat.zero_grad()
         self._reduced = [False] * len(self.flat.buckets)
+        for (_, _, root) in self.flat.buckets:
+            if root is not None:
+                root._bucket_pending = 0     # forwards that were never differentiated must not block the next step
+
+    def _retract_bucket(self, b: int) -> None:
+        """A stack whose bucket was already sent in this step is about to produce more gradient (second backward()
+        before step(): gradient accumulation): the sent result is dropped and the bucket is reduced again when it is
+        final; the collective still reading flat.grad must finish before the new backward writes into it."""
+        if not self._reduced[b]:
+            return
+        if self._comm is not None:
+            torch.cuda.current_stream().wait_stream(self._comm)
+        self._reduced[b] = False
 
     # ---- gradient reduce-scatter of one bucket (called from the encoder stacks' backward, or from step())
     def _reduce_bucket(self, b: int) -> None:
@@ -164,8 +180,9 @@ class FusedAdamW:
         dst = self.gshard[off:off + (hi - lo)]
         src = self.flat.grad[s0:s1]
         if not self._nccl:                                   # gloo (CPU tests) has no reduce_scatter
-            dist.all_reduce(src, group=self.group)
-            dst.copy_(self.flat.grad[lo:hi])
+            tmp = src.clone()                                # flat.grad stays this rank's own sum (see _retract_bucket)
+            dist.all_reduce(tmp, group=self.group)
+            dst.copy_(tmp[lo - s0:hi - s0])
         else:
             cur = torch.cuda.current_stream()
             stream = self._comm if self._comm is not None else cur
@@ -240,9 +257,10 @@ class FusedAdamW:
         off = {id(p): o for p, o in zip(self.flat.params, self.flat.offsets)}
         state = {}
         for i, p in enumerate(self.param_order):
-            o = off[id(p)]
+            o = off.get(id(p))
             st = {}
-            if self.step_count > 0:                      # torch creates per-parameter state lazily at the first step
+            if o is not None and self.step_count > 0:    # torch creates per-parameter state lazily at the first step,
+                                                         # and never for a parameter without a gradient (frozen)
                 st = {"step": torch.tensor(float(self.step_count)),
                       "exp_avg": m[o:o + p.numel()].view(p.shape).clone(),
                       "exp_avg_sq": v[o:o + p.numel()].view(p.shape).clone()}
@@ -283,7 +301,7 @@ class FusedAdamW:
         self.v.zero_()
         for i, p in enumerate(self.param_order):
             st = sd["state"].get(g["params"][i])
-            if not st:
+            if not st or id(p) not in off:               # no state yet, or a frozen parameter's entry: nothing to load
                 continue
             steps.add(int(round(float(st["step"]))))
             o, n = off[id(p)], p.numel()

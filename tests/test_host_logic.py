@@ -355,3 +355,101 @@ def test_forward_pooled_equals_pooling_the_hidden_states(monkeypatch):
     for n, p in rna.named_parameters():
         if n in gref:
             assert torch.allclose(p.grad, gref[n], rtol=1e-2, atol=1e-4), n
+
+
+def test_fused_adamw_state_dict_with_frozen_submodule(monkeypatch):
+    """the reference builds torch.optim.AdamW(model.parameters()) over ALL parameters, frozen encoder ones
+    included (triple_flow/5_training.py:128 on a model whose ESM parameters are frozen, 3_esm_integration.py:83-84), so
+    `param_groups[0]['params']` indexes every parameter and only the trainable ones carry state.  Both directions."""
+    ops_emulator.install(monkeypatch)
+    import clip_dplm_amd as K
+    torch.manual_seed(0)
+    m, ref = _small_clip(K), _small_clip(K)
+    ref.load_state_dict(m.state_dict())
+    for mm in (m, ref):
+        for p in mm.rna_model.parameters():            # a frozen tower in the middle of module.parameters()
+            p.requires_grad_(False)
+    opt = K.FusedAdamW(m, lr=1e-3, weight_decay=0.01, max_grad_norm=None)
+    topt = torch.optim.AdamW(ref.parameters(), lr=1e-3, weight_decay=0.01)
+    g = torch.Generator().manual_seed(1)
+    a, b = torch.randn(16, 32, generator=g), torch.randn(16, 32, generator=g)
+    for _ in range(2):
+        opt.zero_grad(); m.loss(a, b, symmetric=True).backward(); opt.step()
+        topt.zero_grad(); ref.loss(a, b, symmetric=True).backward(); topt.step()
+    fs, ts = opt.state_dict(), topt.state_dict()
+    n_all = len(list(m.parameters()))
+    assert fs["param_groups"][0]["params"] == ts["param_groups"][0]["params"] == list(range(n_all))
+    assert set(fs["state"]) == set(ts["state"])                   # no entries for the frozen parameters
+    frozen = {i for i, p in enumerate(m.parameters()) if not p.requires_grad}
+    assert frozen and not (frozen & set(fs["state"]))
+    for i, ent in ts["state"].items():
+        assert torch.allclose(fs["state"][i]["exp_avg"], ent["exp_avg"], rtol=1e-4, atol=1e-7), i
+    # torch -> fused and fused -> torch
+    m2 = _small_clip(K)
+    m2.load_state_dict(ref.state_dict())
+    for p in m2.rna_model.parameters():
+        p.requires_grad_(False)
+    opt2 = K.FusedAdamW(m2, lr=1.0, max_grad_norm=None)
+    opt2.load_state_dict(ts)
+    assert opt2.step_count == 2
+    opt2.zero_grad(); m2.loss(a, b, symmetric=True).backward(); opt2.step()
+    topt.zero_grad(); ref.loss(a, b, symmetric=True).backward(); topt.step()
+    for (n, p), (_, q) in zip(m2.named_parameters(), ref.named_parameters()):
+        assert torch.allclose(p, q, rtol=1e-4, atol=1e-5), n
+    ref3 = _small_clip(K)
+    for p in ref3.rna_model.parameters():
+        p.requires_grad_(False)
+    torch.optim.AdamW(ref3.parameters(), lr=1e-3).load_state_dict(fs)   # torch accepts the group size
+
+
+def _one_rank_gloo(tmp_path):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"file://{tmp_path}/pg_init", rank=0, world_size=1)
+    return dist
+
+
+@pytest.mark.parametrize("mode", ["micro_batches", "two_backwards", "micro_batches+two_backwards"])
+def test_overlapped_bucket_reduce_waits_for_every_backward(monkeypatch, tmp_path, mode):
+    """with `overlap=True` the encoder stacks start their bucket's reduce-scatter from inside the
+    backward.  When a stack runs backward more than once per optimiser step (micro-batches; gradient accumulation over
+    several backward() calls) the bucket must be sent once, with the complete gradient: overlap == no overlap, bit for
+    bit, and the flat gradient the step saw is the sum of every backward."""
+    ops_emulator.install(monkeypatch)
+    import clip_dplm_amd as K
+    from clip_dplm_amd.encoders import ESM2_SHAPES
+    dist = _one_rank_gloo(tmp_path)
+    try:
+        ESM2_SHAPES["test_tiny"] = (2, 96, 4, 384)
+        g = torch.Generator().manual_seed(9)
+        ids = torch.randint(4, 24, (8, 10), generator=g)
+        rna = torch.randn(8, 10, 64, generator=g)
+        res = {}
+        for overlap in (False, True):
+            torch.manual_seed(0)
+            m = K.ProteinRNACLIP(esm="test_tiny", rna_dim=64, rna_layers=1, rna_heads=8, rna_ffn=128,
+                                 projection_dim=32).eval()
+            if "micro_batches" in mode:
+                m.micro_batches = 2
+            opt = K.FusedAdamW(m, lr=1e-3, weight_decay=0.01, max_grad_norm=1.0, group=dist.group.WORLD, overlap=overlap)
+            sent = []
+            orig = opt._reduce_bucket
+            opt._reduce_bucket = lambda b, _o=orig: (sent.append((b, opt._reduced[b])), _o(b))[1]
+            if overlap:                                   # the callbacks captured the bound method: re-point them
+                for b, (_, _, root) in enumerate(opt.flat.buckets):
+                    if root is not None:
+                        root._grad_bucket_done = (lambda b=b: opt._reduce_bucket(b))
+            opt.zero_grad()
+            m.loss(rna, ids).backward()
+            if "two_backwards" in mode:
+                m.loss(rna.flip(0), ids).backward()
+            gfull = opt.flat.grad.clone()
+            nsq = opt.step().clone()
+            res[overlap] = (torch.cat([p.detach().reshape(-1) for p in opt.flat.params]), gfull, nsq, opt.gshard.clone())
+        p0, g0, n0, s0 = res[False]
+        p1, g1, n1, s1 = res[True]
+        assert torch.equal(g0, g1)
+        assert torch.equal(s0, s1), "the reduced gradient shard differs: a bucket was sent before it was final"
+        assert torch.equal(n0, n1) and torch.equal(p0, p1)
+        assert torch.equal(s1, g1)                        # world 1: the shard IS the whole flat gradient
+    finally:
+        dist.destroy_process_group()
