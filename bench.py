@@ -28,6 +28,9 @@ Other BASELINE configurations (bench lines of their own, not the driver's defaul
     --config c4                frozen ESM-2-650M (33 x 1280) at L = 1024, B_local = 256 + trained RNA tower / heads
     --config c3sim             fused similarity + CE at one rank's config-3 shape (512 x 4096 x 512): achieved GB/s
     --config c5                ICNN transport system 512 / [512, 256], B = 4096 (eval transport maps)
+    --config c1                old/clip.py tiny dual encoder (2 layers, d = 128) on 256 random pairs
+Every line carries `parity` (GPU vs the CPU oracle on the same inputs) and, where BASELINE.md §3 promises one, a
+`cpu_baseline`.
 """
 from __future__ import annotations
 
@@ -50,7 +53,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c2", choices=["c2", "c3sim", "c4", "c5"])
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3sim", "c4", "c5", "stub"],
+                    help="stub: the launch / rendezvous / timing / output plumbing of the multi-rank path on a trivial "
+                         "CPU workload over gloo (tests/test_host_logic.py); never a measurement")
     ap.add_argument("--batch", type=int, default=None, help="pairs per GPU (default: 1024 for c2, 256 for c4, 4096 for c5)")
     ap.add_argument("--seq-len", type=int, default=None)
     ap.add_argument("--esm", default=None)
@@ -115,10 +120,14 @@ def cpu_baseline(model_sd, cfg, L, sample_b=32, steps=3, budget_s=75.0):
     from oracle import model_ref
     ncores = host_threads()
     torch.set_num_threads(ncores)
-    sd = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in model_sd.items()}
+    frozen = cfg.get("frozen_prefix")
+    sd = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point() and not (frozen and k.startswith(frozen)))
+          for k, v in model_sd.items()}
     params = [v for v in sd.values() if v.requires_grad]
     opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01)
     rna, ids = synth_batch(sample_b, L, cfg["rna_dim"], "cpu", 4321)
+    if cfg.get("rna_len") and cfg["rna_len"] != L:
+        rna = rna[:, : cfg["rna_len"]].contiguous()
     times, loss0 = [], None
     t_start = time.perf_counter()
     for it in range(steps + 1):
@@ -136,6 +145,7 @@ def cpu_baseline(model_sd, cfg, L, sample_b=32, steps=3, budget_s=75.0):
         print(f"[cpu_baseline] step {it}: {times[-1]:.2f} s on {ncores} threads", file=sys.stderr, flush=True)
         if time.perf_counter() - t_start > budget_s:      # bounded sample: never hold the bench for minutes
             break
+    steps = len(times) - 1
     timed = sorted(times[1:] if len(times) > 1 else times)   # drop the warm-up step when there is more than one
     dt = timed[len(timed) // 2]                              # median
     return ({"value": round(sample_b / dt, 3), "unit": "seq-pairs/s", "cores": ncores, "kind": "port",
@@ -144,16 +154,40 @@ def cpu_baseline(model_sd, cfg, L, sample_b=32, steps=3, budget_s=75.0):
                        f"{dt:.2f} s/step"}, loss0)
 
 
+GEMM_SOURCES = ("gemm_nt.hip", "gemm_nt_v2.hip", "gemm_nt_v3.hip", "gemm_epilogue.h", "common.h")
+
+
+def gemm_source_hash() -> str:
+    """sha256 over the sources of the dominant kernel (csrc/gemm_nt*.hip + the shared epilogue / common headers): a PMC
+    traffic figure is only attached to a bench line whose kernels are the ones it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in GEMM_SOURCES:
+        with open(os.path.join(ROOT, "clip_dplm_amd", "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def traffic_key(config, B, L, lengths="full", esm=None) -> str:
+    return f"{config}_B{B}_L{L}_{lengths}" + (f"_{esm}" if esm else "")
+
+
 def load_traffic(workload_key):
-    """HBM-side bytes per clipk_gemm_nt launch from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py)."""
+    """HBM-side bytes per clipk_gemm_nt launch from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py), for
+    exactly this workload (config, batch, length, length mode, encoder) — and only while the GEMM sources are the ones
+    the passes ran on.  Returns (entry or None, stale flag)."""
     path = os.path.join(ROOT, "profiles", "traffic_gemm_nt.json")
     try:
         with open(path) as f:
             t = json.load(f)
     except (OSError, ValueError):
-        return None
+        return None, False
     e = t.get(workload_key)
-    return e
+    if e is None:
+        return None, False
+    if e.get("source_sha16") != gemm_source_hash():
+        return None, True
+    return e, False
 
 
 # ====================================================================================================== c2 / c4
@@ -199,6 +233,7 @@ def bench_clip(args):
     _enc.WGRAD_SIDE_STREAM = args.wgrad_stream
     nl, d, h, f = ESM2_SHAPES[esm]
     want_cpu = rank == 0 and world == 1 and not c4 and not (args.no_cpu_baseline and args.no_parity)
+    want_c4_cpu = rank == 0 and world == 1 and c4 and not (args.no_cpu_baseline and args.no_parity)
     sd_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if want_cpu else None
 
     # ---- parity object, GPU side: step-0 loss of a fixed 32-pair sub-batch on the initial weights (eval mode == train
@@ -321,12 +356,26 @@ def bench_clip(args):
     out["step_mfu"] = {"algorithmic_tflop_per_step": round(step_tflop, 2),
                        "achieved_tflops": round(step_tflop / (dt / args.steps), 1),
                        "frac_of_bf16_peak": round(step_tflop / (dt / args.steps) / MFMA_BF16_PEAK_TFLOPS, 4)}
+    if ragged:
+        # the REAL tokens' work: per sequence and layer (8d^2 + 4df) * len + 4 d len^2 (attention is quadratic in the
+        # sequence's own length); the padded figure above counts positions that hold no token
+        lpf, lrf = lp.double(), lr.double()
+        real_esm = float(((8 * d * d + 4 * d * f) * lpf + 4 * d * lpf * lpf).sum()) * nl * (1 if freeze else 3)
+        real_rna = float(((8 * 768 * 768 + 4 * 768 * 2048) * lrf + 4 * 768 * lrf * lrf).sum()) * 6 * 3
+        real_tflop = (real_esm + real_rna) / 1e12
+        out["step_mfu"] = {"algorithmic_tflop_per_step": round(real_tflop, 2),
+                           "achieved_tflops": round(real_tflop / (dt / args.steps), 1),
+                           "frac_of_bf16_peak": round(real_tflop / (dt / args.steps) / MFMA_BF16_PEAK_TFLOPS, 4),
+                           "counts": "real tokens only",
+                           "padded_positions_tflop_per_step": round(step_tflop, 2),
+                           "padded_positions_frac_of_bf16_peak": round(step_tflop / (dt / args.steps) / MFMA_BF16_PEAK_TFLOPS, 4)}
     if timer is not None:
         summ = timer.summary()
         gm = summ.get("gemm_nt")
         if gm:
             achieved = gm["work"] / (gm["total_ms"] * 1e-3) / 1e12
-            traffic = load_traffic(f"{args.config}_B{B}")
+            traffic, traffic_stale = load_traffic(traffic_key(args.config, B, Lp, args.lengths if not c4 else "full",
+                                                              args.esm))
             out["roofline"] = {"bound": "mfma",
                                "kernel": "clipk_gemm_nt = gemm_nt_v3_kernel / gemm_nt_v2_kernel (bf16 16x16x32 MFMA Linear fwd/dgrad)",
                                "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -340,6 +389,16 @@ def bench_clip(args):
                                             "K = 480 shapes are bounded by their output stores, not by the matrix pipe"}
             if traffic:
                 out["roofline"]["traffic_detail"] = {k: traffic[k] for k in traffic if k != "bytes_per_launch"}
+            elif traffic_stale:
+                out["roofline"]["traffic_stale"] = True     # the GEMM sources changed since the PMC passes: re-measure
+                                                            # with tools/profile_bench.sh
+            # per epilogue mode (the GELU pair is the slowest class of the dominant kernel: VERDICT r02 weak #7)
+            out["roofline"]["by_epilogue"] = {
+                k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 1),
+                    "tflops": round(v["work"] / (v["total_ms"] * 1e-3) / 1e12, 1),
+                    "frac": round(v["work"] / (v["total_ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                    "share_of_kernel": round(v["total_ms"] / gm["total_ms"], 4)}
+                for k, v in sorted(timer.summary_by_sub("gemm_nt").items(), key=lambda kv: -kv[1]["total_ms"])}
         src, steps_src, tag = (summ, args.steps, "timed region") if (args.all_kernel_timers or timer_alone is None) \
             else (timer_alone.summary(), 2, "2 extra steps, one HIP stream, outside the timed region")
         out["kernels"] = {k: {"launches_per_step": v["launches"] // steps_src, "avg_us": round(v["avg_us"], 2),
@@ -361,9 +420,183 @@ def bench_clip(args):
             parity["bar"] = 1e-3
             parity["note"] = "step-0 loss, initial weights, 32 pairs (seed 4321), full depth; oracle = CPU f32 restatement"
             out["parity"] = parity
+    if want_c4_cpu:
+        sd_full = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        del opt, model, rna, ids
+        torch.cuda.empty_cache()
+        if not args.no_parity:
+            out["parity"] = c4_parity(device, Lp)
+        if not args.no_cpu_baseline:
+            # config 4 on the host at B = 1, one step (frozen 650M forward at L = 1024 + trained RNA tower)
+            cb, _ = cpu_baseline(sd_full, {"rna_dim": 768, "esm_layers": nl, "esm_heads": h, "rna_layers": 6,
+                                           "rna_heads": 8, "rna_len": Lr, "frozen_prefix": "protein_model."},
+                                 Lp, sample_b=1, steps=1, budget_s=60.0)
+            out["cpu_baseline"] = cb
     emit(out)
     if dist.is_initialized():
         dist.destroy_process_group()
+
+
+def c4_parity(device, Lp):
+    """Config 4's arithmetic at reduced DEPTH: two layers of the ESM-2-650M shape (1280 / 20 x 64 / 5120, frozen) at
+    L = 1024 + two RNA layers + heads, step-0 loss of 8 pairs, GPU vs CPU oracle (bar 1e-3)."""
+    import torch
+
+    import clip_dplm_amd as K
+    from clip_dplm_amd.encoders import ESM2_SHAPES
+    from oracle import model_ref
+    ESM2_SHAPES["c4_parity"] = (2, 1280, 20, 5120)
+    torch.manual_seed(5)
+    m = K.ProteinRNACLIP(esm="c4_parity", rna_layers=2, freeze_protein_encoder=True).eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(99)
+    ids = torch.randint(4, 24, (8, Lp), generator=g)
+    ids[:, 0], ids[:, -1] = 0, 2
+    rna = torch.randn(8, 256, 768, generator=g)
+    m = m.to(device)
+    with torch.no_grad():
+        lg = float(m.loss(rna.to(device), ids.to(device)).item())
+    del m
+    torch.cuda.empty_cache()
+    torch.set_num_threads(host_threads())
+    with torch.no_grad():
+        lo, _, _ = model_ref.protein_rna_clip_loss(sd, rna, ids, None, None, esm_layers=2, esm_heads=20, rna_layers=2,
+                                                   rna_heads=8)
+    return {"sub_batch": 8, "loss_gpu": lg, "loss_oracle": float(lo.item()), "loss_abs_err": abs(lg - float(lo.item())),
+            "bar": 1e-3, "note": f"two layers of the 650M shape (1280 / 20 x 64 / 5120) at L={Lp} + two RNA layers + heads, "
+                                 "step-0 loss of 8 pairs (seed 99); oracle = CPU f32 restatement"}
+
+
+# ====================================================================================================== stub
+def bench_stub(args):
+    """The multi-rank plumbing of bench_clip on a trivial workload (CPU tensors, gloo): same init_distributed(), the
+    same WORLD_SIZE / --gpus check, barrier-bracketed timed region, MAX over ranks, ONE JSON line from rank 0, every
+    other rank silent.  CLIPK_BENCH_STUB_FAIL_RANK=r makes rank r fail after the rendezvous (the launcher's return code
+    must show it).  Touches no GPU."""
+    import torch
+    import torch.distributed as dist
+    from clip_dplm_amd.distributed import init_distributed
+    rank, world, _ = init_distributed(backend="gloo")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    fail = os.environ.get("CLIPK_BENCH_STUB_FAIL_RANK")
+    if fail is not None and int(fail) == rank:
+        raise SystemExit(f"[stub] rank {rank} fails on request")
+    print("library chatter that must not reach the JSON stream")          # (fd 1 points at stderr by now)
+    x = torch.ones(1024) * (rank + 1)
+
+    def step():
+        y = x * 2.0
+        if world > 1:
+            dist.all_reduce(y)
+        return y
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = step()
+    if world > 1:
+        dist.barrier()
+    tmax = torch.tensor([time.perf_counter() - t0])
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = max(tmax.item(), 1e-9)
+    if rank == 0:
+        emit({"metric": "stub", "value": round(1024 * world * args.steps / dt, 1), "unit": "elements/s", "n_gpus": world,
+              "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+              "config": {"workload": "plumbing stub (CPU, gloo)"}, "checksum": float(y.sum().item())})
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+# ====================================================================================================== c1
+def bench_c1(args):
+    """BASELINE config 1 (plumbing): old/clip.py's tiny dual encoder — 2 x Linear(128)+ReLU, LayerNorm, ProjectionHead
+    (128 -> 256 -> 128) per tower — on 256 random pairs: one TRAINING step = forward + one-sided CE (old/ablation.py:16)
+    + backward + fused AdamW (lr 1e-4).  SURVEY §8d inputs: weights torch.manual_seed(0), x ~ N(0,1) from seed 1234.
+    Launch-latency bound (~60 launches of microsecond kernels); reported for completeness, never optimised."""
+    import torch
+    from types import SimpleNamespace as NS
+
+    import clip_dplm_amd as K
+    from clip_dplm_amd import ops
+    from oracle import clip_ref
+    dev = torch.device("cuda:0")
+    B = args.batch or 256
+    sub = lambda hh: NS(hidden_size=hh, num_hidden_layers=2, layer_norm_eps=1e-12)
+    cfg = NS(rna_config=sub(128), protein_config=sub(128), diffmap_config=sub(128), projection_dim=128,
+             logit_scale_init_value=2.6592)
+    torch.manual_seed(0)
+    model = K.RNAProteinCLIPModule(cfg).eval()             # eval: dropout off (BASELINE.md §3), gradients still flow
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(1234)
+    xa, xb = torch.randn(B, 128, generator=g), torch.randn(B, 128, generator=g)
+    model = model.to(dev)
+    xa_d, xb_d = xa.to(dev), xb.to(dev)
+    with torch.no_grad():
+        loss_gpu0 = float(model.loss(xa_d, xb_d, symmetric=False).item())
+    opt = K.FusedAdamW(model, lr=1e-4, weight_decay=0.01, max_grad_norm=None)
+
+    def step():
+        opt.zero_grad()
+        loss = model.loss(xa_d, xb_d, symmetric=False)
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    timer = ops.KernelTimer(("gemm_nt",))
+    ops.set_kernel_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.set_kernel_timer(None)
+    gm = timer.summary().get("gemm_nt")
+    # CPU oracle: the same training step (>= 10 steps, BASELINE.md §3), and the step-0 loss for parity
+    ncores = host_threads()
+    torch.set_num_threads(ncores)
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+    topt = torch.optim.AdamW(list(sd.values()), lr=1e-4, weight_decay=0.01)
+    times, loss_or0 = [], None
+    for it in range(13):
+        t1 = time.perf_counter()
+        topt.zero_grad()
+        lo = clip_ref.ce_diag(clip_ref.rna_protein_clip_forward(sd, xa, xb)["logits_per_rna_protein"])
+        if it == 0:
+            loss_or0 = float(lo.item())
+        lo.backward()
+        topt.step()
+        times.append(time.perf_counter() - t1)
+    timed = sorted(times[3:])
+    cdt = timed[len(timed) // 2]
+    flop_step = 3 * 2 * (2 * B * 128 * 128 * 2 + 2 * B * (128 * 256 + 256 * 128))      # fwd + dgrad + wgrad, both towers
+    ach = gm["work"] / (gm["total_ms"] * 1e-3) / 1e12 if gm else 0.0
+    out = {"metric": "seq-pairs/sec, contrastive training step, old/clip.py tiny dual encoder (config 1)",
+           "value": round(B * args.steps / dt, 1), "unit": "seq-pairs/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": f"BASELINE config 1: old/clip.py RNAProteinCLIPModule (2 layers, d=128, P=128), B={B} "
+                                  "random pairs, training step (fwd + one-sided CE + bwd + fused AdamW)"},
+           "loss": round(float(loss.item()), 5),
+           "roofline": {"bound": "mfma", "kernel": "clipk_gemm_nt (launch-latency bound at these sizes: 8.4 MFLOP per launch)",
+                        "achieved": round(ach, 3), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 6), "traffic": None,
+                        "avg_launch_us": round(gm["avg_us"], 2) if gm else None,
+                        "launches": gm["launches"] if gm else 0,
+                        "algorithmic_gflop_per_step": round(flop_step / 1e9, 3)},
+           "parity": {"loss_gpu": loss_gpu0, "loss_oracle": loss_or0, "loss_abs_err": abs(loss_gpu0 - loss_or0),
+                      "bar": 1e-3, "known_answer": 5.915865,
+                      "note": "one-sided CE at the initial weights (SURVEY §8c known answer 5.915865)"},
+           "cpu_baseline": {"value": round(B / cdt, 1), "unit": "seq-pairs/s", "cores": ncores, "kind": "port",
+                            "sample": f"median of {len(timed)} training steps of the CPU oracle (fwd + CE + bwd + "
+                                      f"torch AdamW) at B={B}, f32, after 3 warm-up steps; {1e3 * cdt:.2f} ms/step"}}
+    emit(out)
 
 
 # ====================================================================================================== c3sim
@@ -426,10 +659,30 @@ def bench_c3sim(args):
                         "avg_launch_us": round(lse_us, 2), "algorithmic_bytes_per_launch": bytes_lse,
                         "f32_mfma_tflops": round(flop_lse / (lse_us * 1e-6) / 1e12, 1),
                         "f32_mfma_frac_of_157": round(flop_lse / (lse_us * 1e-6) / 1e12 / 157.3, 3)},
+           "parity": c3sim_parity(al, bl, a, b, sc, Bl, Bg),
            "kernels": {"simce_lse": {"avg_us": round(lse_us, 2), "GBps": round(bytes_lse / (lse_us * 1e-6) / 1e9, 1)},
                        "simce_grad": {"avg_us": round(grad_us, 2), "GBps": round(bytes_grad / (grad_us * 1e-6) / 1e9, 1),
                                       "f32_mfma_tflops": round(2 * flop_lse / (grad_us * 1e-6) / 1e12, 1)}}}
     emit(out)
+
+
+def c3sim_parity(al, bl, a, b, sc, Bl, Bg):
+    """This rank's share of the global symmetric loss from the fused kernels against the CPU oracle on the MATERIALISED
+    logits block (oracle/clip_ref.py ce_diag arithmetic, f64): 0.5 * (row CE of the local rows vs all keys + column CE
+    of the local columns vs all rows)."""
+    import torch
+    from clip_dplm_amd import ops
+    lr_, pr_ = ops.simce_lse(al, b, sc, label_offset=0)
+    lc_, pc_ = ops.simce_lse(bl, a, sc, label_offset=0)
+    got = 0.5 * ((lr_ - pr_).mean() + (lc_ - pc_).mean()).item()
+    A, Bm, s = a.double().cpu(), b.double().cpu(), float(sc.item())
+    S_r = (A[:Bl] @ Bm.t()) * s                               # local rows x all keys
+    S_c = (Bm[:Bl] @ A.t()) * s                               # local columns (as rows) x all rows
+    want = 0.5 * ((torch.logsumexp(S_r, 1) - S_r[:, :Bl].diagonal()).mean() +
+                  (torch.logsumexp(S_c, 1) - S_c[:, :Bl].diagonal()).mean()).item()
+    return {"loss_gpu": got, "loss_oracle": want, "loss_abs_err": abs(got - want), "bar": 1e-5,
+            "note": f"rank 0's {Bl} rows / columns of the {Bg}-pair symmetric InfoNCE; oracle = f64 CE on the materialised "
+                    "logits block (oracle/clip_ref.ce_diag arithmetic)"}
 
 
 # ====================================================================================================== c5
@@ -463,6 +716,16 @@ def bench_c5(args):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert all(torch.equal(out_g[k], out_[k]) for k in out_)          # same kernels, same inputs: same bits
+    # parity: the three maps of the first 64 samples against the CPU oracle's autograd-of-autograd
+    from oracle import icnn_ref
+    sd_c = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    srcs = {"cell_to_pert": cell, "cell_to_protein": cell, "pert_to_protein": pert}
+    perr = 0.0
+    for name, src in srcs.items():
+        ref = icnn_ref.single_cell_transport(src[:64].cpu(), sd_c, name, 2)
+        perr = max(perr, (out_[name][:64].cpu() - ref).abs().max().item())
+    parity = {"max_abs_err": perr, "bar": 2e-4, "samples": 64,
+              "note": "T(x) of the three maps (LayerNorm'ed, O(1)) vs oracle/icnn_ref.single_cell_transport (CPU f32 autograd)"}
     per_map_bytes = B * 512 * 4 * 2 + 0.79e6 * 4
     flop = 3 * B * 2.0 * 2 * (512 * 512 + 2 * 256 * 512)              # three maps, forward + input-gradient products
     ach = 3 * per_map_bytes * args.steps / dt / 1e9
@@ -480,6 +743,7 @@ def bench_c5(args):
                         "f32_mfma_frac_of_157": round(flop * args.steps / dt / 1e12 / 157.3, 3),
                         "note": "the op is exact-f32 matrix work (2.1 MFLOP / sample / map at 64 FLOP/clk/SIMD): its own "
                                 "bound is the f32 matrix pipe, not HBM"},
+           "parity": parity,
            "eager_ms_per_step": round(1e3 * dt_eager / args.steps, 4)}
     emit(out)
 
@@ -500,7 +764,7 @@ def main():
     global _JSON_FD
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        if args.config not in ("c2", "c4"):
+        if args.config not in ("c2", "c4", "stub"):
             raise SystemExit(f"--config {args.config} is a one-GPU kernel bench")
         sys.exit(self_launch(args))
     # stdout carries exactly one JSON line: library chatter (RCCL prints a version banner on stdout at the first
@@ -510,6 +774,10 @@ def main():
     os.dup2(2, 1)
     if args.config in ("c2", "c4"):
         bench_clip(args)
+    elif args.config == "stub":
+        bench_stub(args)
+    elif args.config == "c1":
+        bench_c1(args)
     elif args.config == "c3sim":
         bench_c3sim(args)
     else:

@@ -7,7 +7,9 @@ from .configuration_hybrid_clip import HybridCLIPConfig, ModelArchitectureConfig
 from .encoders import ESM2Encoder, ESM2_SHAPES, TransformerSeqEncoder, pool
 from .esm_integration import (BiologicalDataType, ESMConfig, ESMIntegration, ESMOutput, GeneProjection,
                               ProteinProjection, create_esm_integration, get_embeddings_batch)
-from .loss import clip_loss
+from .data import MemoryQueue
+from .functional import set_linear_precision
+from .loss import clip_loss, contrastive_loss
 from .modeling_clip import (CLIPEncoder, DiffMapProteinCLIP, DiffMapProteinCLIPModule, OptimizedCLIPModule,
                             OptimizedProjectionHead, ProjectionHead, RNAProteinCLIP, RNAProteinCLIPModule,
                             optimized_clip_loss)
@@ -26,5 +28,5 @@ __all__ = [
     "ESM2Encoder", "ESM2_SHAPES", "TransformerSeqEncoder", "pool", "clip_loss", "FlatParams", "FusedAdamW",
     "cosine_annealing_lr", "CosineAnnealingLR", "EarlyStopping", "train_epoch", "evaluate_model", "save_checkpoint",
     "load_checkpoint", "ESMConfig", "ESMIntegration", "ESMOutput", "BiologicalDataType", "ProteinProjection",
-    "GeneProjection", "create_esm_integration", "get_embeddings_batch",
+    "GeneProjection", "create_esm_integration", "get_embeddings_batch", "MemoryQueue", "contrastive_loss", "set_linear_precision",
 ]

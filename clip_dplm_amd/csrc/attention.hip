@@ -1254,6 +1254,288 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
 }
 
 // =================================================================================================
+// backward, whole head in one workgroup, head dim 96 (the 6 x 768 RNA encoder: 8 heads of 96), 128 < L <= 256, rows
+// that need no rotation, no dropout.
+//
+// The dQ + dK/dV kernel pair reads q, k, v, dO twice (3.6 GB per layer at B = 1024 against 2.0 GB read once) and runs
+// 7 products and the exponentials twice; its dK/dV half gives every 64-key workgroup a prologue and an epilogue as long
+// as its sweep.  Here one workgroup (4 waves, ONE per SIMD: 512 VGPRs) owns a (batch, head): wave w holds the K / V
+// fragments of keys [64w, 64w + 64) (loaded straight from HBM in fragment layout: 16-byte chunk g + 4 ks of row li),
+// their K^T fragments (transposed LDS reads of the staged K rows) and the dK^T / dV^T accumulators in registers - 336
+// of them - and all four waves sweep the eight 32-query blocks TOGETHER: Q / dO blocks are double-buffered in LDS
+// (chunk per lane through registers, the next block requested before the sweep of the current one), delta =
+// rowsum(dO * O) is formed from the staged chunks (shares in LDS, summed in chunk order), dS goes back to LDS transposed
+// (private 4 KiB per wave) to become the B operand of dQ^T += K^T dS^T, and the four waves' dQ shares (their own keys)
+// meet in LDS once per block: written side by side, summed in wave order by all 256 threads, scaled, rounded and
+// stored.  5 products, one softmax pass, every operand read once, no atomics: bitwise reproducible.
+// =================================================================================================
+constexpr int F96_QB = 32;                                 // queries per step
+__host__ __device__ constexpr size_t lds_fused96() {
+  // K rows (then the four dQ shares: 4 x 32 x 100 f32 = 51200 B; then the dK / dV images) | 2 x (Q, dO) blocks |
+  // 4 x dS^T | lse, -delta | delta shares
+  return (size_t)FUSED_LMAX * Geo<96>::RS + 4 * F96_QB * Geo<96>::RS + 4 * 4096 + 2 * FUSED_LMAX * 4 + F96_QB * 12 * 4;
+}
+
+__global__ __launch_bounds__(256, 1) void attn_bwd_fused96_kernel(const AP p) {
+  constexpr int D = 96, RS = Geo<96>::RS, KS = 3, DT = 6, NCH = 12, LQ = FUSED_LMAX, QB = F96_QB, ILD = D + 4;
+  constexpr int KTW = 4, KW = 64, NCK = 2;                 // per wave: four 16-key tiles = two 32-key chunks
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ktile = smem;                                      // [256][RS] K rows; later dQ shares; later dK / dV images
+  float* share = reinterpret_cast<float*>(smem);           // [4 waves][32 q][ILD] f32
+  char* qd = smem + LQ * RS;                               // [2 buffers][Q block | dO block][32][RS]
+  char* dst_all = qd + 4 * QB * RS;                        // [4 waves][2 chunks][32 keys][64 B]
+  float* lse_l = reinterpret_cast<float*>(dst_all + 4 * 4096);   // [256] lse * log2(e); +inf past the end
+  float* dl_l = lse_l + LQ;                                // [256] -delta
+  float* part = dl_l + LQ;                                 // [32][12] delta shares of the block being staged
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int H = p.H;
+  int blk, h, b;
+  work_item(1, H, p.B, blk, h, b);
+  int L = p.L;
+  const long row0 = seq_rows(p, b, L);
+  if (L <= 0) return;                                      // (workgroup-uniform) empty sequence of a packed batch
+  const long tokstride = 3L * H * D, ostride = (long)H * D;
+  const unsigned int HD = (unsigned int)(H * D);
+  const unsigned short* qb_ = p.qkv + row0 * tokstride + (long)h * D;
+  const unsigned short* dob = p.dout + row0 * ostride + (long)h * D;
+  const unsigned short* ob = p.out + row0 * ostride + (long)h * D;
+  const float c2 = p.scale * LOG2E;
+  const int nblk = (L + QB - 1) / QB;
+
+  // ---- Q / dO / O block staging: 32 rows x 12 chunks = 384 (row, chunk) tasks per tensor, two passes of 256 threads
+  // (the second pass of threads >= 128 repeats a task of the first; its store is skipped)
+  u32x4 cq[2], cd[2], co[2];
+  auto issue_block = [&](int j) {
+    const int t = tid + opaque_zero();
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      int idl = ps * 256 + t; idl = idl < QB * NCH ? idl : idl - 256;
+      const int r = idl / NCH, ch = idl - r * NCH;
+      int row = j * QB + r; row = row < L ? row : L - 1;
+      cq[ps] = *reinterpret_cast<const u32x4*>(qb_ + ((unsigned int)row * 3u * HD + 8u * ch));
+      cd[ps] = *reinterpret_cast<const u32x4*>(dob + ((unsigned int)row * HD + 8u * ch));
+      co[ps] = *reinterpret_cast<const u32x4*>(ob + ((unsigned int)row * HD + 8u * ch));
+    }
+  };
+  auto store_block = [&](int j) {                          // -> buffer j & 1, delta shares -> part
+    const int t = tid + opaque_zero();
+    char* qt = qd + (j & 1) * (2 * QB * RS);
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int idl = ps * 256 + t;
+      if (idl < QB * NCH) {
+        const int r = idl / NCH, ch = idl - r * NCH;
+        *reinterpret_cast<u32x4*>(qt + r * RS + ch * 16) = cq[ps];
+        *reinterpret_cast<u32x4*>(qt + QB * RS + r * RS + ch * 16) = cd[ps];
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc += bf16_to_f32(co[ps][e] & 0xffffu) * bf16_to_f32(cd[ps][e] & 0xffffu);
+          acc += bf16_to_f32(co[ps][e] >> 16) * bf16_to_f32(cd[ps][e] >> 16);
+        }
+        part[idl] = acc;
+      }
+    }
+  };
+  auto finish_delta = [&](int j) {                         // after the barrier that follows store_block(j)
+    if (tid < QB) {
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) acc += part[tid * NCH + c];
+      const int q = j * QB + tid;
+      const bool ok = q < L;
+      dl_l[q] = ok ? -acc : 0.f;                           // NEGATED: the dP accumulators start from it
+      if (ok) p.delta[stat_at(p, b, h, H, L, row0, q)] = acc;
+    }
+  };
+
+  // ---- prologue: K rows -> LDS (for the transposed fragments), K / V fragments of this wave's keys straight from HBM
+  issue_block(0);
+  {
+    const int t = tid + opaque_zero();
+#pragma unroll
+    for (int ps = 0; ps < LQ * NCH / 256; ++ps) {          // 12 chunk tasks per thread
+      const int idl = ps * 256 + t;
+      const int r = idl / NCH, ch = idl - r * NCH;
+      const int row = r < L ? r : L - 1;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(qb_ + ((unsigned int)row * 3u * HD + HD + 8u * ch));
+      *reinterpret_cast<u32x4*>(ktile + r * RS + ch * 16) = v;
+    }
+  }
+  bf16x8 kf[KTW][KS], vf[KTW][KS];
+  float kbias[KTW];
+#pragma unroll
+  for (int kt = 0; kt < KTW; ++kt) {
+    const int key = wid * KW + kt * 16 + li;
+    const int row = key < L ? key : L - 1;
+    kbias[kt] = (key < L && (!p.key_mask || p.key_mask[row0 + row])) ? 0.f : -INFINITY;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const unsigned int off = (unsigned int)row * 3u * HD + (unsigned int)(ks * 32 + g * 8);
+      kf[kt][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qb_ + (off + HD)));
+      vf[kt][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qb_ + (off + 2u * HD)));
+    }
+  }
+  lse_l[tid] = tid < L ? p.lse[stat_at(p, b, h, H, L, row0, tid)] * LOG2E : INFINITY;   // p = 2^-inf = 0 past the end
+  store_block(0);
+  __syncthreads();
+  const int trow = 4 * g + (li >> 2), tcolb = 8 * (li & 3);
+  bf16x8 ktf[DT][NCK];                                     // K^T[d tile][32 keys of chunk c]
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int c = 0; c < NCK; ++c) ktf[dt][c] = tr_frag(ktile, RS, wid * KW + c * 32 + trow, dt * 32 + tcolb);
+  finish_delta(0);
+  __syncthreads();                                         // K rows are consumed: the region becomes the dQ shares
+
+  f32x4 dk[DT][KTW], dv[DT][KTW];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int kt = 0; kt < KTW; ++kt) { dk[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt][kt] = dk[dt][kt]; }
+  char* dst = dst_all + wid * 4096;
+  int off_dw[2];                                           // dS^T write: key row li of a 16-key tile, queries qq*16 + 4g ..
+#pragma unroll
+  for (int qq = 0; qq < 2; ++qq) off_dw[qq] = swz64(li, qq * 2 + (g >> 1)) + 8 * (g & 1);
+  const bool wave_live = wid * KW < L;                     // this wave owns at least one real key
+
+#pragma unroll 1
+  for (int j = 0; j < nblk; ++j) {
+    issue_block(j + 1 < nblk ? j + 1 : j);                 // unconditional (no branch around loads); last: re-read, unused
+    const char* qt_ = qd + (j & 1) * (2 * QB * RS);
+    const char* dt_ = qt_ + QB * RS;
+    f32x4 dq[DT][2];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) { dq[dt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dq[dt][1] = dq[dt][0]; }
+    if (wave_live) {
+      u32x2 pk[2][KTW], dsk[2][KTW];
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        // rows of the accumulators are queries (4g + r), columns are this lane's key; dP starts at -delta of its row,
+        // S at 0 / -inf for a valid / masked key
+        const f32x4 nd = *reinterpret_cast<const f32x4*>(dl_l + j * QB + qq * 16 + 4 * g);
+        f32x4 s[KTW], dp[KTW];
+#pragma unroll
+        for (int kt = 0; kt < KTW; ++kt) { s[kt] = f32x4{kbias[kt], kbias[kt], kbias[kt], kbias[kt]}; dp[kt] = nd; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8 qa = row_frag(qt_, RS, qq * 16 + li, ks, lane);
+          const bf16x8 da = row_frag(dt_, RS, qq * 16 + li, ks, lane);
+#pragma unroll
+          for (int kt = 0; kt < KTW; ++kt) {
+            s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kt][ks], s[kt], 0, 0, 0);
+            dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kt][ks], dp[kt], 0, 0, 0);
+          }
+        }
+        const f32x4 ls = *reinterpret_cast<const f32x4*>(lse_l + j * QB + qq * 16 + 4 * g);
+#pragma unroll
+        for (int kt = 0; kt < KTW; ++kt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = fast_exp2(s[kt][r] * c2 - ls[r]);
+            s[kt][r] = pv;                                 // P
+            dp[kt][r] = pv * dp[kt][r];                    // dS = P (dP - delta)
+          }
+          pk[qq][kt] = u32x2{pack_bf16x2(s[kt][0], s[kt][1]), pack_bf16x2(s[kt][2], s[kt][3])};
+          dsk[qq][kt] = u32x2{pack_bf16x2(dp[kt][0], dp[kt][1]), pack_bf16x2(dp[kt][2], dp[kt][3])};
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < NCK; ++c) {
+#pragma unroll
+        for (int ktl = 0; ktl < 2; ++ktl) {
+          const int kt = 2 * c + ktl;
+          const bf16x8 pbf = __builtin_bit_cast(bf16x8, u32x4{pk[0][kt][0], pk[0][kt][1], pk[1][kt][0], pk[1][kt][1]});
+          const bf16x8 dsf = __builtin_bit_cast(bf16x8, u32x4{dsk[0][kt][0], dsk[0][kt][1], dsk[1][kt][0], dsk[1][kt][1]});
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq) *reinterpret_cast<u32x2*>(dst + c * 2048 + ktl * 1024 + off_dw[qq]) = dsk[qq][kt];
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const bf16x8 dot_f = tr_frag(dt_, RS, trow, dt * 32 + tcolb);     // dO^T[d tile][32 q]
+            const bf16x8 qt_f = tr_frag(qt_, RS, trow, dt * 32 + tcolb);      // Q^T
+            dv[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_f, pbf, dv[dt][kt], 0, 0, 0);
+            dk[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_f, dsf, dk[dt][kt], 0, 0, 0);
+          }
+        }
+        // dQ^T[d][q] += K^T[d][32 keys of chunk c] dS^T[32 keys][q]   (the wave's own writes: no barrier needed)
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+          const bf16x8 dsb = tr_frag_off(dst + c * 2048, swz64(trow, qq * 2 + ((li & 3) >> 1)) + 8 * (li & 1));
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt)
+            dq[dt][qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[dt][c], dsb, dq[dt][qq], 0, 0, 0);
+        }
+      }
+    }
+    // this wave's share of dQ (its keys only) for block j, as [q][d] f32 rows (zeros from a wave without keys)
+    {
+      float* sh = share + wid * (QB * ILD);
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+          *reinterpret_cast<f32x4*>(sh + (qq * 16 + li) * ILD + dt * 16 + 4 * g) = dq[dt][qq];
+    }
+    store_block(j + 1);                                    // the other buffer (last step: a copy nobody reads)
+    __syncthreads();
+    // ---- sum the four shares in wave order, scale, round, store: thread t -> query t / 8, 12 head dims
+    {
+      const int r = tid >> 3, c0 = (tid & 7) * 12;
+      f32x4 a[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) a[i] = *reinterpret_cast<const f32x4*>(share + r * ILD + c0 + 4 * i);
+#pragma unroll
+      for (int w = 1; w < 4; ++w)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) a[i] += *reinterpret_cast<const f32x4*>(share + w * (QB * ILD) + r * ILD + c0 + 4 * i);
+      const int q = j * QB + r;
+      if (q < L) {
+        unsigned short* dqrow = p.dqkv + (row0 + q) * tokstride + (long)h * D + c0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          u32x2 w2;
+          w2[0] = pack_bf16x2(a[i][0] * p.scale, a[i][1] * p.scale);
+          w2[1] = pack_bf16x2(a[i][2] * p.scale, a[i][3] * p.scale);
+          *reinterpret_cast<u32x2*>(dqrow + 4 * i) = w2;
+        }
+      }
+    }
+    if (j + 1 < nblk) finish_delta(j + 1);
+    __syncthreads();
+  }
+
+  // ---- dK^T (x scale) and dV^T accumulators -> bf16 [key][d] images (one after the other, over the shares) -> rows
+  unsigned short* dkb = p.dqkv + row0 * tokstride + HD + (long)h * D;
+#pragma unroll 1
+  for (int which = 0; which < 2; ++which) {
+#pragma unroll
+    for (int kt = 0; kt < KTW; ++kt)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const f32x4 v = which == 0 ? dk[dt][kt] * p.scale : dv[dt][kt];
+        u32x2 wv;
+        wv[0] = pack_bf16x2(v[0], v[1]);
+        wv[1] = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<u32x2*>(ktile + (wid * KW + kt * 16 + li) * RS + (dt * 16 + 4 * g) * 2) = wv;
+      }
+    __syncthreads();
+    {
+      const int t = tid + opaque_zero();
+#pragma unroll
+      for (int ps = 0; ps < LQ * NCH / 256; ++ps) {
+        const int idl = ps * 256 + t;
+        const int r = idl / NCH, ch = idl - r * NCH;
+        if (r < L)
+          *reinterpret_cast<u32x4*>(dkb + ((unsigned int)r * 3u * HD + (unsigned int)which * HD + 8u * ch)) =
+              *reinterpret_cast<const u32x4*>(ktile + r * RS + ch * 16);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// =================================================================================================
 // forward, whole head in one workgroup (head dim <= 32, 128 < L <= 256, rows that need no rotation): all 256 K and V
 // rows are staged ONCE per head (the general kernel's two 128-query workgroups each stage all of them) and stay in
 // LDS while the four waves take two passes of 32 queries each.  Same tiles, same 64-key sub-block order and the
@@ -1533,8 +1815,24 @@ void launch_fused(const AP& p, hipStream_t st) {
   else launch_fused_nw<ROPE, D, 4>(p, st);
 }
 
+inline void launch_fused96(const AP& p, hipStream_t st) {
+  constexpr size_t lds = lds_fused96();
+  static_assert(lds <= 160 * 1024, "fused96 LDS budget");
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused96_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(attn_bwd_fused96_kernel, dim3(p.B * p.H), dim3(256), lds, st, p);
+}
+
 template <int DP, int DR, int DX>
 int launch_bwd(const AP& p, hipStream_t st) {
+  if constexpr (DP == 96 && DR == 0 && DX == 96) {
+    // whole-head kernel for the 6 x 768 RNA encoder's heads (8 x 96) at L <= 256; option attn_fused_bwd = 0 keeps the
+    // dQ + dK/dV pair (tests compare the two)
+    if (!p.drop_thr && clipk_opt_get(OPT_ATTN_FUSED_BWD) != 0 && p.L > 128 && p.L <= FUSED_LMAX) {
+      launch_fused96(p, st);
+      return clipk_check_launch();
+    }
+  }
   if constexpr (DP == 32) {
     // whole-head kernel for the short-head encoders (ESM-2 8M / 35M / 150M at L <= 256); option attn_fused_bwd = 0
     // keeps the two-kernel path (tests compare the two)

@@ -58,3 +58,36 @@ def unpad(x, valid):
     """Padded [B, L, ...] + validity mask [B, L] (True / 1 = real token, right-padded) -> packed triple."""
     lens = valid.long().sum(1)
     return pack_sequences([x[i, : int(lens[i])] for i in range(x.shape[0])])
+
+
+class MemoryQueue:
+    """tong/utils/data.py:154-184: fixed-size FIFO of past embeddings for contrastive negatives, with TRUE wrap-around
+    (a batch that crosses the end continues at row 0; `old/clip_opt.py:76-81` resets the pointer to 0 instead and
+    forgets the older rows — `OptimizedCLIPModule(cache_semantics=...)` offers both).  Same attributes (`size`, `dim`,
+    `ptr`, `queue`) and the same `enqueue_dequeue(embeddings) -> queue` as the reference: the WHOLE queue is returned,
+    rows that were never written are zeros.  `device=` places the buffer (the reference keeps it on the CPU)."""
+
+    def __init__(self, size, dim, device=None):
+        self.size = size
+        self.dim = dim
+        self.ptr = 0
+        self.queue = torch.zeros(size, dim, device=device)
+
+    @torch.no_grad()
+    def enqueue_dequeue(self, embeddings):
+        n = embeddings.shape[0]
+        if self.queue is None:                                   # (reference :168-170)
+            self.queue = embeddings.detach()
+            return self.queue
+        e = embeddings.detach().to(self.queue.device, self.queue.dtype)
+        if n > self.size:
+            raise ValueError(f"a batch of {n} rows does not fit a queue of {self.size}")   # the reference's slice assignment raises too
+        if self.ptr + n > self.size:
+            first = self.size - self.ptr
+            self.queue[self.ptr:] = e[:first]
+            self.queue[: n - first] = e[first:]
+            self.ptr = n - first
+        else:
+            self.queue[self.ptr:self.ptr + n] = e
+            self.ptr = (self.ptr + n) % self.size
+        return self.queue

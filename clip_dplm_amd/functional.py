@@ -132,10 +132,53 @@ class LinearFn(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
-def linear(x, weight, bias, cache: WeightCache, act=None, out_dtype=torch.float32):
+class LinearF32Fn(torch.autograd.Function):
+    """y = x W^T + b in EXACT f32 (clipk_gemm_f32: f32-input MFMA, bitwise an fmaf chain) — the arithmetic of the
+    reference's own fp32 callers (old/ablation.py:9-18 runs old/clip.py without autocast).  Opt-in per Linear
+    (`KLinear.precision = "f32"`, `set_linear_precision`); the bf16-MFMA LinearFn is the default."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return ops.gemm_f32(x, weight, bias=bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = ops.gemm_f32(dy, weight, trans_b=True) if ctx.needs_input_grad[0] else None
+        dw = ops.gemm_f32(dy, x, trans_a=True, trans_b=True) if ctx.needs_input_grad[1] else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.pool_fwd(dy, 1, dy.shape[0], None, 1).reshape(-1) * float(dy.shape[0])   # column sum
+        return dx, dw, db
+
+
+def linear(x, weight, bias, cache: WeightCache, act=None, out_dtype=torch.float32, precision: str = "bf16"):
     lead = x.shape[:-1]
-    y = LinearFn.apply(x.reshape(-1, x.shape[-1]), weight, bias, cache, act, out_dtype)
+    x2 = x.reshape(-1, x.shape[-1])
+    if precision == "f32":
+        y = LinearF32Fn.apply(x2.float().contiguous(), weight, bias)
+        if act is not None:
+            y = ActFn.apply(y, act)
+        if out_dtype != torch.float32:
+            y = _bf16(y)
+    else:
+        y = LinearFn.apply(x2, weight, bias, cache, act, out_dtype)
     return y.reshape(*lead, y.shape[-1])
+
+
+def set_linear_precision(module: torch.nn.Module, precision: str = "bf16") -> torch.nn.Module:
+    """Select the arithmetic of every kernel-backed Linear under `module`: "bf16" (default: bf16 operands, f32
+    accumulate, the north-star arithmetic) or "f32" (exact-f32 MFMA: the MLP towers and heads of old/clip.py then
+    reproduce the reference's fp32 forward to ~1e-6).  Transformer stacks keep their bf16 GEMMs."""
+    if precision not in ("bf16", "f32"):
+        raise ValueError(f"precision must be 'bf16' or 'f32', got {precision!r}")
+    for m in module.modules():
+        if hasattr(m, "_cache") and isinstance(m, torch.nn.Linear):
+            m.precision = precision
+    return module
 
 
 class LayerNormFn(torch.autograd.Function):

@@ -97,6 +97,17 @@ def clip_loss(a_embeds: torch.Tensor, b_embeds: torch.Tensor, logit_scale_exp: t
     return ClipLossFn.apply(a_embeds, b_embeds, logit_scale_exp, float(w_row), float(w_col), cache, group)
 
 
+def contrastive_loss(x: torch.Tensor, y: torch.Tensor, temperature: float = 0.1, queue: Optional[torch.Tensor] = None,
+                     group=None) -> torch.Tensor:
+    """tong/utils/losses.py:4-19: InfoNCE with an optional memory queue — both inputs L2-normalised, the queue rows
+    appended to the keys as extra negatives (detached), one-sided CE(x y^T / temperature, arange).  Same fused kernels as
+    clip_loss (w_row = 1, w_col = 0, cache = queue): neither the [B, B + Q] logits nor the concatenated keys exist."""
+    from . import functional as KF
+    scale = torch.full((1,), 1.0 / float(temperature), dtype=torch.float32, device=x.device)
+    cache = None if queue is None else queue.detach().to(dtype=torch.float32).contiguous()
+    return clip_loss(KF.l2_normalize(x), KF.l2_normalize(y), scale, symmetric=False, cache=cache, group=group)
+
+
 _TRI_PAIRS = ((0, 1), (1, 0), (0, 2), (2, 0), (1, 2), (2, 1))      # (cell,pert) (pert,cell) (cell,prot) ...
 
 

@@ -34,12 +34,14 @@ from .loss import clip_loss
 class KLinear(nn.Linear):
     """nn.Linear whose forward/backward are the bf16-MFMA gemm_nt / gemm_wgrad kernels (f32 master weights)."""
 
+    precision = "bf16"          # "f32": exact-f32 MFMA (KF.set_linear_precision)
+
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self._cache = KF.WeightCache()
 
     def forward(self, x, act: Optional[str] = None, out_dtype=torch.float32):
-        return KF.linear(x, self.weight, self.bias, self._cache, act=act, out_dtype=out_dtype)
+        return KF.linear(x, self.weight, self.bias, self._cache, act=act, out_dtype=out_dtype, precision=self.precision)
 
 
 class KLayerNorm(nn.LayerNorm):
@@ -209,11 +211,21 @@ class OptimizedProjectionHead(nn.Module):
 
 class OptimizedCLIPModule(nn.Module):
     """old/clip_opt.py:46-128.  The cache is a non-persistent buffer (moves with .to(), not in state_dict —
-    SURVEY App. A-4) and keeps the reference's update semantics (App. A-7: updated before use, pointer reset to
-    0 on overflow).  Under torch.distributed the embeddings are all-gathered differentiably (App. A-5)."""
+    SURVEY App. A-4).  Under torch.distributed the embeddings are all-gathered differentiably (App. A-5).
 
-    def __init__(self, config):
+    cache_semantics — both update the cache BEFORE it is used, as the reference does:
+      "reference" (default): old/clip_opt.py:76-81 — a batch that does not fit resets the pointer to 0, and the
+                   negatives are `cache[:ptr]`, i.e. after a wrap only the newest rows;
+      "fifo":      tong/utils/data.py:154-184 (`MemoryQueue`) — true wrap-around; the negatives are every row written
+                   so far, i.e. once full always the newest `cache_size` rows.  Identical to "reference" until the first
+                   wrap."""
+
+    def __init__(self, config, cache_semantics: str = "reference"):
         super().__init__()
+        if cache_semantics not in ("reference", "fifo"):
+            raise ValueError(f"cache_semantics must be 'reference' or 'fifo', got {cache_semantics!r}")
+        self.cache_semantics = cache_semantics
+        self.cache_filled = 0                   # fifo: rows written so far, capped at cache_size
         self.config = config
         self.register_buffer("protein_embedding_cache", torch.zeros(config.cache_size, config.projection_dim),
                              persistent=False)
@@ -230,10 +242,27 @@ class OptimizedCLIPModule(nn.Module):
 
     def update_cache(self, protein_embeds):
         batch_size = protein_embeds.size(0)
-        if self.cache_ptr + batch_size > self.config.cache_size:
+        size = self.config.cache_size
+        if self.cache_semantics == "fifo":
+            if batch_size > size:
+                raise ValueError(f"a batch of {batch_size} rows does not fit a cache of {size}")
+            e = protein_embeds.detach()
+            first = min(batch_size, size - self.cache_ptr)
+            self.protein_embedding_cache[self.cache_ptr:self.cache_ptr + first] = e[:first]
+            if first < batch_size:
+                self.protein_embedding_cache[: batch_size - first] = e[first:]
+            self.cache_ptr = (self.cache_ptr + batch_size) % size
+            self.cache_filled = min(size, self.cache_filled + batch_size)
+            return
+        if self.cache_ptr + batch_size > size:
             self.cache_ptr = 0
         self.protein_embedding_cache[self.cache_ptr:self.cache_ptr + batch_size] = protein_embeds.detach()
-        self.cache_ptr = (self.cache_ptr + batch_size) % self.config.cache_size
+        self.cache_ptr = (self.cache_ptr + batch_size) % size
+
+    def cache_rows(self):
+        """The rows that serve as extra negatives now (None when there are none)."""
+        n = self.cache_filled if self.cache_semantics == "fifo" else self.cache_ptr
+        return self.protein_embedding_cache[:n].contiguous() if n > 0 else None
 
     def embed(self, diffmap_values, protein_values):
         ed = self.diffmap_projection(self.diffmap_model(diffmap_values))
@@ -249,8 +278,8 @@ class OptimizedCLIPModule(nn.Module):
             ed, ep = all_gather_with_grad(ed), all_gather_with_grad(ep)
         out = {
             "logits_per_diffmap_protein": KF.sim_logits(ed, ep, scale),
-            "logits_per_diffmap_cache": KF.sim_logits(ed, self.protein_embedding_cache[: self.cache_ptr].contiguous(), scale)
-            if self.cache_ptr > 0 else ed.new_zeros((ed.shape[0], 0)),
+            "logits_per_diffmap_cache": KF.sim_logits(ed, self.cache_rows(), scale)
+            if self.cache_rows() is not None else ed.new_zeros((ed.shape[0], 0)),
             "diffmap_embeds": ed,
             "protein_embeds": ep,
         }
@@ -260,7 +289,7 @@ class OptimizedCLIPModule(nn.Module):
         """Fused equivalent of optimized_clip_loss(self(diffmap, protein)) without materialised logits."""
         ed, ep = self.embed(diffmap_values, protein_values)
         self.update_cache(ep)
-        cache = self.protein_embedding_cache[: self.cache_ptr].contiguous() if self.cache_ptr > 0 else None
+        cache = self.cache_rows()
         return clip_loss(ed, ep, self.logit_scale.exp().clamp(max=100), symmetric=True, cache=cache, group=group)
 
 

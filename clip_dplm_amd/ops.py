@@ -25,8 +25,21 @@ class KernelTimer:
         self.only = None if only is None else set(only)    # restrict to these kernel names (two events per launch cost
                                                            # ~1 % of a training step when every launch is timed)
 
-    def add(self, name, s, e, work, nbytes=0.0):
-        self.records.setdefault(name, []).append((s, e, work, nbytes))
+    def add(self, name, s, e, work, nbytes=0.0, sub=None):
+        self.records.setdefault(name, []).append((s, e, work, nbytes, sub))
+
+    def summary_by_sub(self, name):
+        """The launches of kernel `name` grouped by their sub-tag (gemm_nt: the epilogue mode) -> same fields as
+        summary().  Call after torch.cuda.synchronize()."""
+        groups = {}
+        for r in self.records.get(name, []):
+            groups.setdefault(r[4] or "-", []).append(r)
+        out = {}
+        for sub, recs in groups.items():
+            ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+            out[sub] = {"launches": len(recs), "total_ms": ms, "avg_us": 1e3 * ms / max(len(recs), 1),
+                        "work": float(sum(r[2] for r in recs)), "bytes": float(sum(r[3] for r in recs))}
+        return out
 
     def summary(self):
         """name -> dict(launches, total_ms, avg_us, work) — call after torch.cuda.synchronize()."""
@@ -46,14 +59,14 @@ def set_kernel_timer(t: Optional[KernelTimer]) -> None:
     _TIMER = t
 
 
-def _timed(name: str, work: float, fn, nbytes: float = 0.0):
+def _timed(name: str, work: float, fn, nbytes: float = 0.0, sub=None):
     if _TIMER is None or (_TIMER.only is not None and name not in _TIMER.only):
         return fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     r = fn()
     e.record()
-    _TIMER.add(name, s, e, work, nbytes)
+    _TIMER.add(name, s, e, work, nbytes, sub)
     return r
 
 
@@ -161,7 +174,14 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
     # algorithmic bytes: both operands once, every output / epilogue operand once
     nb = 2.0 * (M * K + N * K) + M * N * (c.element_size() + (2 if out_preact else 0) + (2 if dact_aux is not None else 0)
                                           + (residual.element_size() if residual is not None else 0))
-    check(_timed("gemm_nt", 2.0 * M * N * K, lambda: _lib().clipk_gemm_nt(C.byref(args), _stream()), nb), "clipk_gemm_nt")
+    sub = None
+    if _TIMER is not None:                                   # epilogue mode of this launch (bench.py: per-mode rates)
+        sub = ("dact_" + str(dact) if dact_aux is not None else ("act_" + str(act) if act else "linear")) + \
+              ("+preact" if out_preact else "") + ("+rope" if rope is not None else "") + \
+              ("+res_" + ("f32" if residual.dtype == torch.float32 else "bf16") if residual is not None else "") + \
+              ("+drop" if dropout else "") + ("->f32" if c.dtype == torch.float32 else "->bf16")
+    check(_timed("gemm_nt", 2.0 * M * N * K, lambda: _lib().clipk_gemm_nt(C.byref(args), _stream()), nb, sub),
+          "clipk_gemm_nt")
     return (c, pre) if out_preact else c
 
 

@@ -109,3 +109,29 @@ def tri_modal_losses(cell_embed, pert_embed, protein_embed, logit_scale):
     ce = clip_loss_symmetric((cell_embed @ protein_embed.t()) * s)
     pe = clip_loss_symmetric((pert_embed @ protein_embed.t()) * s)
     return cp + ce + pe, cp, ce, pe
+
+
+def memory_queue_enqueue(queue: torch.Tensor, ptr: int, embeddings: torch.Tensor):
+    """tong/utils/data.py:154-184 `MemoryQueue.enqueue_dequeue` as a pure function: FIFO write of the batch at `ptr`
+    with true wrap-around (the tail of the batch continues at row 0); returns (queue, new ptr).  The reference returns
+    the WHOLE queue, zero rows that were never written included."""
+    size, n = queue.shape[0], embeddings.shape[0]
+    q = queue.clone()
+    e = embeddings.detach()
+    if ptr + n > size:
+        first = size - ptr
+        q[ptr:] = e[:first]
+        q[: n - first] = e[first:]
+        return q, n - first
+    q[ptr:ptr + n] = e
+    return q, (ptr + n) % size
+
+
+def contrastive_loss_queue(x, y, temperature: float = 0.1, queue: Optional[torch.Tensor] = None):
+    """tong/utils/losses.py:4-19: normalise both, append the queue rows to the keys, one-sided CE(x y^T / tau, arange)."""
+    x = l2_normalize(x)
+    y = l2_normalize(y)
+    if queue is not None:
+        y = torch.cat([y, queue.detach()], dim=0)
+    sim = (x @ y.t()) / temperature
+    return (torch.logsumexp(sim, dim=1) - sim[:, : x.shape[0]].diagonal()).mean()

@@ -53,3 +53,20 @@ def contrastive_model_forward(sd: SD, cell_state, connectivity, gene_esm_embeddi
     total, cp, cpr, ppr = clip_ref.tri_modal_losses(ce, pe, pr, sd["logit_scale"])
     return {"cell_embed": ce, "pert_embed": pe, "protein_embed": pr, "loss": total, "cell_pert_loss": cp,
             "cell_protein_loss": cpr, "pert_protein_loss": ppr}
+
+
+def rnarbp_clip_forward(sd: SD, rna_emb, rbp_emb, num_layers: int = 3):
+    """RNARBPCLIPModel.forward of current/rna_clip_codes.ipynb:1925-1954 (state_dict keys of that class): NaN-padded
+    `[B, L, D]` inputs -> `create_padding_mask` (:1726-1736) -> 3 x nn.TransformerEncoderLayer(d, 8 heads, 4d, relu) +
+    LayerNorm fed (B, L, D) although batch_first=False, mask transposed to match (:1936-1946): attention runs over the
+    BATCH axis per position -> position 0 -> RNARBPCLIPProjectionHead -> normalise -> symmetric CE
+    with exp(logit_scale).  Returns (rna_embed, rbp_embed, loss)."""
+    def enc(x, prefix):
+        valid = ~torch.isnan(x).any(-1)                      # [B, L]
+        xt = torch.nan_to_num(x, 0.0).transpose(0, 1)        # [L, B, D]: "batch" = position, "sequence" = sample
+        y = encoder_ref.post_ln_encoder(xt, sd, prefix, num_layers, 8, valid.transpose(0, 1), "relu", 1e-5, 1e-5)
+        return y.transpose(0, 1)[:, 0]
+    a = clip_ref.l2_normalize(clip_ref.optimized_projection_head(enc(rna_emb, "rna_encoder"), sd, "rna_projection"))
+    b = clip_ref.l2_normalize(clip_ref.optimized_projection_head(enc(rbp_emb, "rbp_encoder"), sd, "rbp_projection"))
+    loss = clip_ref.clip_loss_symmetric((a @ b.t()) * sd["logit_scale"].exp())
+    return a, b, loss

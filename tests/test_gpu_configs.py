@@ -307,3 +307,47 @@ def test_c5_icnn_factory_dims_vs_oracle(dev, B):
         c = getattr(model, name).cost(src.to(dev), tgts[name].to(dev))
         cref, _, _ = icnn_ref.transport_cost(ref, clip_ref._ln(tgts[name], sd, f"{name}.output_norm", 1e-5))
         assert abs(c.cost.item() - cref.item()) < 1e-3, (name, c.cost.item(), cref.item())
+
+
+# ------------------------------------------------------------------------------ the notebook model at its own dims
+def test_notebook_model_at_its_own_dims_vs_oracle(dev):
+    """VERDICT r02 #3a / missing #5: the ONE variant the reference trained (current/rna_clip_codes.ipynb:2312-2360:
+    71,646,299 parameters, RNA features [32, L, 120] -> head dim 15 (zero-padded to 16 in the kernels), RBP features
+    [32, 557-2542, 1280] -> head dim 160, 3 post-LN layers each, projection 512) at B = 32 with L_rbp = 600 and ragged
+    NaN padding, against the CPU oracle (pinned to the reference by notebook_model(_b32).npz at reduced widths):
+    |loss_gpu - loss_oracle| <= 1e-3 and gradient directions at both ends of both towers."""
+    import clip_dplm_amd as K
+    from oracle import model_ref
+    torch.manual_seed(0)
+    m = K.RNARBPCLIPModel(rna_dim=120, rbp_dim=1280, projection_dim=512).eval()
+    assert sum(p.numel() for p in m.parameters()) == 71_646_299                  # the logged parameter count (:2312)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(7)
+    B, Lr, Lp = 32, 48, 600
+    rna = torch.randn(B, Lr, 120, generator=g)
+    rbp = torch.randn(B, Lp, 1280, generator=g)
+    lr = torch.randint(10, Lr + 1, (B,), generator=g)
+    lp = torch.randint(Lp // 3, Lp + 1, (B,), generator=g)
+    lr[0], lp[0] = Lr, Lp
+    for i in range(B):
+        rna[i, lr[i]:] = float("nan")
+        rbp[i, lp[i]:] = float("nan")
+    m = m.to(dev)
+    ea, eb, loss = m(rna.to(dev), rbp.to(dev))
+    loss.backward()
+    names = ["rbp_encoder.layers.0.self_attn.in_proj_weight", "rbp_encoder.layers.2.linear2.weight",
+             "rna_encoder.layers.0.self_attn.in_proj_weight", "rna_encoder.layers.2.linear1.weight",
+             "rbp_projection.projection.0.weight", "rna_projection.skip.weight", "logit_scale"]
+    sdr = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 64)))
+    oa, ob, ref = model_ref.rnarbp_clip_forward(sdr, rna, rbp)
+    ref.backward()
+    err = abs(loss.item() - ref.item())
+    print(f"notebook own dims: loss_gpu={loss.item():.6f} loss_oracle={ref.item():.6f} |diff|={err:.2e}")
+    assert err < 1e-3, err
+    assert (ea.cpu() - oa.detach()).abs().max().item() < 0.02 and (eb.cpu() - ob.detach()).abs().max().item() < 0.02
+    got = dict(m.named_parameters())
+    for n in names:
+        c = _cos(got[n].grad, sdr[n].grad) if n != "logit_scale" else 1.0
+        assert c > 0.99, (n, c)
+    assert abs(got["logit_scale"].grad.item() - sdr["logit_scale"].grad.item()) < 0.05 * abs(sdr["logit_scale"].grad.item()) + 1e-4

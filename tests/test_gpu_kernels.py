@@ -399,6 +399,9 @@ def _rope_tables(L, D, dev):
     (2, 256, 4, 32, True, True),
     (2, 130, 3, 16, False, True),
     (9, 256, 5, 24, False, False),     # batch not a multiple of 8 (plain work-item order)
+    (1, 2542, 8, 160, False, True),    # the longest RBP sequence of the reference's run at its head dim (1280 / 8):
+                                       # current/rna_clip_codes.ipynb:2340 ([32, 2542, 1280])
+    (2, 600, 8, 160, False, True),
 ])
 def test_attention_fwd_bwd(dev, B, L, H, D, use_rope, use_mask):
     ops = _ops()
@@ -462,6 +465,40 @@ def test_attention_bwd_whole_head_vs_two_kernel(dev, B, L, H, D, use_rope, waves
     assert torch.isfinite(g1).all()
     denom = g2.abs().max().item()
     assert (g1 - g2).abs().max().item() / denom < 8e-3       # one bf16 ulp of the largest gradient
+
+
+@pytest.mark.parametrize("B,L,H", [(8, 256, 8), (3, 190, 4), (2, 129, 2), (5, 255, 3), (1, 256, 1), (16, 233, 8)])
+def test_attention_bwd_whole_head_hd96_vs_two_kernel(dev, B, L, H, kopt):
+    """The whole-head backward for the RNA encoder's heads (hd 96, 128 < L <= 256: one workgroup per head, every operand
+    read once, 5 products) against the dQ + dK/dV pair and against f32 autograd: ragged lengths + key padding, the
+    delta = rowsum(dO * O) side output, bitwise reproducibility."""
+    ops = _ops()
+    D = 96
+    qkv = _rand((B * L, 3 * H * D), dev, 170, 1.0, dtype=torch.bfloat16)
+    dout = _rand((B * L, H * D), dev, 171, 1.0, dtype=torch.bfloat16)
+    scale = D ** -0.5
+    lens = torch.tensor([L] + [max(1, L - 37 * (i + 1)) for i in range(B - 1)])
+    mask = (torch.arange(L)[None] < lens[:, None]).to(torch.uint8).contiguous().to(dev)
+    dout = (dout.view(B, L, -1) * mask[..., None].to(dout.dtype)).view(B * L, -1).contiguous()
+    for m in (mask, None):
+        out, lse = ops.attn_fwd(qkv, B, L, H, D, key_mask=m, rope=None, q_scale=scale)
+        kw = dict(key_mask=m, rope=None, q_scale=scale)
+        kopt("attn_fused_bwd", 0)
+        g2 = ops.attn_bwd(qkv, out, dout, lse, B, L, H, D, **kw).float()
+        kopt("attn_fused_bwd", 1)
+        g1 = ops.attn_bwd(qkv, out, dout, lse, B, L, H, D, **kw).float()
+        assert torch.equal(g1, ops.attn_bwd(qkv, out, dout, lse, B, L, H, D, **kw).float())      # reproducible
+        m3 = (m if m is not None else torch.ones_like(mask)).view(B * L, 1).float()
+        g1, g2 = g1 * m3, g2 * m3
+        assert torch.isfinite(g1).all()
+        denom = g2.abs().max().item()
+        assert (g1 - g2).abs().max().item() / denom < 8e-3, (g1 - g2).abs().max().item() / denom
+        # ... and against f32 autograd on the same bf16-rounded inputs
+        qf = qkv.float().requires_grad_(True)
+        ref, _ = _attn_ref(qf, B, L, H, D, m, None, scale)
+        gref, = torch.autograd.grad(ref, qf, dout.float())
+        gref = gref * m3
+        assert (g1 - gref).abs().max().item() / gref.abs().max().item() < 4e-2
 
 
 @pytest.mark.parametrize("B,L,H,D", [(8, 256, 20, 24), (3, 190, 4, 32), (2, 129, 3, 16), (5, 255, 2, 24)])
@@ -675,6 +712,28 @@ def test_attention_varlen_equals_padded_with_mask(dev, H, D, use_rope, lens):
     gr = g_ref[seld].float()
     assert torch.isfinite(gk.float()).all()
     assert (gk.float() - gr).abs().max().item() < 8e-3 * max(1.0, gr.abs().max().item())
+
+
+@pytest.mark.parametrize("H,lens", [(8, [256, 131, 40, 200, 1, 129]), (2, [255, 64, 256])])
+def test_attention_varlen_whole_head_hd96(dev, kopt, H, lens):
+    """Packed batches whose longest sequence fits the hd-96 whole-head backward (one workgroup per (sequence, head), rows
+    and length from cu_seqlens) against the general varlen kernels."""
+    ops = _ops()
+    D = 96
+    B, Lm, T = len(lens), max(lens), sum(lens)
+    g = torch.Generator().manual_seed(T + D)
+    qkv = (torch.randn(T, 3 * H * D, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    dout = (torch.randn(T, H * D, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    cu = torch.zeros(B + 1, dtype=torch.int32)
+    cu[1:] = torch.cumsum(torch.tensor(lens), 0)
+    cu = cu.to(dev)
+    qs = D ** -0.5
+    o, lse = ops.attn_varlen_fwd(qkv, cu, Lm, H, D, rope=None, q_scale=qs)
+    g1 = ops.attn_varlen_bwd(qkv, o, dout, lse, cu, Lm, H, D, rope=None, q_scale=qs)
+    kopt("attn_fused_bwd", 0)
+    g0 = ops.attn_varlen_bwd(qkv, o, dout, lse, cu, Lm, H, D, rope=None, q_scale=qs)
+    assert torch.isfinite(g1.float()).all()
+    assert (g1.float() - g0.float()).abs().max().item() < 8e-3 * max(1.0, g0.float().abs().max().item())
 
 
 @pytest.mark.parametrize("H,D,lens", [(20, 24, [256, 200, 37, 129, 1, 64]), (4, 32, [130, 255, 3]), (6, 16, [256, 256, 17])])

@@ -49,6 +49,7 @@ def _steps(K, m, opt, ids, rna, group, dev):
             if not getattr(opt, "overlap", False):              # this rank's contribution, by parameter
                 out["grad"] = torch.cat([opt.flat.grad[o:o + p.numel()].float()
                                          for p, o in zip(opt.flat.params, opt.flat.offsets)]).cpu()
+                out["grad_mp"] = torch.cat([p.grad.detach().float().reshape(-1) for p in m.parameters()]).cpu()
         opt.step()
     torch.cuda.synchronize()
     out["loss2"] = loss.item()
@@ -99,14 +100,24 @@ def test_rccl_ranks_match_single_process(dev, world):
     gsum = sum(res[r]["plain"]["grad"] for r in range(world))
     assert cos(gsum, ref["grad"], dim=0) > 0.995                                    # summed rank gradients
     assert (gsum - ref["grad"]).abs().max() < 0.05 * ref["grad"].abs().max()
+    live, o = torch.zeros_like(ref["grad_mp"], dtype=torch.bool), 0
+    for p in m.parameters():                                   # per parameter: small tensors are judged on their own scale
+        gp = ref["grad_mp"][o:o + p.numel()].abs()
+        live[o:o + p.numel()] = gp >= 0.01 * gp.max().clamp_min(1e-30)
+        o += p.numel()
+    assert live.float().mean() > 0.2
     for r in range(world):
         for mode in ("plain", "overlap"):
             got = res[r][mode]
             assert abs(got["loss"] - ref["loss"]) < 1e-3, (mode, got["loss"], ref["loss"])
             assert abs(got["loss2"] - ref["loss2"]) < 2e-3, (mode, got["loss2"], ref["loss2"])
             # AdamW's first steps move a weight by ~lr whatever its gradient's size, so entries whose gradient is
-            # rounding noise (e.g. the key bias, analytically zero) may step the other way: compare the update's direction
-            assert cos(got["params"] - got["init"], ref["params"] - ref["init"], dim=0) > 0.9, (mode, r)
+            # rounding noise (e.g. the key bias, analytically zero) may step the other way: the update's direction is
+            # compared on the entries whose single-process gradient is not negligible (>= 1 % of the largest entry of
+            # its own parameter), where a mis-sharded bucket of small parameters would show
+            du, dr = got["params"] - got["init"], ref["params"] - ref["init"]
+            assert cos(du[live], dr[live], dim=0) > 0.99, (mode, r, cos(du[live], dr[live], dim=0).item())
+            assert cos(du, dr, dim=0) > 0.9, (mode, r)
         assert res[r]["overlap"]["reduced_in_backward"] == [True, True, False]     # both encoder stacks' buckets
         assert torch.equal(res[r]["overlap"]["params"], res[r]["plain"]["params"])  # same arithmetic, other schedule
         assert torch.equal(res[r]["plain"]["params"], res[0]["plain"]["params"])    # ranks hold identical weights

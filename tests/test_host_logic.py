@@ -453,3 +453,194 @@ def test_overlapped_bucket_reduce_waits_for_every_backward(monkeypatch, tmp_path
         assert torch.equal(s1, g1)                        # world 1: the shard IS the whole flat gradient
     finally:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------- round-3 boundary rows
+def test_esm_integration_surface_matches_the_reference():
+    """VERDICT r02 #1 / SURVEY a12: ESMConfig (triple_flow/1_config.py:153-183), ESMIntegration(config)
+    (3_esm_integration.py:53-72), create_esm_integration / get_embeddings_batch (:215-245): construction, attributes,
+    state_dict keys (== the reference module's, recorded in the fixture), the tokenizer, the errors."""
+    import dataclasses
+
+    import clip_dplm_amd as K
+    from clip_dplm_amd import esm_integration as E
+    from clip_dplm_amd.encoders import ESM2_SHAPES
+    cfg = K.ESMConfig()
+    assert [f.name for f in dataclasses.fields(cfg)] == ["model_name", "esm_dim", "protein_dim", "gene_dim",
+                                                          "num_attention_heads", "dropout", "use_sequence_context",
+                                                          "max_sequence_length", "tokenizer_path"]
+    assert (cfg.model_name, cfg.esm_dim, cfg.protein_dim, cfg.gene_dim, cfg.max_sequence_length) == \
+        ("esm2_t33_650M_UR50D", 1280, 512, 512, 1024)
+    with pytest.raises(ValueError, match="Invalid ESM model"):
+        K.ESMConfig(model_name="esm1b").validate_model()
+    assert {m.name: m.value for m in K.BiologicalDataType}["PROTEIN_SEQUENCE"] == "protein_sequence"
+    ESM2_SHAPES["test_tiny96"] = (2, 96, 4, 384)
+    m = K.ESMIntegration(K.ESMConfig(model_name="test_tiny96", esm_dim=96, protein_dim=32, gene_dim=32,
+                                     max_sequence_length=24))
+    assert m.config.max_sequence_length == 24 and m.cache == {}
+    assert not any(p.requires_grad for p in m.model.parameters())                  # :83-84
+    assert all(p.requires_grad for p in m.protein_projection.parameters())
+    z = np.load(os.path.join(G, "esm_integration.npz"))
+    ref_keys = {k[2:] for k in z.files if k.startswith("w:")}
+    own = set(m.state_dict())
+    # (EsmModel's buffers and its contact-prediction head — not on the path — are the only reference keys without a twin)
+    extra = {k for k in ref_keys - own if not (k.endswith("position_ids") or "inv_freq" in k or "contact_head" in k)}
+    assert not extra and not (own - ref_keys), (sorted(extra)[:5], sorted(own - ref_keys)[:5])
+    m.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}, strict=False)
+    # keyword alias of earlier rounds, and the factory
+    m2 = K.ESMIntegration("test_tiny96", protein_dim=16, gene_dim=8, max_sequence_length=50)
+    assert m2.config.esm_dim == 96 and m2.max_sequence_length == 50
+    m3 = K.create_esm_integration("test_tiny96", esm_dim=96, protein_dim=16)
+    assert isinstance(m3, K.ESMIntegration) and m3.config.protein_dim == 16
+    with pytest.raises(ValueError, match="hidden size"):
+        K.ESMIntegration(K.ESMConfig(model_name="test_tiny96"))                    # esm_dim 1280 != 96
+    # tokenizer == transformers.EsmTokenizer on the fixture's vectors
+    ids, mask = E.tokenize([str(s) for s in z["sequences"]], 24)
+    assert torch.equal(ids, torch.from_numpy(z["input_ids"])) and torch.equal(mask, torch.from_numpy(z["attention_mask"]))
+    ids, mask = E.tokenize([str(s) for s in z["edge_sequences"]], 16)
+    assert torch.equal(ids, torch.from_numpy(z["edge_input_ids"]))
+    assert torch.equal(mask, torch.from_numpy(z["edge_attention_mask"]))
+
+
+def test_esm_integration_get_embeddings_emulated(monkeypatch):
+    """get_embeddings end to end on the emulated kernels vs the reference's outputs: truncation, cache hit keyed on the
+    sequences only (3_esm_integration.py:100-102), get_embeddings_batch."""
+    ops_emulator.install(monkeypatch)
+    import clip_dplm_amd as K
+    from clip_dplm_amd.encoders import ESM2_SHAPES
+    ESM2_SHAPES["test_tiny96"] = (2, 96, 4, 384)
+    z = np.load(os.path.join(G, "esm_integration.npz"))
+    m = K.ESMIntegration(K.ESMConfig(model_name="test_tiny96", esm_dim=96, protein_dim=32, gene_dim=32,
+                                     max_sequence_length=24)).eval()
+    m.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")}, strict=False)
+    seqs = [str(s) for s in z["sequences"]]
+    out = m.get_embeddings(seqs, K.BiologicalDataType.PROTEIN_SEQUENCE)
+    mask = torch.from_numpy(z["attention_mask"])[..., None].float()
+    ref = torch.from_numpy(z["protein_embeddings"])
+    assert out.embeddings.shape == ref.shape and out.attention_weights is None
+    assert ((out.embeddings - ref) * mask).abs().max().item() < 0.08             # bf16 GEMM emulation, LN outputs
+    assert m.get_embeddings(seqs, K.BiologicalDataType.PERTURBATION) is out       # cache ignores data_type
+    m.cache.clear()
+    g = m.get_embeddings(seqs, K.BiologicalDataType.GENE_EXPRESSION).embeddings
+    assert (g - torch.from_numpy(z["gene_embeddings"])).abs().max().item() < 0.1
+    m.cache.clear()
+    same_len = ["ACDEFGHIKL", "LKIHGFEDCA", "MMMMMMMMMM", "ACDEFGHIKA"]
+    b = K.get_embeddings_batch(same_len, m, K.BiologicalDataType.PROTEIN_SEQUENCE, batch_size=2)
+    assert b.shape == (4, 12, 32)
+    with pytest.raises(RuntimeError):                                           # ragged slices: torch.cat raises, as upstream
+        K.get_embeddings_batch(["ACD", "ACDE", "ACDEFGH", "A"], m, K.BiologicalDataType.PROTEIN_SEQUENCE, batch_size=2)
+
+
+def test_protein_rna_clip_from_config():
+    """HybridCLIPConfig -> model.  architectures['transformer'] (run1/configuration_hybrid_clip.py
+    :153-157 + :68-79), projection_dim, logit_scale_init_value, use_mean_pooling are consumed."""
+    import clip_dplm_amd as K
+    from clip_dplm_amd.encoders import ESM2_SHAPES
+    ESM2_SHAPES["test_tiny96"] = (2, 96, 4, 384)
+    cfg = K.HybridCLIPConfig(rna_config={}, protein_config={}, diffmap_config={})
+    arch = cfg.architectures["transformer"]
+    assert (arch.num_layers, arch.hidden_size, arch.attention_heads, arch.intermediate_size, arch.hidden_act,
+            arch.layer_norm_eps) == (6, 768, 8, 2048, "gelu", 1e-12)
+    m = K.ProteinRNACLIP.from_config(cfg, esm="test_tiny96")
+    r = m.rna_model
+    assert (r.embed_dim, r.num_layers, r.nhead, r.activation, r.eps, r.dropout) == (768, 6, 8, "gelu", 1e-12, 0.1)
+    assert r.layers[0].linear1.weight.shape == (2048, 768)
+    assert m.rna_projection.projection[4].weight.shape == (512, 1024) and m.pooling == "mean"
+    assert abs(m.logit_scale.item() - 2.6592) < 1e-6 and m.config is cfg
+    # the same keys as the directly constructed BASELINE model
+    direct = K.ProteinRNACLIP(esm="test_tiny96")
+    assert set(m.state_dict()) == set(direct.state_dict())
+    cfg2 = K.HybridCLIPConfig(rna_config={}, protein_config={}, diffmap_config={}, projection_dim=64,
+                              logit_scale_init_value=1.5, use_mean_pooling=False,
+                              architectures={"transformer": K.ModelArchitectureConfig(
+                                  type="transformer", num_layers=2, hidden_size=64, attention_heads=4,
+                                  intermediate_size=128, hidden_act="relu", layer_norm_eps=1e-5, dropout=0.0)})
+    m2 = K.ProteinRNACLIP.from_config(cfg2, esm="test_tiny96", freeze_protein_encoder=True)
+    assert (m2.rna_model.embed_dim, m2.rna_model.num_layers, m2.rna_model.nhead, m2.rna_model.activation) == (64, 2, 4, "relu")
+    assert m2.pooling == "first" and abs(m2.logit_scale.item() - 1.5) < 1e-6
+    assert m2.protein_projection.projection[4].weight.shape == (64, 128)
+    assert not any(p.requires_grad for p in m2.protein_model.parameters())
+    with pytest.raises(ValueError, match="transformer"):
+        K.ProteinRNACLIP.from_config(cfg, architecture="mlp")
+
+
+def test_cache_semantics_reference_vs_fifo(monkeypatch):
+    """SURVEY §8f-1 / VERDICT r02 #4: `cache_semantics="reference"` = old/clip_opt.py:76-81 (reset to 0 on overflow,
+    cache[:ptr]); "fifo" = tong/utils/data.py:154-184 (true wrap-around, every row written so far).  Identical until
+    the first wrap; the fifo rows equal the oracle's MemoryQueue restatement (pinned by queue_loss.npz)."""
+    ops_emulator.install(monkeypatch)
+    import clip_dplm_amd as K
+    cfg = NS(diffmap_config=sub(16), protein_config=sub(16), projection_dim=8, cache_size=40)
+    torch.manual_seed(0)
+    ref_m, fifo_m = K.OptimizedCLIPModule(cfg).eval(), K.OptimizedCLIPModule(cfg, cache_semantics="fifo").eval()
+    fifo_m.load_state_dict(ref_m.state_dict())
+    with pytest.raises(ValueError):
+        K.OptimizedCLIPModule(cfg, cache_semantics="lifo")
+    g = torch.Generator().manual_seed(3)
+    oq, optr = torch.zeros(40, 8), 0
+    for step in range(4):                                              # 4 x 16 rows into 40: wraps at step 2
+        d, p = torch.randn(16, 16, generator=g), torch.randn(16, 16, generator=g)
+        lr, lf = ref_m.loss(d, p), fifo_m.loss(d, p)
+        _, ep = fifo_m.embed(d, p)
+        oq, optr = clip_ref.memory_queue_enqueue(oq, optr, ep.detach())
+        assert fifo_m.cache_ptr == optr and fifo_m.cache_filled == min(40, 16 * (step + 1))
+        assert torch.equal(fifo_m.protein_embedding_cache, oq)
+        if step < 2:
+            assert torch.equal(lr, lf) and ref_m.cache_ptr == fifo_m.cache_ptr
+        else:
+            assert ref_m.cache_rows().shape[0] < fifo_m.cache_rows().shape[0] == 40
+            assert lf.item() > lr.item()                               # more negatives: larger partition function
+    out = fifo_m(d, p, gather_distributed=False)
+    assert out["logits_per_diffmap_cache"].shape == (16, 40)
+    # MemoryQueue mirror: same states as the reference's class on the fixture's batches
+    z = np.load(os.path.join(G, "queue_loss.npz"))
+    q = K.MemoryQueue(64, 16)
+    for step in range(5):
+        full = q.enqueue_dequeue(torch.nn.functional.normalize(torch.from_numpy(z[f"y{step}"]), dim=-1))
+        assert torch.equal(full, torch.from_numpy(z[f"queue{step}"])) and q.ptr == int(z[f"ptr{step}"])
+    # contrastive_loss (tong/utils/losses.py:4-19) on the emulated fused kernels vs the reference's values
+    q2 = torch.zeros(64, 16)
+    for step in range(5):
+        x, y = torch.from_numpy(z[f"x{step}"]), torch.from_numpy(z[f"y{step}"])
+        assert abs(K.contrastive_loss(x, y, 0.1, q2).item() - float(z[f"loss{step}"])) < 1e-4
+        q2 = torch.from_numpy(z[f"queue{step}"])
+    assert abs(K.contrastive_loss(x, y, 0.1).item() - float(z["loss_noqueue"])) < 1e-4
+
+
+def _run_bench(extra, env_extra=None, drop_dist_env=True):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if not (drop_dist_env and k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"))}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, capture_output=True, text=True,
+                          env=env, timeout=600)
+
+
+def test_bench_self_launch_plumbing_with_two_gloo_ranks():
+    """VERDICT r02 #8 (first contact with a multi-GPU node, rehearsed on CPU): `bench.py --gpus 2` starts its own two
+    ranks through torch.distributed.run; rank 0's JSON line is the ONLY thing on stdout (library chatter and the other
+    rank stay off it); a failing child gives a non-zero return code; a WORLD_SIZE / --gpus mismatch exits cleanly."""
+    import json
+    r = _run_bench(["--config", "stub", "--gpus", "2", "--steps", "3", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["checksum"] == 1024 * 2.0 * (1 + 2)                     # the all-reduce saw both ranks
+    assert "library chatter" in r.stderr and "library chatter" not in r.stdout
+    # a rank that dies after the rendezvous: the launcher's return code is the bench's
+    r = _run_bench(["--config", "stub", "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                   {"CLIPK_BENCH_STUB_FAIL_RANK": "1"})
+    assert r.returncode != 0 and not r.stdout.strip()
+    assert "rank 1 fails on request" in r.stderr
+    # under a launcher whose world size is not --gpus: one clean message, no traceback, no JSON
+    r = _run_bench(["--config", "stub", "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                   {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, drop_dist_env=False)
+    assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE=1" in r.stderr and "Traceback" not in r.stderr
+    assert not r.stdout.strip()
+    # one rank, no launcher: same line
+    r = _run_bench(["--config", "stub", "--gpus", "1", "--steps", "2", "--warmup", "0"])
+    assert r.returncode == 0 and json.loads(r.stdout.strip())["n_gpus"] == 1

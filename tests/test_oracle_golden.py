@@ -189,3 +189,59 @@ def test_trimodal_oracle_vs_reference_fixture():
         assert (o[k] - tt(k)).abs().max().item() < 3e-5, k
     for k in ("cell_pert_loss", "cell_protein_loss", "pert_protein_loss", "loss"):
         assert abs(o[k].item() - float(z[k])) < 3e-5, k
+
+
+# ---------------------------------------------------------------------------------------------- round-3 fixtures
+def test_clip_opt_b128():
+    """old/clip_opt.py at its caller's batch (B = 128), cache holding two earlier batches."""
+    z, sd = load("clip_opt_b128.npz")
+    o = clip_ref.optimized_clip_forward(sd, t(z, "diffmap"), t(z, "protein"), t(z, "cache"))
+    assert torch.allclose(o["logits_per_diffmap_protein"], t(z, "logits"), atol=3e-5)
+    assert torch.allclose(o["logits_per_diffmap_cache"], t(z, "logits_cache"), atol=3e-5)
+    assert abs(clip_ref.optimized_clip_loss(o).item() - float(z["loss"])) < 1e-5
+
+
+def test_notebook_model_b32_loss_and_grads():
+    """The notebook model at B = 32 with ragged NaN padding: embeddings, loss and EVERY parameter gradient of the
+    reference's autograd."""
+    from oracle import model_ref
+    z, sd = load("notebook_model_b32.npz")
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    a, b, loss = model_ref.rnarbp_clip_forward(sdg, t(z, "rna"), t(z, "rbp"))
+    assert torch.allclose(a, t(z, "rna_embed"), atol=2e-5) and torch.allclose(b, t(z, "rbp_embed"), atol=2e-5)
+    assert abs(loss.item() - float(z["loss"])) < 2e-5
+    loss.backward()
+    for k, v in sdg.items():
+        ref = t(z, "g:" + k)
+        assert (v.grad - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item()), k
+
+
+def test_memory_queue_and_queue_loss():
+    """tong/utils/data.py:154-184 + tong/utils/losses.py:4-19: five batches of 24 rows through a 64-row queue (wraps
+    twice): queue contents, pointer and the tau = 0.1 one-sided loss against the queue BEFORE each enqueue."""
+    z = np.load(os.path.join(G, "queue_loss.npz"))
+    q, ptr = torch.zeros(64, 16), 0
+    for step in range(5):
+        x, y = t(z, f"x{step}"), t(z, f"y{step}")
+        assert abs(clip_ref.contrastive_loss_queue(x, y, 0.1, q).item() - float(z[f"loss{step}"])) < 2e-6
+        q, ptr = clip_ref.memory_queue_enqueue(q, ptr, torch.nn.functional.normalize(y, dim=-1))
+        assert torch.equal(q, t(z, f"queue{step}")) and ptr == int(z[f"ptr{step}"])
+    assert abs(clip_ref.contrastive_loss_queue(x, y, 0.1, None).item() - float(z["loss_noqueue"])) < 2e-6
+
+
+def test_esm_integration_end_to_end():
+    """triple_flow/3_esm_integration.py:90-135 run by the reference itself (tools/make_golden.py gen_esm_integration):
+    tokenizer (truncation at max_sequence_length, <unk> runs, in-text special tokens), frozen ESM-2, both projections."""
+    from oracle import esm_integration_ref as eref
+    z, sd = load("esm_integration.npz")
+    seqs = [str(s) for s in z["sequences"]]
+    kw = dict(esm_layers=2, esm_heads=4, max_sequence_length=24)
+    p, ids, mask = eref.get_embeddings(seqs, sd, protein=True, **kw)
+    g, _, _ = eref.get_embeddings(seqs, sd, protein=False, **kw)
+    assert torch.equal(ids, t(z, "input_ids")) and torch.equal(mask, t(z, "attention_mask"))
+    assert ids.shape[1] == 24 and ids[0, -1].item() == 2                  # the long sequence was cut to 22 residues
+    m = mask[..., None].float()
+    assert torch.allclose(p * m, t(z, "protein_embeddings") * m, atol=5e-5)
+    assert torch.allclose(g, t(z, "gene_embeddings"), atol=5e-5)
+    ei, em = eref.tokenize([str(s) for s in z["edge_sequences"]], 16)
+    assert torch.equal(ei, t(z, "edge_input_ids")) and torch.equal(em, t(z, "edge_attention_mask"))

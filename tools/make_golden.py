@@ -405,6 +405,165 @@ def gen_esm_projections():
     save("esm_projections.npz", **arrays)
 
 
+
+# ------------------------------------------------------------------------------------------------ larger-batch variants
+def gen_clip_opt_b128(refclip):
+    """old/clip_opt.py at the batch of its caller (run1/full.py:189-198: B = 128), three batches so the cache holds two
+    earlier ones: the loss bar of the GPU test is the north-star 1e-3 at this batch."""
+    import clip_opt as refopt
+    refopt.CLIPEncoder = refclip.CLIPEncoder
+    cfg = NS(diffmap_config=sub(48), protein_config=sub(96), projection_dim=32, cache_size=512)
+    torch.manual_seed(1)
+    m = refopt.OptimizedCLIPModule(cfg).eval()
+    g = torch.Generator().manual_seed(17)
+    B = 128
+    batches = [(torch.randn(B, 48, generator=g), torch.randn(B, 96, generator=g)) for _ in range(3)]
+    with torch.no_grad():
+        for d, pr in batches[:2]:
+            m(d, pr, gather_distributed=False)
+        ptr_before = m.cache_ptr
+        out = m(*batches[2], gather_distributed=False)
+        loss = refopt.optimized_clip_loss(out)
+    cache = m.protein_embedding_cache[: m.cache_ptr].clone()
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    o = clip_ref.optimized_clip_forward(sd, batches[2][0], batches[2][1], cache)
+    check("opt b128 logits", o["logits_per_diffmap_protein"], out["logits_per_diffmap_protein"], 3e-5)
+    check("opt b128 loss", clip_ref.optimized_clip_loss(o), loss, 2e-6)
+    save("clip_opt_b128.npz", diffmap=batches[2][0].numpy(), protein=batches[2][1].numpy(), cache=cache.numpy(),
+         cache_ptr=m.cache_ptr, cache_ptr_before=ptr_before, logits=out["logits_per_diffmap_protein"].numpy(),
+         logits_cache=out["logits_per_diffmap_cache"].numpy(), loss=loss.item(), **sd_np(m))
+
+
+def gen_notebook_b32():
+    """The notebook model (current/rna_clip_codes.ipynb cells 24 + 28) at the notebook's batch size (B = 32, :1987) and
+    reduced widths (the 71.6 M-parameter original does not fit a fixture; tests/test_gpu_configs.py runs it at its own
+    widths against the oracle this function checks)."""
+    from oracle import model_ref
+    nb = json.load(open(REF + "/current/rna_clip_codes.ipynb"))
+    ns = {"torch": torch, "nn": nn, "F": F, "np": np}
+    for i in (24, 28):
+        exec("".join(nb["cells"][i]["source"]), ns)
+    torch.manual_seed(2)
+    model = ns["RNARBPCLIPModel"](rna_dim=40, rbp_dim=128, projection_dim=64).eval()
+    g = torch.Generator().manual_seed(5)
+    B, Lr, Lp = 32, 12, 40
+    rna = torch.randn(B, Lr, 40, generator=g)
+    rbp = torch.randn(B, Lp, 128, generator=g)
+    lr = torch.randint(3, Lr + 1, (B,), generator=g)
+    lp = torch.randint(9, Lp + 1, (B,), generator=g)
+    lr[0], lp[0] = Lr, Lp
+    for i in range(B):
+        rna[i, lr[i]:] = float("nan")
+        rbp[i, lp[i]:] = float("nan")
+    rna.requires_grad_(False)
+    ea, eb, loss = model(rna, rbp)
+    grads = torch.autograd.grad(loss, list(model.parameters()))
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    oa, ob, ol = model_ref.rnarbp_clip_forward(sdg, rna, rbp)
+    check("notebook b32 rna embed", oa.detach(), ea.detach(), 2e-5)
+    check("notebook b32 rbp embed", ob.detach(), eb.detach(), 2e-5)
+    check("notebook b32 loss", ol.detach(), loss.detach(), 2e-5)
+    ol.backward()
+    for (n, _), gr in zip(model.named_parameters(), grads):
+        err = (sdg[n].grad - gr).abs().max().item()
+        assert err <= 1e-4 * max(1.0, gr.abs().max().item()), (n, err)
+    print("  oracle gradients == reference gradients for every parameter")
+    arrays = {"g:" + n: gr.numpy() for (n, _), gr in zip(model.named_parameters(), grads)}
+    save("notebook_model_b32.npz", rna=rna.numpy(), rbp=rbp.numpy(), rna_embed=ea.detach().numpy(),
+         rbp_embed=eb.detach().numpy(), loss=loss.item(), **arrays, **sd_np(model))
+
+
+# ------------------------------------------------------------------------------------------------ tong/ queue + loss
+def gen_queue_loss():
+    """tong/utils/data.py:154-184 `MemoryQueue` (true wrap-around FIFO) and tong/utils/losses.py:4-19
+    `contrastive_loss` (one-sided, tau = 0.1, queue rows appended to the keys).  data.py imports scanpy / anndata at
+    module level (absent here), so the class is taken by source span, like the notebook cells; losses.py imports."""
+    import ast
+    src = open(REF + "/tong/utils/data.py").read()
+    node = next(n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == "MemoryQueue")
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=[node], type_ignores=[]), "tong/utils/data.py", "exec"), ns)
+    losses = _load("tong_losses", REF + "/tong/utils/losses.py")
+    size, dim, B = 64, 16, 24
+    q = ns["MemoryQueue"](size, dim)
+    g = torch.Generator().manual_seed(23)
+    arrays, oq, optr = {}, torch.zeros(size, dim), 0
+    for step in range(5):                                     # 5 x 24 rows into 64: wraps at step 2 and at step 4
+        x, y = torch.randn(B, dim, generator=g), torch.randn(B, dim, generator=g)
+        loss = losses.contrastive_loss(x, y, temperature=0.1, queue=q.queue)
+        ol = clip_ref.contrastive_loss_queue(x, y, 0.1, oq)
+        check(f"queue loss step {step}", ol, loss, 2e-6)
+        yn = F.normalize(y, dim=-1)
+        full = q.enqueue_dequeue(yn)
+        oq, optr = clip_ref.memory_queue_enqueue(oq, optr, yn)
+        check(f"queue state step {step}", oq, full, 0.0)
+        assert optr == q.ptr, (optr, q.ptr)
+        arrays.update({f"x{step}": x.numpy(), f"y{step}": y.numpy(), f"loss{step}": loss.item(),
+                       f"queue{step}": full.clone().numpy(), f"ptr{step}": q.ptr})
+    loss_noq = losses.contrastive_loss(x, y, temperature=0.1)
+    check("queue loss without queue", clip_ref.contrastive_loss_queue(x, y, 0.1, None), loss_noq, 2e-6)
+    save("queue_loss.npz", loss_noqueue=loss_noq.item(), **arrays)
+
+
+# ------------------------------------------------------------------------------------------------ ESMIntegration e2e
+def gen_esm_integration():
+    """The reference's own `ESMIntegration.get_embeddings` (triple_flow/3_esm_integration.py:90-135) end to end:
+    tokenizer call, frozen ESM-2, projection, cache.  Its two `from_pretrained(<name>)` calls (:77-80) are pointed at a
+    locally constructed seeded `transformers.EsmModel` (explicit shape, as gen_esm) and a `transformers.EsmTokenizer`
+    built from the 33-token alphabet written to a temp file: nothing is fetched."""
+    import tempfile
+    from transformers import EsmConfig, EsmModel, EsmTokenizer
+    from oracle import esm_integration_ref as eref
+    cfgm = _load("config", REF + "/triple_flow/1_config.py")
+    esmi = _load("esm_integration", REF + "/triple_flow/3_esm_integration.py")
+    tmp = tempfile.mkdtemp()
+    with open(os.path.join(tmp, "vocab.txt"), "w") as f:
+        f.write("\n".join(eref.VOCAB) + "\n")
+    hf_cfg = EsmConfig(vocab_size=33, hidden_size=96, num_hidden_layers=2, num_attention_heads=4, intermediate_size=384,
+                       position_embedding_type="rotary", token_dropout=True, emb_layer_norm_before=False,
+                       pad_token_id=1, mask_token_id=32, layer_norm_eps=1e-5, hidden_dropout_prob=0.0,
+                       attention_probs_dropout_prob=0.0)
+
+    def local_model(name):
+        torch.manual_seed(4)
+        return EsmModel(hf_cfg, add_pooling_layer=False)
+    esmi.AutoModel = NS(from_pretrained=local_model)
+    esmi.AutoTokenizer = NS(from_pretrained=lambda name: EsmTokenizer(os.path.join(tmp, "vocab.txt")))
+    cfg = cfgm.ESMConfig(model_name="esm2_t33_650M_UR50D", esm_dim=96, protein_dim=32, gene_dim=32,
+                         max_sequence_length=24)
+    torch.manual_seed(6)
+    ref = esmi.ESMIntegration(cfg).eval()
+    assert not any(p.requires_grad for p in ref.model.parameters())
+    seqs = ["MKTAYIAKQRQISFVKSHFSRQLEERLGLIEVQ",          # longer than max_sequence_length - 2: truncated
+            "ACDEFGHIKLMNPQRSTVWY", "MKV", "AXBZUO", "ACD<mask>EFxyzGH", "M K T A"]
+    P = cfgm.BiologicalDataType.PROTEIN_SEQUENCE
+    out_p = ref.get_embeddings(seqs, P)
+    again = ref.get_embeddings(seqs, cfgm.BiologicalDataType.PERTURBATION)
+    assert again is out_p, "the reference's cache is keyed on the sequences only"
+    ref.cache.clear()
+    out_g = ref.get_embeddings(seqs, cfgm.BiologicalDataType.PERTURBATION)
+    tok = ref.tokenizer(seqs, padding=True, truncation=True, max_length=24, return_tensors="pt")
+    sd = {k: v.detach() for k, v in ref.state_dict().items()}
+    kw = dict(esm_layers=2, esm_heads=4, max_sequence_length=24)
+    op, ids, mask = eref.get_embeddings(seqs, sd, protein=True, **kw)
+    og, _, _ = eref.get_embeddings(seqs, sd, protein=False, **kw)
+    assert torch.equal(ids, tok["input_ids"]) and torch.equal(mask, tok["attention_mask"])
+    m = mask[..., None].float()
+    check("esm integration protein", op * m, out_p.embeddings * m, 5e-5)
+    check("esm integration gene (all keys attended, as the reference does)", og, out_g.embeddings, 5e-5)
+    # tokenizer vectors on their own (EsmTokenizer edge cases)
+    edge = ["ACDxyEF", "AC DE", "A  xy zz C", "A.-B", "A<null_1>C<pad>D<cls>E<eos>F<unk>G", "<mas k>A", " A ", "xyz", "",
+            "MKT" * 20]
+    et = ref.tokenizer(edge, padding=True, truncation=True, max_length=16, return_tensors="pt")
+    ei, em = eref.tokenize(edge, 16)
+    assert torch.equal(ei, et["input_ids"]) and torch.equal(em, et["attention_mask"])
+    save("esm_integration.npz", sequences=np.array(seqs), input_ids=ids.numpy(), attention_mask=mask.numpy(),
+         protein_embeddings=out_p.embeddings.numpy(), gene_embeddings=out_g.embeddings.numpy(),
+         edge_sequences=np.array(edge), edge_input_ids=et["input_ids"].numpy(),
+         edge_attention_mask=et["attention_mask"].numpy(), **sd_np(sd))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "proj":
         _load("config", REF + "/triple_flow/1_config.py")
@@ -412,6 +571,14 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "icnn":
         gen_icnn()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "r03":            # the round-3 additions only
+        sys.path[:0] = [REF + "/run1", REF + "/old"]
+        import clip as _refclip
+        gen_clip_opt_b128(_refclip)
+        gen_notebook_b32()
+        gen_queue_loss()
+        gen_esm_integration()
         sys.exit(0)
     rc = gen_clip_c1()
     gen_clip_opt(rc)
@@ -421,4 +588,8 @@ if __name__ == "__main__":
     gen_esm()
     gen_icnn()
     gen_esm_projections()
+    gen_clip_opt_b128(rc)
+    gen_notebook_b32()
+    gen_queue_loss()
+    gen_esm_integration()
     print("all golden fixtures written and the oracle agrees with the reference on each")

@@ -31,6 +31,15 @@ def per_launch(path, counter, match):
     return tot / n * 1024.0, n
 
 
+def source_hash():
+    """bench.gemm_source_hash(): the entry is only valid for the GEMM sources it was measured on."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    return b.gemm_source_hash()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--fetch", required=True)
@@ -48,7 +57,7 @@ def main():
              "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), KiB per dispatch "
                        "averaged over the kernel's dispatches; FETCH_SIZE x2 (gfx950 reports half of wide reads), "
                        "WRITE_SIZE exact; includes Infinity-Cache hits",
-             "command": a.cmd}
+             "command": a.cmd, "source_sha16": source_hash()}
     data = {}
     if os.path.exists(a.out):
         with open(a.out) as f:

@@ -19,7 +19,7 @@ timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv 
 echo "write pass done"
 F=$(find $OUT/pmc_fetch -name '*counter_collection.csv' | head -1)
 W=$(find $OUT/pmc_write -name '*counter_collection.csv' | head -1)
-python3 tools/pmc_traffic.py --fetch $F --write $W --key c2_B1024 --out $OUT/traffic_gemm_nt.json \
+python3 tools/pmc_traffic.py --fetch $F --write $W --key c2_B1024_L256_full --out $OUT/traffic_gemm_nt.json \
   --cmd "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python3 bench.py $PARGS" || exit 4
 # keep the transfer small: only the stats CSV and the reduced JSON travel back whole; drop the big per-dispatch tables
 find $OUT -name '*kernel_trace.csv' -delete
