@@ -27,6 +27,13 @@ tools/probes/libwgrad_trace.so: clip_dplm_amd/csrc/gemm_wgrad_v3.hip clip_dplm_a
 # ... and its timing ablations (results garbage): make tools/probes/libwgrad_trace_abl3.so
 tools/probes/libwgrad_trace_abl%.so: clip_dplm_amd/csrc/gemm_wgrad_v3.hip clip_dplm_amd/csrc/core.hip clip_dplm_amd/csrc/common.h
 	$(HIPCC) $(HIPFLAGS) -DCLIPK_WGRAD_TRACE -DCLIPK_WGRAD_ABL=$* -shared -o $@ clip_dplm_amd/csrc/gemm_wgrad_v3.hip clip_dplm_amd/csrc/core.hip
+# experiment builds of the 256 x 256 Linear kernel with in-kernel clock stamps (tools/exp_gemm_mfma_shape.py):
+# libgemm_trace16.so = the product's 16x16x32 main loop, libgemm_trace32.so = the same loop issuing 32x32x16 MFMAs
+# (timing only: results garbage).  Both run WITHOUT the epilogue (option gemm_abl = 1): the main loop alone.
+tools/probes/libgemm_trace16.so: clip_dplm_amd/csrc/gemm_nt_v3.hip clip_dplm_amd/csrc/core.hip clip_dplm_amd/csrc/common.h clip_dplm_amd/csrc/gemm_epilogue.h
+	$(HIPCC) $(HIPFLAGS) -DCLIPK_EXPERIMENTS -DCLIPK_GEMM_TRACE -shared -o $@ clip_dplm_amd/csrc/gemm_nt_v3.hip clip_dplm_amd/csrc/core.hip
+tools/probes/libgemm_trace32.so: clip_dplm_amd/csrc/gemm_nt_v3.hip clip_dplm_amd/csrc/core.hip clip_dplm_amd/csrc/common.h clip_dplm_amd/csrc/gemm_epilogue.h
+	$(HIPCC) $(HIPFLAGS) -DCLIPK_EXPERIMENTS -DCLIPK_GEMM_TRACE -DCLIPK_GEMM_MFMA32 -shared -o $@ clip_dplm_amd/csrc/gemm_nt_v3.hip clip_dplm_amd/csrc/core.hip
 tools/probes/probe_layouts: tools/probes/probe_layouts.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -Wno-unused-value -o $@ $<
 tools/probes/probe_gather: tools/probes/probe_gather.hip

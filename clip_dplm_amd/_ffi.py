@@ -97,6 +97,7 @@ SIGNATURES = {
     "clipk_pool_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "clipk_pool_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "clipk_pool_varlen_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "clipk_layernorm_bwd2": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "clipk_pool_varlen_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "clipk_sumsq_workspace": (_sz, [_i64]),
     "clipk_sumsq": (_i, [_vp, _i64, _vp, _vp, _sz, _vp]),
@@ -104,7 +105,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 3          # CLIPK_ABI_VERSION of the library these signatures / the GemmArgs layout were written for
+ABI_VERSION = 4          # CLIPK_ABI_VERSION of the library these signatures / the GemmArgs layout were written for
 
 
 def load() -> C.CDLL:

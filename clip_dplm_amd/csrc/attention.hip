@@ -1271,18 +1271,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
 // =================================================================================================
 constexpr int F96_QB = 32;                                 // queries per step
 __host__ __device__ constexpr size_t lds_fused96() {
-  // K rows (then the four dQ shares: 4 x 32 x 100 f32 = 51200 B; then the dK / dV images) | 2 x (Q, dO) blocks |
-  // 4 x dS^T | lse, -delta | delta shares
-  return (size_t)FUSED_LMAX * Geo<96>::RS + 4 * F96_QB * Geo<96>::RS + 4 * 4096 + 2 * FUSED_LMAX * 4 + F96_QB * 12 * 4;
+  // K rows (then the dK / dV images) | the four dQ shares (4 x 32 x 100 f32) | 2 x (Q, dO) blocks | 4 x dS^T |
+  // lse, -delta | delta shares
+  return (size_t)FUSED_LMAX * Geo<96>::RS + 4 * F96_QB * 100 * 4 + 4 * F96_QB * Geo<96>::RS + 4 * 4096 +
+         2 * FUSED_LMAX * 4 + F96_QB * 12 * 4;
 }
 
 __global__ __launch_bounds__(256, 1) void attn_bwd_fused96_kernel(const AP p) {
   constexpr int D = 96, RS = Geo<96>::RS, KS = 3, DT = 6, NCH = 12, LQ = FUSED_LMAX, QB = F96_QB, ILD = D + 4;
   constexpr int KTW = 4, KW = 64, NCK = 2;                 // per wave: four 16-key tiles = two 32-key chunks
+  constexpr int NKP = LQ * NCH / 256;                      // K-row chunk tasks per thread (12)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* ktile = smem;                                      // [256][RS] K rows; later dQ shares; later dK / dV images
-  float* share = reinterpret_cast<float*>(smem);           // [4 waves][32 q][ILD] f32
-  char* qd = smem + LQ * RS;                               // [2 buffers][Q block | dO block][32][RS]
+  char* ktile = smem;                                      // [256][RS] K rows (transposed fragments); later dK / dV images
+  float* share = reinterpret_cast<float*>(smem + LQ * RS); // [4 waves][32 q][ILD] f32
+  char* qd = smem + LQ * RS + 4 * QB * ILD * 4;            // [2 buffers][Q block | dO block][32][RS]
   char* dst_all = qd + 4 * QB * RS;                        // [4 waves][2 chunks][32 keys][64 B]
   float* lse_l = reinterpret_cast<float*>(dst_all + 4 * 4096);   // [256] lse * log2(e); +inf past the end
   float* dl_l = lse_l + LQ;                                // [256] -delta
@@ -1290,21 +1292,22 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused96_kernel(const AP p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
   const int H = p.H;
-  int blk, h, b;
-  work_item(1, H, p.B, blk, h, b);
-  int L = p.L;
-  const long row0 = seq_rows(p, b, L);
-  if (L <= 0) return;                                      // (workgroup-uniform) empty sequence of a packed batch
   const long tokstride = 3L * H * D, ostride = (long)H * D;
   const unsigned int HD = (unsigned int)(H * D);
-  const unsigned short* qb_ = p.qkv + row0 * tokstride + (long)h * D;
-  const unsigned short* dob = p.dout + row0 * ostride + (long)h * D;
-  const unsigned short* ob = p.out + row0 * ostride + (long)h * D;
   const float c2 = p.scale * LOG2E;
-  const int nblk = (L + QB - 1) / QB;
+  const int nheads = p.B * H;
 
-  // ---- Q / dO / O block staging: 32 rows x 12 chunks = 384 (row, chunk) tasks per tensor, two passes of 256 threads
-  // (the second pass of threads >= 128 repeats a task of the first; its store is skipped)
+  // ---- the head whose rows are being LOADED (the next one, from the end of the current sweep on)
+  const unsigned short *lq = nullptr, *ldo = nullptr, *lo = nullptr;
+  int lL = 1;
+  auto point_at = [&](int w, int& L_, long& row0_, int& b_, int& h_) {
+    int blk_;
+    work_item_at(w, 1, H, p.B, blk_, h_, b_);
+    L_ = p.L;
+    row0_ = seq_rows(p, b_, L_);
+  };
+  // Q / dO / O block staging: 32 rows x 12 chunks = 384 (row, chunk) tasks per tensor, two passes of 256 threads (the
+  // second pass of threads >= 128 repeats a task of the first; its store is skipped)
   u32x4 cq[2], cd[2], co[2];
   auto issue_block = [&](int j) {
     const int t = tid + opaque_zero();
@@ -1312,10 +1315,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused96_kernel(const AP p) {
     for (int ps = 0; ps < 2; ++ps) {
       int idl = ps * 256 + t; idl = idl < QB * NCH ? idl : idl - 256;
       const int r = idl / NCH, ch = idl - r * NCH;
-      int row = j * QB + r; row = row < L ? row : L - 1;
-      cq[ps] = *reinterpret_cast<const u32x4*>(qb_ + ((unsigned int)row * 3u * HD + 8u * ch));
-      cd[ps] = *reinterpret_cast<const u32x4*>(dob + ((unsigned int)row * HD + 8u * ch));
-      co[ps] = *reinterpret_cast<const u32x4*>(ob + ((unsigned int)row * HD + 8u * ch));
+      int row = j * QB + r; row = row < lL ? row : lL - 1;
+      cq[ps] = *reinterpret_cast<const u32x4*>(lq + ((unsigned int)row * 3u * HD + 8u * ch));
+      cd[ps] = *reinterpret_cast<const u32x4*>(ldo + ((unsigned int)row * HD + 8u * ch));
+      co[ps] = *reinterpret_cast<const u32x4*>(lo + ((unsigned int)row * HD + 8u * ch));
     }
   };
   auto store_block = [&](int j) {                          // -> buffer j & 1, delta shares -> part
@@ -1338,200 +1341,246 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused96_kernel(const AP p) {
       }
     }
   };
-  auto finish_delta = [&](int j) {                         // after the barrier that follows store_block(j)
-    if (tid < QB) {
-      float acc = 0.f;
+  // K / V fragments of this wave's keys straight from HBM in fragment layout (16-byte chunk g + 4 ks of row li), the
+  // K rows for the transposed fragments (chunk per lane, through registers), lse of row tid, the key-mask bias
+  bf16x8 kf[KTW][KS], vf[KTW][KS];
+  float kbias[KTW], lse_r;
+  auto issue_head = [&](int w) {                           // sets lq / ldo / lo / lL to head w and requests its rows
+    int L_, b_, h_;
+    long row0_;
+    point_at(w, L_, row0_, b_, h_);
+    if (L_ <= 0) { L_ = 1; row0_ = row0_ > 0 ? row0_ - 1 : 0; }   // empty sequence: an in-range dummy row, never used
+    lL = L_;
+    lq = p.qkv + row0_ * tokstride + (long)h_ * D;
+    ldo = p.dout + row0_ * ostride + (long)h_ * D;
+    lo = p.out + row0_ * ostride + (long)h_ * D;
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) acc += part[tid * NCH + c];
-      const int q = j * QB + tid;
-      const bool ok = q < L;
-      dl_l[q] = ok ? -acc : 0.f;                           // NEGATED: the dP accumulators start from it
-      if (ok) p.delta[stat_at(p, b, h, H, L, row0, q)] = acc;
+    for (int kt = 0; kt < KTW; ++kt) {
+      const int key = wid * KW + kt * 16 + li;
+      const int row = key < L_ ? key : L_ - 1;
+      kbias[kt] = (key < L_ && (!p.key_mask || p.key_mask[row0_ + row])) ? 0.f : -INFINITY;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const unsigned int off = (unsigned int)row * 3u * HD + (unsigned int)(ks * 32 + g * 8);
+        kf[kt][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lq + (off + HD)));
+        vf[kt][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lq + (off + 2u * HD)));
+      }
     }
+    lse_r = p.lse[stat_at(p, b_, h_, H, L_, row0_, tid < L_ ? tid : L_ - 1)];
+    issue_block(0);
   };
 
-  // ---- prologue: K rows -> LDS (for the transposed fragments), K / V fragments of this wave's keys straight from HBM
-  issue_block(0);
-  {
-    const int t = tid + opaque_zero();
-#pragma unroll
-    for (int ps = 0; ps < LQ * NCH / 256; ++ps) {          // 12 chunk tasks per thread
-      const int idl = ps * 256 + t;
-      const int r = idl / NCH, ch = idl - r * NCH;
-      const int row = r < L ? r : L - 1;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(qb_ + ((unsigned int)row * 3u * HD + HD + 8u * ch));
-      *reinterpret_cast<u32x4*>(ktile + r * RS + ch * 16) = v;
-    }
-  }
-  bf16x8 kf[KTW][KS], vf[KTW][KS];
-  float kbias[KTW];
-#pragma unroll
-  for (int kt = 0; kt < KTW; ++kt) {
-    const int key = wid * KW + kt * 16 + li;
-    const int row = key < L ? key : L - 1;
-    kbias[kt] = (key < L && (!p.key_mask || p.key_mask[row0 + row])) ? 0.f : -INFINITY;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const unsigned int off = (unsigned int)row * 3u * HD + (unsigned int)(ks * 32 + g * 8);
-      kf[kt][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qb_ + (off + HD)));
-      vf[kt][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qb_ + (off + 2u * HD)));
-    }
-  }
-  lse_l[tid] = tid < L ? p.lse[stat_at(p, b, h, H, L, row0, tid)] * LOG2E : INFINITY;   // p = 2^-inf = 0 past the end
-  store_block(0);
-  __syncthreads();
   const int trow = 4 * g + (li >> 2), tcolb = 8 * (li & 3);
-  bf16x8 ktf[DT][NCK];                                     // K^T[d tile][32 keys of chunk c]
-#pragma unroll
-  for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-    for (int c = 0; c < NCK; ++c) ktf[dt][c] = tr_frag(ktile, RS, wid * KW + c * 32 + trow, dt * 32 + tcolb);
-  finish_delta(0);
-  __syncthreads();                                         // K rows are consumed: the region becomes the dQ shares
-
-  f32x4 dk[DT][KTW], dv[DT][KTW];
-#pragma unroll
-  for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-    for (int kt = 0; kt < KTW; ++kt) { dk[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt][kt] = dk[dt][kt]; }
   char* dst = dst_all + wid * 4096;
   int off_dw[2];                                           // dS^T write: key row li of a 16-key tile, queries qq*16 + 4g ..
 #pragma unroll
   for (int qq = 0; qq < 2; ++qq) off_dw[qq] = swz64(li, qq * 2 + (g >> 1)) + 8 * (g & 1);
-  const bool wave_live = wid * KW < L;                     // this wave owns at least one real key
 
-#pragma unroll 1
-  for (int j = 0; j < nblk; ++j) {
-    issue_block(j + 1 < nblk ? j + 1 : j);                 // unconditional (no branch around loads); last: re-read, unused
-    const char* qt_ = qd + (j & 1) * (2 * QB * RS);
-    const char* dt_ = qt_ + QB * RS;
-    f32x4 dq[DT][2];
+  // Persistent: one workgroup per CU walks heads w, w + gridDim.x, ...; the rows of the NEXT head are requested right
+  // after the sweep of the current one (its K / V fragment registers are dead by then) and land while the dK / dV
+  // images are written out.
+  int w = blockIdx.x;
+  if (w < nheads) issue_head(w);
+  for (; w < nheads; w += gridDim.x) {
+    int L, b, h;
+    long row0;
+    point_at(w, L, row0, b, h);
+    const int wnext = w + (int)gridDim.x < nheads ? w + (int)gridDim.x : w;   // last head: re-request its own rows
+    if (L <= 0) {                                          // (workgroup-uniform) empty sequence of a packed batch
+      issue_head(wnext);
+      continue;
+    }
+    const int nblk = (L + QB - 1) / QB;
+    const auto finish_delta = [&](int j) {                 // after the barrier that follows store_block(j)
+      if (tid < QB) {
+        float acc = 0.f;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) { dq[dt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; dq[dt][1] = dq[dt][0]; }
-    if (wave_live) {
-      u32x2 pk[2][KTW], dsk[2][KTW];
+        for (int c = 0; c < NCH; ++c) acc += part[tid * NCH + c];
+        const int q = j * QB + tid;
+        const bool ok = q < L;
+        dl_l[q] = ok ? -acc : 0.f;                         // NEGATED: the dP accumulators start from it
+        if (ok) p.delta[stat_at(p, b, h, H, L, row0, q)] = acc;
+      }
+    };
+    // ---- K rows -> LDS for the transposed fragments (chunk per lane through registers; L2-hot: the same rows came
+    // through as fragments while the previous head was written out), block 0 -> buffer 0, lse
+    {
+      const int t = tid + opaque_zero();
+      const unsigned short* kb_ = p.qkv + row0 * tokstride + (long)h * D + HD;
 #pragma unroll
-      for (int qq = 0; qq < 2; ++qq) {
-        // rows of the accumulators are queries (4g + r), columns are this lane's key; dP starts at -delta of its row,
-        // S at 0 / -inf for a valid / masked key
-        const f32x4 nd = *reinterpret_cast<const f32x4*>(dl_l + j * QB + qq * 16 + 4 * g);
-        f32x4 s[KTW], dp[KTW];
+      for (int half = 0; half < 2; ++half) {
+        u32x4 kr[NKP / 2];
 #pragma unroll
-        for (int kt = 0; kt < KTW; ++kt) { s[kt] = f32x4{kbias[kt], kbias[kt], kbias[kt], kbias[kt]}; dp[kt] = nd; }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const bf16x8 qa = row_frag(qt_, RS, qq * 16 + li, ks, lane);
-          const bf16x8 da = row_frag(dt_, RS, qq * 16 + li, ks, lane);
-#pragma unroll
-          for (int kt = 0; kt < KTW; ++kt) {
-            s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kt][ks], s[kt], 0, 0, 0);
-            dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kt][ks], dp[kt], 0, 0, 0);
-          }
+        for (int ps = 0; ps < NKP / 2; ++ps) {
+          const int idl = (half * (NKP / 2) + ps) * 256 + t;
+          const int r = idl / NCH, ch = idl - r * NCH;
+          kr[ps] = *reinterpret_cast<const u32x4*>(kb_ + ((unsigned int)(r < L ? r : L - 1) * 3u * HD + 8u * ch));
         }
-        const f32x4 ls = *reinterpret_cast<const f32x4*>(lse_l + j * QB + qq * 16 + 4 * g);
 #pragma unroll
-        for (int kt = 0; kt < KTW; ++kt) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float pv = fast_exp2(s[kt][r] * c2 - ls[r]);
-            s[kt][r] = pv;                                 // P
-            dp[kt][r] = pv * dp[kt][r];                    // dS = P (dP - delta)
-          }
-          pk[qq][kt] = u32x2{pack_bf16x2(s[kt][0], s[kt][1]), pack_bf16x2(s[kt][2], s[kt][3])};
-          dsk[qq][kt] = u32x2{pack_bf16x2(dp[kt][0], dp[kt][1]), pack_bf16x2(dp[kt][2], dp[kt][3])};
+        for (int ps = 0; ps < NKP / 2; ++ps) {
+          const int idl = (half * (NKP / 2) + ps) * 256 + t;
+          const int r = idl / NCH, ch = idl - r * NCH;
+          *reinterpret_cast<u32x4*>(ktile + r * RS + ch * 16) = kr[ps];
         }
       }
+    }
+    lse_l[tid] = tid < L ? lse_r * LOG2E : INFINITY;       // p = 2^-inf = 0 past the end
+    store_block(0);
+    __syncthreads();
+    finish_delta(0);
+    __syncthreads();
+
+    f32x4 dk[DT][KTW], dv[DT][KTW];
 #pragma unroll
-      for (int c = 0; c < NCK; ++c) {
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int ktl = 0; ktl < 2; ++ktl) {
-          const int kt = 2 * c + ktl;
-          const bf16x8 pbf = __builtin_bit_cast(bf16x8, u32x4{pk[0][kt][0], pk[0][kt][1], pk[1][kt][0], pk[1][kt][1]});
-          const bf16x8 dsf = __builtin_bit_cast(bf16x8, u32x4{dsk[0][kt][0], dsk[0][kt][1], dsk[1][kt][0], dsk[1][kt][1]});
+      for (int kt = 0; kt < KTW; ++kt) { dk[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt][kt] = dk[dt][kt]; }
+    const bool wave_live = wid * KW < L;                   // this wave owns at least one real key
+    unsigned short* dqb = p.dqkv + row0 * tokstride + (long)h * D;
+
+#pragma unroll 1
+    for (int j = 0; j < nblk; ++j) {
+      if (j + 1 < nblk) issue_block(j + 1);                // (workgroup-uniform branch; the last step requests nothing)
+      const char* qt_ = qd + (j & 1) * (2 * QB * RS);
+      const char* dt_ = qt_ + QB * RS;
+      if (wave_live) {
+        u32x2 pk[2][KTW], dsk[2][KTW];
 #pragma unroll
-          for (int qq = 0; qq < 2; ++qq) *reinterpret_cast<u32x2*>(dst + c * 2048 + ktl * 1024 + off_dw[qq]) = dsk[qq][kt];
+        for (int qq = 0; qq < 2; ++qq) {
+          // rows of the accumulators are queries (4g + r), columns are this lane's key; dP starts at -delta of its row,
+          // S at 0 / -inf for a valid / masked key
+          const f32x4 nd = *reinterpret_cast<const f32x4*>(dl_l + j * QB + qq * 16 + 4 * g);
+          f32x4 s[KTW], dp[KTW];
 #pragma unroll
-          for (int dt = 0; dt < DT; ++dt) {
-            const bf16x8 dot_f = tr_frag(dt_, RS, trow, dt * 32 + tcolb);     // dO^T[d tile][32 q]
-            const bf16x8 qt_f = tr_frag(qt_, RS, trow, dt * 32 + tcolb);      // Q^T
+          for (int kt = 0; kt < KTW; ++kt) { s[kt] = f32x4{kbias[kt], kbias[kt], kbias[kt], kbias[kt]}; dp[kt] = nd; }
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 qa = row_frag(qt_, RS, qq * 16 + li, ks, lane);
+            const bf16x8 da = row_frag(dt_, RS, qq * 16 + li, ks, lane);
+#pragma unroll
+            for (int kt = 0; kt < KTW; ++kt) {
+              s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kt][ks], s[kt], 0, 0, 0);
+              dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kt][ks], dp[kt], 0, 0, 0);
+            }
+          }
+          const f32x4 ls = *reinterpret_cast<const f32x4*>(lse_l + j * QB + qq * 16 + 4 * g);
+#pragma unroll
+          for (int kt = 0; kt < KTW; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float pv = fast_exp2(s[kt][r] * c2 - ls[r]);
+              s[kt][r] = pv;                               // P
+              dp[kt][r] = pv * dp[kt][r];                  // dS = P (dP - delta)
+            }
+            pk[qq][kt] = u32x2{pack_bf16x2(s[kt][0], s[kt][1]), pack_bf16x2(s[kt][2], s[kt][3])};
+            dsk[qq][kt] = u32x2{pack_bf16x2(dp[kt][0], dp[kt][1]), pack_bf16x2(dp[kt][2], dp[kt][3])};
+          }
+        }
+        // dS^T -> the wave's private [key][query] tiles first: the transposed read-back has the dV / dK block to land
+#pragma unroll
+        for (int kt = 0; kt < KTW; ++kt)
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq)
+            *reinterpret_cast<u32x2*>(dst + (kt >> 1) * 2048 + (kt & 1) * 1024 + off_dw[qq]) = dsk[qq][kt];
+        // dV^T[d][key] += dO^T[d][32 q] P[32 q][key], dK^T += Q^T dS: ONE transposed fragment pair per d tile for all
+        // four key tiles (the fragments do not depend on the key tile)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const bf16x8 dot_f = tr_frag(dt_, RS, trow, dt * 32 + tcolb);       // dO^T[d tile][32 q]
+          const bf16x8 qt_f = tr_frag(qt_, RS, trow, dt * 32 + tcolb);        // Q^T
+#pragma unroll
+          for (int kt = 0; kt < KTW; ++kt) {
+            const bf16x8 pbf = __builtin_bit_cast(bf16x8, u32x4{pk[0][kt][0], pk[0][kt][1], pk[1][kt][0], pk[1][kt][1]});
+            const bf16x8 dsf = __builtin_bit_cast(bf16x8, u32x4{dsk[0][kt][0], dsk[0][kt][1], dsk[1][kt][0], dsk[1][kt][1]});
             dv[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_f, pbf, dv[dt][kt], 0, 0, 0);
             dk[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_f, dsf, dk[dt][kt], 0, 0, 0);
           }
         }
-        // dQ^T[d][q] += K^T[d][32 keys of chunk c] dS^T[32 keys][q]   (the wave's own writes: no barrier needed)
-#pragma unroll
-        for (int qq = 0; qq < 2; ++qq) {
-          const bf16x8 dsb = tr_frag_off(dst + c * 2048, swz64(trow, qq * 2 + ((li & 3) >> 1)) + 8 * (li & 1));
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt)
-            dq[dt][qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[dt][c], dsb, dq[dt][qq], 0, 0, 0);
-        }
       }
-    }
-    // this wave's share of dQ (its keys only) for block j, as [q][d] f32 rows (zeros from a wave without keys)
-    {
+      // dQ^T[d][q] += K^T[d][32 keys of chunk c] dS^T[32 keys][q], one 16-query tile at a time (24 accumulator registers
+      // instead of 48; the wave's own dS^T writes: no barrier needed), then this wave's share of dQ (its keys only) for
+      // block j as [q][d] f32 rows (zeros from a wave without keys)
       float* sh = share + wid * (QB * ILD);
 #pragma unroll
-      for (int qq = 0; qq < 2; ++qq)
+      for (int qq = 0; qq < 2; ++qq) {
+        f32x4 dq[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (wave_live) {
+#pragma unroll
+          for (int c = 0; c < NCK; ++c) {
+            const bf16x8 dsb = tr_frag_off(dst + c * 2048, swz64(trow, qq * 2 + ((li & 3) >> 1)) + 8 * (li & 1));
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+              // K^T[d tile][32 keys of chunk c]: re-read from the staged K rows (12 resident fragments would cost 48
+              // registers the sweep does not have)
+              const bf16x8 ktf = tr_frag(ktile, RS, wid * KW + c * 32 + trow, dt * 32 + tcolb);
+              dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsb, dq[dt], 0, 0, 0);
+            }
+          }
+        }
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
-          *reinterpret_cast<f32x4*>(sh + (qq * 16 + li) * ILD + dt * 16 + 4 * g) = dq[dt][qq];
-    }
-    store_block(j + 1);                                    // the other buffer (last step: a copy nobody reads)
-    __syncthreads();
-    // ---- sum the four shares in wave order, scale, round, store: thread t -> query t / 8, 12 head dims
-    {
-      const int r = tid >> 3, c0 = (tid & 7) * 12;
-      f32x4 a[3];
+          *reinterpret_cast<f32x4*>(sh + (qq * 16 + li) * ILD + dt * 16 + 4 * g) = dq[dt];
+      }
+      if (j + 1 < nblk) store_block(j + 1);                // the other buffer
+      __syncthreads();
+      // ---- sum the four shares in wave order, scale, round, store: thread t -> query t / 8, 12 head dims
+      {
+        const int r = tid >> 3, c0 = (tid & 7) * 12;
+        f32x4 a[3];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) a[i] = *reinterpret_cast<const f32x4*>(share + r * ILD + c0 + 4 * i);
+        for (int i = 0; i < 3; ++i) a[i] = *reinterpret_cast<const f32x4*>(share + r * ILD + c0 + 4 * i);
 #pragma unroll
-      for (int w = 1; w < 4; ++w)
+        for (int ww = 1; ww < 4; ++ww)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) a[i] += *reinterpret_cast<const f32x4*>(share + w * (QB * ILD) + r * ILD + c0 + 4 * i);
-      const int q = j * QB + r;
-      if (q < L) {
-        unsigned short* dqrow = p.dqkv + (row0 + q) * tokstride + (long)h * D + c0;
+          for (int i = 0; i < 3; ++i) a[i] += *reinterpret_cast<const f32x4*>(share + ww * (QB * ILD) + r * ILD + c0 + 4 * i);
+        const int q = j * QB + r;
+        if (q < L) {
+          unsigned short* dqrow = dqb + (unsigned int)q * 3u * HD + c0;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          u32x2 w2;
-          w2[0] = pack_bf16x2(a[i][0] * p.scale, a[i][1] * p.scale);
-          w2[1] = pack_bf16x2(a[i][2] * p.scale, a[i][3] * p.scale);
-          *reinterpret_cast<u32x2*>(dqrow + 4 * i) = w2;
+          for (int i = 0; i < 3; ++i) {
+            u32x2 w2;
+            w2[0] = pack_bf16x2(a[i][0] * p.scale, a[i][1] * p.scale);
+            w2[1] = pack_bf16x2(a[i][2] * p.scale, a[i][3] * p.scale);
+            *reinterpret_cast<u32x2*>(dqrow + 4 * i) = w2;
+          }
         }
       }
+      if (j + 1 < nblk) finish_delta(j + 1);
+      __syncthreads();
     }
-    if (j + 1 < nblk) finish_delta(j + 1);
-    __syncthreads();
-  }
 
-  // ---- dK^T (x scale) and dV^T accumulators -> bf16 [key][d] images (one after the other, over the shares) -> rows
-  unsigned short* dkb = p.dqkv + row0 * tokstride + HD + (long)h * D;
+    // ---- the next head's rows: K / V fragment registers are free now; they land under the write-out below
+    issue_head(wnext);
+
+    // ---- dK^T (x scale) and dV^T accumulators -> bf16 [key][d] images (one after the other, over the shares) -> rows
 #pragma unroll 1
-  for (int which = 0; which < 2; ++which) {
+    for (int which = 0; which < 2; ++which) {
 #pragma unroll
-    for (int kt = 0; kt < KTW; ++kt)
+      for (int kt = 0; kt < KTW; ++kt)
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        const f32x4 v = which == 0 ? dk[dt][kt] * p.scale : dv[dt][kt];
-        u32x2 wv;
-        wv[0] = pack_bf16x2(v[0], v[1]);
-        wv[1] = pack_bf16x2(v[2], v[3]);
-        *reinterpret_cast<u32x2*>(ktile + (wid * KW + kt * 16 + li) * RS + (dt * 16 + 4 * g) * 2) = wv;
+        for (int dt = 0; dt < DT; ++dt) {
+          const f32x4 v = which == 0 ? dk[dt][kt] * p.scale : dv[dt][kt];
+          u32x2 wv;
+          wv[0] = pack_bf16x2(v[0], v[1]);
+          wv[1] = pack_bf16x2(v[2], v[3]);
+          *reinterpret_cast<u32x2*>(ktile + (wid * KW + kt * 16 + li) * RS + (dt * 16 + 4 * g) * 2) = wv;
+        }
+      __syncthreads();
+      {
+        const int t = tid + opaque_zero();
+#pragma unroll
+        for (int ps = 0; ps < NKP; ++ps) {
+          const int idl = ps * 256 + t;
+          const int r = idl / NCH, ch = idl - r * NCH;
+          if (r < L)
+            *reinterpret_cast<u32x4*>(dqb + ((unsigned int)r * 3u * HD + (unsigned int)(which + 1) * HD + 8u * ch)) =
+                *reinterpret_cast<const u32x4*>(ktile + r * RS + ch * 16);
+        }
       }
-    __syncthreads();
-    {
-      const int t = tid + opaque_zero();
-#pragma unroll
-      for (int ps = 0; ps < LQ * NCH / 256; ++ps) {
-        const int idl = ps * 256 + t;
-        const int r = idl / NCH, ch = idl - r * NCH;
-        if (r < L)
-          *reinterpret_cast<u32x4*>(dkb + ((unsigned int)r * 3u * HD + (unsigned int)which * HD + 8u * ch)) =
-              *reinterpret_cast<const u32x4*>(ktile + r * RS + ch * 16);
-      }
+      __syncthreads();
     }
-    __syncthreads();
   }
 }
 
@@ -1820,7 +1869,8 @@ inline void launch_fused96(const AP& p, hipStream_t st) {
   static_assert(lds <= 160 * 1024, "fused96 LDS budget");
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused96_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(attn_bwd_fused96_kernel, dim3(p.B * p.H), dim3(256), lds, st, p);
+  const int nheads = p.B * p.H, cus = attn_cu_count();
+  hipLaunchKernelGGL(attn_bwd_fused96_kernel, dim3(nheads < cus ? nheads : cus), dim3(256), lds, st, p);
 }
 
 template <int DP, int DR, int DX>

@@ -5,7 +5,7 @@
 #include <stdint.h>
 #include "../../include/clipk.h"
 
-#define CLIPK_ABI_VERSION 3
+#define CLIPK_ABI_VERSION 4
 #define WAVE 64
 
 // Kernel-selection options (core.hip): set explicitly through clipk_set_option(), never read from the environment.
@@ -122,6 +122,18 @@ __device__ __forceinline__ float act_grad(float x, int act) {
   if (act == CLIPK_ACT_CELU) return x > 0.f ? 1.f : expf(x);
   if (act == CLIPK_ACT_SOFTPLUS) return x > 20.f ? 1.f : 1.0f / (1.0f + expf(-x));
   return 1.f;
+}
+
+// second derivative of the activations the ICNN potential uses (2_icnn_core.py:121-127: CELU default, softplus): the
+// training branch back-propagates through T(x) = dPsi/dx, i.e. through act'
+__device__ __forceinline__ float act_grad2(float x, int act) {
+  if (act == CLIPK_ACT_CELU) return x > 0.f ? 0.f : expf(x);
+  if (act == CLIPK_ACT_SOFTPLUS) {
+    if (x > 20.f) return 0.f;
+    const float sg = 1.0f / (1.0f + expf(-x));
+    return sg * (1.0f - sg);
+  }
+  return 0.f;                                             // none / relu (piecewise linear)
 }
 
 // ---- dropout: counter-based mask, keep(seed, element index) = hash32(...) >= thr with thr = p * 2^32.  No state, no

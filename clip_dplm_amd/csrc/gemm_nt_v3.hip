@@ -58,6 +58,26 @@ struct Params {
 // half was already accumulated by the K-tile before)
 template <int NH, int MH, int KLO = 0>
 __device__ __forceinline__ void quad(f32x4 (&acc)[4][8], const bf16x8 (&wf)[2][2][2], const bf16x8 (&xf)[4][2]) {
+#ifdef CLIPK_GEMM_MFMA32
+  // TIMING-ONLY experiment (tools/exp_gemm_mfma_shape.py): the same quadrant as 8 x
+  // v_mfma_f32_32x32x16_bf16 (2 m-tiles of 32 x 1 n-tile of 32 x 4 k-steps of 16; 8 x 32 = 256 pipe cycles, as 16 x
+  // 16) on the SAME 12 fragment registers and the same 32 accumulator registers.  The fragments were fetched in the
+  // 16x16x32 lane layout, so the products are garbage (random bf16 data all the same: realistic operand toggling);
+  // instruction mix, LDS traffic, register footprint and MFMA pipe cycles are those of a real 32x32x16 loop.
+  typedef __attribute__((ext_vector_type(16))) float f32x16;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    f32x16 c;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) c[e] = acc[NH * 2 + (e >> 3)][MH * 4 + mt * 2 + ((e >> 2) & 1)][e & 3];
+#pragma unroll
+    for (int ks = 2 * KLO; ks < 4; ++ks)
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[NH][ks & 1][ks >> 1], xf[mt * 2 + (ks & 1)][ks >> 1], c, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[NH * 2 + (e >> 3)][MH * 4 + mt * 2 + ((e >> 2) & 1)][e & 3] = c[e];
+  }
+  return;
+#endif
 #pragma unroll
   for (int kk = KLO; kk < 2; ++kk)
 #pragma unroll
@@ -70,6 +90,12 @@ __device__ __forceinline__ void quad(f32x4 (&acc)[4][8], const bf16x8 (&wf)[2][2
 
 #define CLIPK_BAR() __builtin_amdgcn_s_barrier()
 #define CLIPK_SB() __builtin_amdgcn_sched_barrier(0)
+#ifdef CLIPK_GEMM_TRACE
+// experiment builds (tools/exp_gemm_mfma_shape.py): shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) summed
+// over the main loops of workgroup 0, and its K-tile count -> cycles per K-tile and the in-kernel clock
+// (MI355X_MICROARCH.md, DVFS item 6).  The stamps go to a buffer of their own; no output depends on them.
+__device__ unsigned long long* g_gemm_trace = nullptr;
+#endif
 #define CLIPK_STR2(x) #x
 #define CLIPK_STR(x) CLIPK_STR2(x)
 // counted wait that tolerates NS younger-than-the-loads store instructions (NS is a template constant 0..32)
@@ -241,6 +267,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v3_kernel(const Params p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef CLIPK_GEMM_TRACE
+    const bool tr_on = blockIdx.x == 0 && tid == 0 && g_gemm_trace != nullptr;
+    unsigned long long tc0 = 0, tr0 = 0;
+    if (tr_on) { tc0 = __builtin_amdgcn_s_memtime(); tr0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
     tile_body(std::integral_constant<int, 3>{}, 0);
     for (int T = 1; T < nk - 2; ++T) tile_body(std::integral_constant<int, 0>{}, T);
     tile_body(std::integral_constant<int, 1>{}, nk - 2);
@@ -249,6 +280,13 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_v3_kernel(const Params p) {
     const int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const int gn_e = cn0 + wn * 64 + (lane_e & 7) * 8;
     tile_body(std::integral_constant<int, 2>{}, nk - 1);
+#ifdef CLIPK_GEMM_TRACE
+    if (tr_on) {
+      g_gemm_trace[0] += __builtin_amdgcn_s_memtime() - tc0;
+      g_gemm_trace[1] += __builtin_amdgcn_s_memrealtime() - tr0;
+      g_gemm_trace[2] += (unsigned long long)nk;
+    }
+#endif
     if (wm == 0) CLIPK_BAR();                                   // re-align: every fragment read of this tile retired
     CLIPK_SB();
     // bias before the prefetch: vmcnt is in-order, a load issued after the prefetch could not be waited for
@@ -308,6 +346,12 @@ int cu_count() {
 }
 
 }  // namespace
+
+#ifdef CLIPK_GEMM_TRACE
+extern "C" int clipk_gemm_v3_set_trace(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // called by clipk_gemm_nt (gemm_nt.hip) after it validated the arguments (K % 32 == 0, K >= 192)
 extern "C" int clipk_gemm_nt_v3_launch(const clipk_gemm_args* a, void* stream) {

@@ -301,6 +301,136 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Backward OF the LayerNorm(+activation) backward (second order).  The ICNN transport map is T(x) = dPsi/dx
+// (2_icnn_core.py:181-211, create_graph=True) and its training loss is a function of T, so autograd differentiates
+// the first backward  da = r (u - mean u - xh mean(u xh)),  u = dy * act'(n) * gamma,  n = xh gamma + beta,
+// xh = (a - mean a) r,  r = rstd(a)  with respect to (dy, a, gamma, beta).  With g the cotangent of da, per row:
+//   w  = r (g - mean g - xh mean(g xh))                     (the same projection applied to g)
+//   d_dy = w gamma act'(n)
+//   q  = w gamma dy act''(n)                                (cotangent of n through act')
+//   tt = q gamma - r (u mean(g xh) + g mean(u xh))          (cotangent of xh: through n, and explicit in da)
+//   d_a = r (tt - mean tt - xh (mean(tt xh) + mean(g da)))  (through xh and through r)
+//   d_gamma += w dy act'(n) + q xh,   d_beta += q           (column sums over the rows)
+// One wave per row, the row in registers, two rounds of shuffle reductions; dgamma / dbeta as per-block partial rows
+// + the deterministic column reduce of the first-order kernel.
+// -------------------------------------------------------------------------------------------------
+struct LnBwd2 {
+  const float* g; const float* dy; const float* a; long ld;
+  const float* gamma; const float* beta; const float* mean; const float* rstd; int act;
+  float* d_dy; float* d_a; float* part; int rows, cols;
+};
+
+template <int VPL>
+__global__ __launch_bounds__(256) void ln_bwd2_kernel(const LnBwd2 p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  const int nch = p.cols >> 2;
+  f32x4 gm[VPL], bt[VPL], dgm[VPL], dbt[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    const int c = lane + 64 * v;
+    gm[v] = f32x4{0.f, 0.f, 0.f, 0.f}; bt[v] = gm[v]; dgm[v] = gm[v]; dbt[v] = gm[v];
+    if (c < nch) {
+      gm[v] = *reinterpret_cast<const f32x4*>(p.gamma + 4 * c);
+      if (p.act != CLIPK_ACT_NONE) bt[v] = *reinterpret_cast<const f32x4*>(p.beta + 4 * c);
+    }
+  }
+  const float inv_n = 1.0f / (float)p.cols;
+  for (int row = wave; row < p.rows; row += nwaves) {
+    const float mean = p.mean[row], r = p.rstd[row];
+    f32x4 xh[VPL], gv[VPL], u[VPL], k1[VPL], k2[VPL];      // u = dy act'(n), k1 = act'(n), k2 = gamma dy act''(n)
+    float su = 0.f, sux = 0.f, sg = 0.f, sgx = 0.f, sgu = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int c = lane + 64 * v;
+      xh[v] = f32x4{0.f, 0.f, 0.f, 0.f}; gv[v] = xh[v]; u[v] = xh[v]; k1[v] = xh[v]; k2[v] = xh[v];
+      if (c < nch) {
+        const long o = (long)row * p.ld + 4 * c;
+        const f32x4 av = *reinterpret_cast<const f32x4*>(p.a + o);
+        const f32x4 dyv = *reinterpret_cast<const f32x4*>(p.dy + o);
+        gv[v] = *reinterpret_cast<const f32x4*>(p.g + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = (av[e] - mean) * r;
+          float a1 = 1.f, a2 = 0.f;
+          if (p.act != CLIPK_ACT_NONE) {
+            const float n = x * gm[v][e] + bt[v][e];
+            a1 = act_grad(n, p.act);
+            a2 = act_grad2(n, p.act);
+          }
+          xh[v][e] = x;
+          k1[v][e] = a1;
+          k2[v][e] = gm[v][e] * dyv[e] * a2;
+          const float ud = dyv[e] * a1;                     // dy act'(n): d_gamma's first term pairs it with w
+          u[v][e] = ud;
+          const float ug = ud * gm[v][e];                   // the first backward's u
+          su += ug; sux += ug * x; sg += gv[v][e]; sgx += gv[v][e] * x; sgu += gv[v][e] * ug;
+        }
+      }
+    }
+    const float mu = wave_sum(su) * inv_n, cux = wave_sum(sux) * inv_n, mg = wave_sum(sg) * inv_n,
+                dgx = wave_sum(sgx) * inv_n, mgu = wave_sum(sgu) * inv_n;
+    const float e_gda = r * (mgu - mg * mu - dgx * cux);   // mean(g da)
+    f32x4 tt[VPL], w[VPL];
+    float st = 0.f, stx = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int c = lane + 64 * v;
+      tt[v] = f32x4{0.f, 0.f, 0.f, 0.f}; w[v] = tt[v];
+      if (c < nch) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = xh[v][e];
+          const float ww = r * (gv[v][e] - mg - x * dgx);
+          w[v][e] = ww;
+          const float q = ww * k2[v][e];                   // w gamma dy act''(n)
+          const float ug = u[v][e] * gm[v][e];              // u with gamma
+          const float t = q * gm[v][e] - r * (ug * dgx + gv[v][e] * cux);
+          tt[v][e] = t;
+          st += t; stx += t * x;
+          dgm[v][e] += ww * u[v][e] + q * x;
+          dbt[v][e] += q;
+        }
+      }
+    }
+    const float mt = wave_sum(st) * inv_n, mtx = wave_sum(stx) * inv_n;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      const int c = lane + 64 * v;
+      if (c < nch) {
+        const long o = (long)row * p.ld + 4 * c;
+        f32x4 ddy, da;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ddy[e] = w[v][e] * gm[v][e] * k1[v][e];
+          da[e] = r * (tt[v][e] - mt - xh[v][e] * (mtx + e_gda));
+        }
+        if (p.d_dy) *reinterpret_cast<f32x4*>(p.d_dy + o) = ddy;
+        if (p.d_a) *reinterpret_cast<f32x4*>(p.d_a + o) = da;
+      }
+    }
+  }
+  float* sm = reinterpret_cast<float*>(smem);          // [4][2][cols]
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    const int c = lane + 64 * v;
+    if (c < nch) {
+      *reinterpret_cast<f32x4*>(sm + (wid * 2 + 0) * p.cols + 4 * c) = dgm[v];
+      *reinterpret_cast<f32x4*>(sm + (wid * 2 + 1) * p.cols + 4 * c) = dbt[v];
+    }
+  }
+  __syncthreads();
+  const int nw = blockDim.x >> 6;
+  for (int i = threadIdx.x; i < 2 * p.cols; i += blockDim.x) {
+    float acc = 0.f;
+    for (int ww = 0; ww < nw; ++ww) acc += sm[ww * 2 * p.cols + i];
+    p.part[(long)blockIdx.x * 2 * p.cols + i] = acc;
+  }
+}
+
 // part: [nparts][ncols] with ncols = 2*cols ([dgamma | dbeta]).  Block = 16 columns x 16 row groups: a thread sums
 // every 16th partial row with 8 independent loads in flight (the old 64 x 4 shape ran 15 blocks of 256-deep
 // dependent chains: 33 us for a 4 MB input), LDS combines the 16 groups in a fixed order (deterministic).
@@ -497,6 +627,42 @@ extern "C" int clipk_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, c
     rc = clipk_check_launch();
   }
   return rc;
+}
+
+// Second-order LayerNorm(+activation) backward (see ln_bwd2_kernel): f32 only, [rows, cols] row-major with one leading
+// dimension.  workspace: clipk_layernorm_bwd_workspace(rows, cols) bytes.  d_gamma / d_beta are overwritten
+// (accumulate = 0) or added to (accumulate = 1); either both or neither.
+extern "C" int clipk_layernorm_bwd2(const float* g, const float* dy, const float* a, int64_t ld, const float* gamma,
+                                    const float* beta, const float* mean, const float* rstd, int act, float* d_dy,
+                                    float* d_a, float* d_gamma, float* d_beta, int accumulate, int rows, int cols,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  if (!g || !dy || !a || !gamma || !mean || !rstd || rows <= 0 || cols <= 0 || !workspace) return CLIPK_ERR_BAD_ARG;
+  if (act != CLIPK_ACT_NONE && !beta) return CLIPK_ERR_BAD_ARG;
+  if (act != CLIPK_ACT_NONE && act != CLIPK_ACT_CELU && act != CLIPK_ACT_SOFTPLUS) return CLIPK_ERR_UNSUPPORTED;
+  if ((d_gamma == nullptr) != (d_beta == nullptr)) return CLIPK_ERR_BAD_ARG;
+  if ((cols & 3) || (ld & 3)) return CLIPK_ERR_UNSUPPORTED;
+  const int blocks = ln_blocks_cap(rows, 512);
+  if (workspace_bytes < (size_t)blocks * 2 * cols * sizeof(float)) return CLIPK_ERR_BAD_ARG;
+  LnBwd2 p{g, dy, a, (long)ld, gamma, beta, mean, rstd, act, d_dy, d_a, (float*)workspace, rows, cols};
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)4 * 2 * cols * sizeof(float);
+#define LN_BWD2_CALL(V)                                                                                      \
+  do {                                                                                                       \
+    if (lds > 65536)                                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd2_kernel<V>),                            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+    hipLaunchKernelGGL((ln_bwd2_kernel<V>), dim3(blocks), dim3(256), lds, st, p);                            \
+  } while (0)
+  const int nch_ = cols >> 2;
+  if (nch_ <= 64 * 2) LN_BWD2_CALL(2);
+  else if (nch_ <= 64 * 4) LN_BWD2_CALL(4);
+  else if (nch_ <= 64 * 8) LN_BWD2_CALL(8);
+  else return CLIPK_ERR_UNSUPPORTED;
+#undef LN_BWD2_CALL
+  if (d_gamma)
+    hipLaunchKernelGGL(colreduce_kernel, dim3((2 * cols + 15) / 16), dim3(256), 0, st, (const float*)workspace,
+                       blocks, 2 * cols, d_gamma, d_beta, cols, accumulate);
+  return clipk_check_launch();
 }
 
 extern "C" int clipk_layernorm_meanpool_fwd(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta, float eps,

@@ -421,7 +421,7 @@ class ESM2Encoder(nn.Module):
 
     def qkv_version_fn(self, i):
         s = self.encoder.layer[i].attention.self
-        return lambda: s.query.weight._version + s.key.weight._version + s.value.weight._version
+        return KF.params_version(s.query.weight, s.key.weight, s.value.weight)
 
     def flat_param_groups(self):
         """Parameters FusedAdamW's flat buffer should store back to back: q/k/v weights, q/k/v biases per layer."""
@@ -506,6 +506,10 @@ class ESM2Encoder(nn.Module):
 # LayerNorms.  Normalised O(1) values lose nothing that the bf16 GEMM operands had not lost already: full-depth loss
 # parity 1.2e-5 / 1.9e-4 (ragged), gradient cosines 0.9999 (tests/test_gpu_configs.py).  The pre-LN ESM stream is
 # un-normalised and stays f32 (bf16 there moved the loss by 6e-3).
+# Per stack: `TransformerSeqEncoder(residual_dtype="bf16" | "f32")`.  bf16 is the default of the BASELINE towers (mean
+# pooling over 256 rows averages the rounding away); the notebook / tri-modal encoders pool ONE row (position 0,
+# rna_clip_codes.ipynb:1948-1949) and default to the f32 residual: at B = 32 the bf16 one alone moved their loss by
+# ~1e-3 (round 3, tools/exp_notebook_parity.py).  CLIPK_POSTLN_F32_RESIDUAL=1 forces f32 everywhere.
 POSTLN_BF16_RESIDUAL = os.environ.get("CLIPK_POSTLN_F32_RESIDUAL", "0") != "1"
 
 
@@ -518,7 +522,7 @@ def _post_layer_fwd(x, xb, p, meta, dr=None):
     """dr = None or (p_drop, seed_attn, seed_drop1, seed_ffn, seed_drop2): the four nn.Dropout sites of
     nn.TransformerEncoderLayer (attention probabilities; out_proj output; FFN activation; linear2 output), each a
     counter-based mask recomputed in the backward from the same seed."""
-    B, L, H, D, mask, act, eps, qs, seq = meta
+    B, L, H, D, mask, act, eps, qs, seq, res16 = meta
     da, d1, df, d2 = (None,) * 4 if dr is None else tuple((dr[0], sd) for sd in dr[1:])
     qkv = ops.gemm_nt(xb, p["in"].wb, bias=p["in"].b)
     if seq is not None:
@@ -526,7 +530,7 @@ def _post_layer_fwd(x, xb, p, meta, dr=None):
     else:
         ctx, lse = ops.attn_fwd(qkv, B, L, H, D, key_mask=mask, rope=None, q_scale=qs, dropout=da)
     s1 = ops.gemm_nt(ctx, p["out"].wb, bias=p["out"].b, residual=x, out_dtype=_SUM_DT, dropout=d1)
-    if POSTLN_BF16_RESIDUAL:
+    if res16:
         _, x1b, m1, r1 = ops.layernorm_fwd(s1, p["n1_w"], p["n1_b"], eps, want_f32=False, want_bf16=True)
         x1 = x1b
     else:
@@ -537,7 +541,7 @@ def _post_layer_fwd(x, xb, p, meta, dr=None):
         g = ops.gemm_nt(x1b, p["fc1"].wb, bias=p["fc1"].b, act="relu", dropout=df)
         u = g                                    # relu'(pre) == relu'(relu(pre)); a dropped element has g = 0 either way
     s2 = ops.gemm_nt(g, p["fc2"].wb, bias=p["fc2"].b, residual=x1, out_dtype=_SUM_DT, dropout=d2)
-    if POSTLN_BF16_RESIDUAL:
+    if res16:
         _, yb, m2, r2 = ops.layernorm_fwd(s2, p["n2_w"], p["n2_b"], eps, want_f32=False, want_bf16=True)
         y = yb
     else:
@@ -546,7 +550,7 @@ def _post_layer_fwd(x, xb, p, meta, dr=None):
 
 
 def _post_layer_bwd(dy, p, saved, meta, dr=None, need_dx=True):
-    B, L, H, D, mask, act, eps, qs, seq = meta
+    B, L, H, D, mask, act, eps, qs, seq, res16 = meta
     da, d1, df, d2 = (None,) * 4 if dr is None else tuple((dr[0], sd) for sd in dr[1:])
     xb, qkv, ctx, lse, s1, x1b, m1, r1, g, u, s2, m2, r2 = saved
     gr = {}
@@ -554,7 +558,7 @@ def _post_layer_bwd(dy, p, saved, meta, dr=None, need_dx=True):
     # residual-path gradient
     # (bf16 mode: the LayerNorm-backward kernels emit only the bf16 gradient, which is both the next GEMM operand — with
     # the dropout mask when there is one — and the residual-path gradient added in the dgrad epilogue)
-    lowp = POSTLN_BF16_RESIDUAL and dr is None
+    lowp = res16 and dr is None
     ds2, ds2b, gr["n2_w"], gr["n2_b"] = _ln_bwd(dy, s2, p["n2_w"], p["n2_b"], m2, r2, want_f32=not lowp, want_bf16=True,
                                                 dropout_bf16=d2)
     du = ops.gemm_nt(ds2b, p["fc2"].wtb, dact_aux=u, dact=act, dropout=df)     # x mask(ffn) x act'(u)
@@ -594,7 +598,8 @@ class PostLNStackFn(torch.autograd.Function):
         nl = module.num_layers
         E, H = module.embed_dim, module.nhead
         D = module.head_dim_padded
-        meta = (B, L, H, D, mask_u8, module.activation, module.eps, float(E // H) ** -0.5, seq)
+        meta = (B, L, H, D, mask_u8, module.activation, module.eps, float(E // H) ** -0.5, seq,
+                module.residual_dtype == "bf16" and POSTLN_BF16_RESIDUAL)
         x = x.contiguous()
         xb = ops.to_bf16(x)
         fin_w, fin_b = flat[0], flat[1]
@@ -681,8 +686,11 @@ class TransformerSeqEncoder(nn.Module):
     grad_bucket = True          # see ESM2Encoder
 
     def __init__(self, embed_dim=768, num_layers=6, nhead=8, dim_feedforward=2048, activation="gelu",
-                 layer_norm_eps=1e-12, final_eps=None, dropout: float = 0.0):
+                 layer_norm_eps=1e-12, final_eps=None, dropout: float = 0.0, residual_dtype: str = "bf16"):
         super().__init__()
+        if residual_dtype not in ("bf16", "f32"):
+            raise ValueError(f"residual_dtype must be 'bf16' or 'f32', got {residual_dtype!r}")
+        self.residual_dtype = residual_dtype
         self.embed_dim, self.num_layers, self.nhead = embed_dim, num_layers, nhead
         # nn.TransformerEncoderLayer's dropout (rna_clip_codes.ipynb:1915 uses 0.1): attention probabilities, out_proj
         # output, FFN activation, linear2 output.  In training mode each site draws a counter-based mask inside the

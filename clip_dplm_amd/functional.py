@@ -26,7 +26,9 @@ def _cache_key(w: torch.Tensor, version=None):
     """Identity + version of a master weight.  For a fused zero-copy view of several Parameters (ESM's qkv:
     torch.as_strided of the flat buffer, whose own _version never moves) the caller passes the sum of the source
     Parameters' versions, so load_state_dict / re-initialisation / another optimiser invalidate the copy too."""
-    return (w.data_ptr(), w._version if version is None else ("src", version), _WEIGHT_EPOCH, tuple(w.shape))
+    if version is not None:                  # a DERIVED operand (fused view, torch.cat / pad of Parameters, rebuilt per
+        return ("src", version, _WEIGHT_EPOCH, tuple(w.shape))      # call): its identity is that of its sources
+    return (w.data_ptr(), w._version, _WEIGHT_EPOCH, tuple(w.shape))
 
 
 class WeightCache:
@@ -102,8 +104,8 @@ class LinearFn(torch.autograd.Function):
     """y = act(x W^T + b)   (old/clip.py:11,16,27,31).  x: [M,K] f32 or bf16; y dtype selectable."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, cache: WeightCache, act, out_dtype):
-        wb, wtb = cache.get(weight)
+    def forward(ctx, x, weight, bias, cache: WeightCache, act, out_dtype, version_fn=None):
+        wb, wtb = cache.get(weight, version_fn)
         xb = _bf16(x)
         need_pre = act == "gelu"
         r = ops.gemm_nt(xb, wb, bias=bias, act=act, out_dtype=out_dtype, out_preact=need_pre)
@@ -129,7 +131,7 @@ class LinearFn(torch.autograd.Function):
         dw = db = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dw, db = ops.gemm_wgrad(g, xb, want_bias=ctx.has_bias)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 class LinearF32Fn(torch.autograd.Function):
@@ -155,17 +157,22 @@ class LinearF32Fn(torch.autograd.Function):
         return dx, dw, db
 
 
-def linear(x, weight, bias, cache: WeightCache, act=None, out_dtype=torch.float32, precision: str = "bf16"):
+def params_version(*params):
+    """version_fn for an operand derived from these Parameters (concatenated / padded per call): the cached bf16 copies
+    stay valid while none of the sources changed (keyed on the derived tensor's pointer the cache never hit)."""
+    return lambda: tuple((p.data_ptr(), p._version) for p in params)
+
+
+def linear(x, weight, bias, cache: WeightCache, act=None, out_dtype=torch.float32, precision: str = "bf16",
+           version_fn=None):
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])
     if precision == "f32":
         y = LinearF32Fn.apply(x2.float().contiguous(), weight, bias)
         if act is not None:
-            y = ActFn.apply(y, act)
-        if out_dtype != torch.float32:
-            y = _bf16(y)
+            y = ActFn.apply(y, act)                       # (out_dtype is a bf16-path hint: an f32 Linear stays f32)
     else:
-        y = LinearFn.apply(x2, weight, bias, cache, act, out_dtype)
+        y = LinearFn.apply(x2, weight, bias, cache, act, out_dtype, version_fn)
     return y.reshape(*lead, y.shape[-1])
 
 

@@ -21,8 +21,10 @@ Two paths, selected by `module.training`:
     norm clip of T (:203-209), cost on the normalised target (4_transport_maps.py:124-143) — with back-propagation
     THROUGH T, i.e. second derivatives of Psi.  Every matrix product of that path (forward, first and second
     order) runs on the exact-f32 MFMA kernel through `_MatmulNT`, an autograd Function whose backward is built from
-    itself and is therefore differentiable again; the element-wise glue on [B, hidden] tensors (LayerNorm, CELU /
-    softplus and their first / second derivatives) is ATen's, because torch.autograd has to differentiate it twice.
+    itself and is therefore differentiable again; LayerNorm (+ CELU / softplus) runs on the fused row kernels through
+    `_LNActFn` -> `_LNActBwdFn` -> clipk_layernorm_bwd2 (the hand-derived second-order backward, round 3), softplus(W+)
+    on the activation kernels; what is left to ATen is scalar-level glue (the `scale` multiply and add, the no_grad
+    rescale statistic, the per-row norm clip and the cost's row norms / means) and hessian()'s third derivatives.
 Only the working family of architectures is supported (hidden_dims[:-1] == input_dim).
 """
 from __future__ import annotations
@@ -99,6 +101,69 @@ def _linear_f32(x, weight, bias=None):
     return y if bias is None else y + bias
 
 
+class _LNActBwdFn(torch.autograd.Function):
+    """First backward of LayerNorm(+activation) as a differentiable op: (dy, a, gamma, beta) -> da on
+    clipk_layernorm_bwd; its own backward is the second-order kernel clipk_layernorm_bwd2.  That is what back-propagation
+    THROUGH the transport map T(x) = dPsi/dx needs (2_icnn_core.py:197-201 builds T with create_graph=True)."""
+
+    @staticmethod
+    def forward(ctx, dy, a, gamma, beta, mean, rstd, act):
+        da, _, dg, db = ops.layernorm_bwd(dy.contiguous(), a, gamma, beta, mean, rstd, act=act)
+        ctx.save_for_backward(dy, a, gamma, beta, mean, rstd)
+        ctx.act = act
+        ctx.mark_non_differentiable(dg, db)                  # first-order parameter gradients: leaves of the step
+        return da, dg, db
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g, _gdg, _gdb):
+        dy, a, gamma, beta, mean, rstd = ctx.saved_tensors
+        d_dy, d_a, d_gamma, d_beta = ops.layernorm_bwd2(g.contiguous(), dy, a, gamma, beta, mean, rstd, act=ctx.act)
+        return d_dy, d_a, d_gamma, d_beta, None, None, None
+
+
+class _LNActFn(torch.autograd.Function):
+    """y = act(LayerNorm(a)) on the fused kernel (2_icnn_core.py:121-127: norm then CELU / softplus; act None: the
+    input / output LayerNorms of 4_transport_maps.py:103-104).  Differentiable twice: backward = _LNActBwdFn."""
+
+    @staticmethod
+    def forward(ctx, a, gamma, beta, eps, act):
+        a = a.contiguous().float()
+        y, _, mean, rstd = ops.layernorm_fwd(a, gamma, beta, eps, act=act)
+        ctx.save_for_backward(a, gamma, beta, mean, rstd)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, gamma, beta, mean, rstd = ctx.saved_tensors
+        da, dg, db = _LNActBwdFn.apply(dy, a, gamma, beta, mean, rstd, ctx.act)
+        return da, dg, db, None, None
+
+
+def _layer_norm(mod: nn.LayerNorm, x, act=None):
+    return _LNActFn.apply(x, mod.weight, mod.bias, mod.eps, act)
+
+
+class _ActFn(torch.autograd.Function):
+    """Elementwise activation on clipk_act_fwd / clipk_act_bwd: softplus of the positive-weight matrix
+    (2_icnn_core.py:84-86).  The weights enter Psi AND T only through the value softplus(W+), so one derivative is all
+    the training step asks of it."""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return ops.act_fwd(x, act)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.act_bwd(dy.contiguous(), x, ctx.act), None
+
+
 class ConvexLayer(nn.Module):
     """2_icnn_core.py:42-127.  Parameters: linear.{weight,bias}, pos_weights, scale, norm.{weight,bias}."""
 
@@ -117,20 +182,30 @@ class ConvexLayer(nn.Module):
         """softplus(W+ + eps) (:84-86); the eps shift is a [out,in] elementwise add (plumbing), softplus a kernel."""
         return ops.act_fwd((self.pos_weights.detach() + self.config.eps).contiguous(), "softplus")
 
-    def forward(self, x: torch.Tensor, z: Optional[torch.Tensor] = None, scale: Optional[float] = None) -> torch.Tensor:
-        """Differentiable (train-mode) layer, 2_icnn_core.py:88-127."""
+    def forward(self, x: torch.Tensor, z: Optional[torch.Tensor] = None, scale: Optional[float] = None,
+                any_order: bool = False) -> torch.Tensor:
+        """Differentiable (train-mode) layer, 2_icnn_core.py:88-127.  Matrix products on the exact-f32 MFMA kernel;
+        LayerNorm + activation and softplus(W+) on the fused row / elementwise kernels through autograd Functions that
+        can be differentiated twice (the training step goes through T = dPsi/dx).  any_order = True keeps the
+        ATen composition of the element-wise part (hessian(): third derivatives)."""
+        act = "softplus" if self.config.activation == "softplus" else "celu"
+        kernels = not any_order and self.config.use_layer_norm
         y = _linear_f32(x, self.linear.weight, self.linear.bias)
         if z is not None:
             scale = scale if scale is not None else self.scale
-            zc = _linear_f32(z, F.softplus(self.pos_weights + self.config.eps)) * scale
+            pw = _ActFn.apply(self.pos_weights + self.config.eps, "softplus") if kernels else \
+                F.softplus(self.pos_weights + self.config.eps)
+            zc = _linear_f32(z, pw) * scale
             if self.training:
                 with torch.no_grad():                     # as in the reference: the rescaled tensor is a constant
                     zs = zc.abs().mean()
                     if zs > self.config.gradient_clip:
                         zc = zc * (self.config.gradient_clip / zs)
             y = y + zc
+        if kernels:
+            return _layer_norm(self.norm, y, act)
         y = self.norm(y)
-        return F.softplus(y) if self.config.activation == "softplus" else F.celu(y)
+        return F.softplus(y) if act == "softplus" else F.celu(y)
 
 
 class SingleCellICNN(nn.Module):
@@ -172,14 +247,15 @@ class SingleCellICNN(nn.Module):
         psi = z @ self.final.weight.t() + self.final.bias if need_psi else None
         return psi, (x, xh, m0, r0, saved, act)
 
-    def _forward_diff(self, x: torch.Tensor, return_intermediates: bool = False):
-        """Differentiable (to any order) forward, :156-179: matrix products on the exact-f32 MFMA kernel through the
-        re-differentiable _MatmulNT, LayerNorm / activation by ATen.  Train mode, and hessian() in either mode."""
-        x = self.input_norm(x.float())
+    def _forward_diff(self, x: torch.Tensor, return_intermediates: bool = False, any_order: bool = False):
+        """Differentiable forward, :156-179: matrix products on the exact-f32 MFMA kernel through the re-differentiable
+        _MatmulNT; LayerNorm (+ CELU / softplus) on the fused kernels through _LNActFn (differentiable twice: the
+        training step).  any_order = True: the element-wise part by ATen, for hessian()'s third derivatives."""
+        x = self.input_norm(x.float()) if any_order else _layer_norm(self.input_norm, x.float())
         inter = [] if return_intermediates else None
         z = None
         for layer in self.layers:
-            z = layer(x, z)
+            z = layer(x, z, any_order=any_order)
             if return_intermediates:
                 inter.append(z)
         return _linear_f32(z, self.final.weight, self.final.bias), inter
@@ -189,7 +265,7 @@ class SingleCellICNN(nn.Module):
             return self._forward_diff(x, return_intermediates)
         if not self.config.use_layer_norm:                # the fused LN + activation kernels do not apply: same
             with torch.no_grad():                         # products, activation by ATen
-                return self._forward_diff(x)[0], None
+                return self._forward_diff(x, any_order=True)[0], None
         psi, _ = self._forward(x)
         return psi, None
 
@@ -207,7 +283,7 @@ class SingleCellICNN(nn.Module):
         if not self.config.use_layer_norm:                # no hand-derived chain without the fused LN kernels
             with torch.enable_grad():
                 xr = x.detach().requires_grad_(True)
-                grad, = torch.autograd.grad(self._forward_diff(xr)[0].sum(), xr)
+                grad, = torch.autograd.grad(self._forward_diff(xr, any_order=True)[0].sum(), xr)
             return grad.detach()
         return self._gradient_eval(x)
 
@@ -218,7 +294,7 @@ class SingleCellICNN(nn.Module):
         norm-clipped T of the training branch and adds hessian_reg * I.  Like the reference it keeps the graph
         (create_graph=True) so that a Hessian penalty can be trained through."""
         x = x if x.requires_grad else x.detach().requires_grad_(True)
-        y = self._forward_diff(x)[0]
+        y = self._forward_diff(x, any_order=True)[0]
         grad, = torch.autograd.grad(y.sum(), x, create_graph=True, retain_graph=True)
         if self.training:
             gn = grad.norm(dim=-1, keepdim=True)
@@ -282,9 +358,10 @@ class SingleCellTransport(nn.Module):
 
     def forward(self, source: torch.Tensor, target: Optional[torch.Tensor] = None):
         if self.training:                                 # 4_transport_maps.py:113-145, differentiable
-            transported = self.output_norm(self.transport_net.gradient(self.input_norm(source.float())))
+            transported = _layer_norm(self.output_norm,
+                                      self.transport_net.gradient(_layer_norm(self.input_norm, source.float())))
             if target is not None:
-                cost, metrics = self.cost_fn(transported, self.output_norm(target.float()))
+                cost, metrics = self.cost_fn(transported, _layer_norm(self.output_norm, target.float()))
                 return TransportOutput(transported=transported, cost=cost, metrics=metrics)
             return transported
         return self._forward_eval(source)

@@ -104,7 +104,9 @@ def contrastive_loss(x: torch.Tensor, y: torch.Tensor, temperature: float = 0.1,
     clip_loss (w_row = 1, w_col = 0, cache = queue): neither the [B, B + Q] logits nor the concatenated keys exist."""
     from . import functional as KF
     scale = torch.full((1,), 1.0 / float(temperature), dtype=torch.float32, device=x.device)
-    cache = None if queue is None else queue.detach().to(dtype=torch.float32).contiguous()
+    # a private copy, as the reference's `queue.clone().detach()`: the queue is overwritten in place by the next
+    # enqueue, which may come before this loss's backward
+    cache = None if queue is None else queue.detach().to(dtype=torch.float32).clone()
     return clip_loss(KF.l2_normalize(x), KF.l2_normalize(y), scale, symmetric=False, cache=cache, group=group)
 
 

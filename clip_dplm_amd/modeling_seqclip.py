@@ -40,8 +40,9 @@ class RNARBPCLIPEncoder(TransformerSeqEncoder):
     """rna_clip_codes.ipynb:1911-1923: 3 x nn.TransformerEncoderLayer(d, nhead=8, ffn=4d) + LayerNorm."""
 
     def __init__(self, embed_dim, num_layers=3, dropout: float = 0.1):
+        # position-0 pooling (no averaging over rows): keep the residual stream in f32 (encoders.POSTLN_BF16_RESIDUAL)
         super().__init__(embed_dim=embed_dim, num_layers=num_layers, nhead=8, dim_feedforward=embed_dim * 4,
-                         activation="relu", layer_norm_eps=1e-5, final_eps=1e-5, dropout=dropout)
+                         activation="relu", layer_norm_eps=1e-5, final_eps=1e-5, dropout=dropout, residual_dtype="f32")
 
 
 class RNARBPCLIPModel(nn.Module):

@@ -76,7 +76,7 @@ class CellStateEncoder(nn.Module):
     def forward(self, x, connectivity):
         e = self.encoder
         xp, wp = _pad_k(x, e[0].weight)                    # gene_dim + 1 is odd: pad K for the MFMA tiles
-        h = KF.linear(xp, wp, e[0].bias, self._c0)
+        h = KF.linear(xp, wp, e[0].bias, self._c0, version_fn=KF.params_version(e[0].weight))
         h = e[1](h, act="gelu")                            # LayerNorm + erf-GELU in one kernel
         h = e[3](h)
         graph_mask = (connectivity.sum(-1) == 0).bool()    # cells without neighbours are not attended to
@@ -98,7 +98,8 @@ class PerturbationEncoder(nn.Module):
         xin = torch.cat([gene_esm_embeddings, values.unsqueeze(-1).to(gene_esm_embeddings.dtype)], -1)
         w = torch.cat([self.esm_projection.weight, self.value_encoder.weight], 1)
         xin, w = _pad_k(xin, w)
-        x = KF.linear(xin, w, self.esm_projection.bias + self.value_encoder.bias, self._c)
+        x = KF.linear(xin, w, self.esm_projection.bias + self.value_encoder.bias, self._c,
+                      version_fn=KF.params_version(self.esm_projection.weight, self.value_encoder.weight))
         return self.transformer(x)
 
 

@@ -420,6 +420,29 @@ def layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=None, dx_add=None, want_f3
     return dx32, dx16, dgamma, dbeta
 
 
+def layernorm_bwd2(g, dy, a, gamma, beta, mean, rstd, act=None, dgamma=None, dbeta=None, accumulate=False):
+    """Backward of layernorm_bwd (second order, f32; act in {None, "celu", "softplus"}): cotangent g of da ->
+    (d_dy, d_a, d_gamma, d_beta).  See clipk_layernorm_bwd2."""
+    _need_cuda(g, dy, a, gamma, mean, rstd)
+    rows, cols = a.shape
+    g, dy, a = g.contiguous(), dy.contiguous(), a.contiguous()
+    assert g.dtype == dy.dtype == a.dtype == torch.float32
+    d_dy, d_a = torch.empty_like(a), torch.empty_like(a)
+    if dgamma is None:
+        dgamma = torch.empty(cols, dtype=torch.float32, device=a.device)
+        dbeta = torch.empty(cols, dtype=torch.float32, device=a.device)
+        accumulate = False
+    lib = _lib()
+    nbytes = lib.clipk_layernorm_bwd_workspace(rows, cols)
+    ws = workspace(nbytes, a.device, "ln")
+    check(_timed("layernorm_bwd2", 5.0 * rows * cols * 4,
+                 lambda: lib.clipk_layernorm_bwd2(g.data_ptr(), dy.data_ptr(), a.data_ptr(), a.stride(0), gamma.data_ptr(),
+                                                  ptr(beta), mean.data_ptr(), rstd.data_ptr(), ACT[act], d_dy.data_ptr(),
+                                                  d_a.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), int(accumulate),
+                                                  rows, cols, ws.data_ptr(), nbytes, _stream())), "clipk_layernorm_bwd2")
+    return d_dy, d_a, dgamma, dbeta
+
+
 def meanpool_fused_supported(cols: int) -> bool:
     """Row widths clipk_layernorm_meanpool_fwd takes (its four partial rows must fit 64 KiB of LDS)."""
     return cols % 4 == 0 and (4 * cols + 4) * 4 <= 65536

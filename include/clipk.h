@@ -222,6 +222,19 @@ int clipk_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, const void* 
                         float* dgamma, float* dbeta, int accumulate,
                         int rows, int cols, float drop_p, uint32_t drop_seed, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Backward OF clipk_layernorm_bwd (second order), f32: the ICNN transport map is T(x) = dPsi/dx
+ * (triple_flow/2_icnn_core.py:181-211: torch.autograd.grad(..., create_graph=True)) and the training loss of
+ * triple_flow/4_transport_maps.py:113-145 is a function of T, so autograd differentiates the first backward
+ *   da = LNact_bwd(dy; a, gamma, beta)   (what clipk_layernorm_bwd computes, act in {NONE, CELU, SOFTPLUS})
+ * with respect to dy, a, gamma and beta.  g = cotangent of da [rows, cols]; outputs d_dy, d_a [rows, cols] (either may
+ * be NULL) and d_gamma / d_beta [cols] (both or neither; overwritten or accumulated).  mean / rstd as saved by
+ * clipk_layernorm_fwd for `a`.  One leading dimension ld for g, dy, a, d_dy, d_a.  workspace:
+ * clipk_layernorm_bwd_workspace(rows, cols) bytes. */
+int clipk_layernorm_bwd2(const float* g, const float* dy, const float* a, int64_t ld, const float* gamma,
+                         const float* beta, const float* mean, const float* rstd, int act, float* d_dy, float* d_a,
+                         float* d_gamma, float* d_beta, int accumulate, int rows, int cols,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 /* Final LayerNorm of an encoder + masked mean over the L token rows of each sample in one pass: pooled[b] =
  * mean_{l valid} LN(x[b, l]) (the pooling of run1/configuration_hybrid_clip.py:109,148 `use_mean_pooling`, fair-esm
  * mean over residues current/tf_clip_codes (1).ipynb:1188, behind the encoders' last LayerNorm modeling_esm.py:552-553 /

@@ -230,6 +230,36 @@ def layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=None, dx_add=None, want_f3
     return (dx if want_f32 else None), dxb, dg, db
 
 
+def layernorm_bwd2(g, dy, a, gamma, beta, mean, rstd, act=None, dgamma=None, dbeta=None, accumulate=False):
+    """Backward of the LayerNorm(+act) backward by torch autograd over a torch restatement of the first backward
+    (statistics recomputed from `a`, as the kernel's derivation assumes)."""
+    eps_free = True                                        # mean / rstd are functions of a: recompute rstd from var
+    with torch.enable_grad():
+        dyr, ar = dy.detach().clone().requires_grad_(True), a.detach().clone().requires_grad_(True)
+        gr = gamma.detach().clone().requires_grad_(True)
+        br = (beta.detach().clone().requires_grad_(True)) if beta is not None else None
+        mu = ar.mean(-1, keepdim=True)
+        var = ((ar - mu) ** 2).mean(-1, keepdim=True)
+        # rstd = (var + eps)^-1/2 with the eps the forward used: recover it from the saved rstd of the same rows
+        eps = (1.0 / rstd.double() ** 2 - var.detach().double().squeeze(-1)).mean().clamp_min(0).float()
+        r = torch.rsqrt(var + eps)
+        xh = (ar - mu) * r
+        u = dyr * gr
+        if act is not None:
+            n = xh * gr + br
+            u = u * torch.autograd.grad(_act(n, act).sum(), n, create_graph=True)[0]
+        da = r * (u - u.mean(-1, keepdim=True) - xh * (u * xh).mean(-1, keepdim=True))
+        ins = [dyr, ar, gr] + ([br] if (br is not None and act is not None) else [])
+        outs = torch.autograd.grad(da, ins, g, allow_unused=True)
+    d_dy, d_a, dg = outs[0], outs[1], outs[2]
+    db = outs[3] if len(outs) > 3 and outs[3] is not None else torch.zeros_like(gamma)
+    if dgamma is not None:
+        dgamma.copy_(dgamma + dg if accumulate else dg)
+        dbeta.copy_(dbeta + db if accumulate else db)
+        dg, db = dgamma, dbeta
+    return d_dy, d_a, dg, db
+
+
 def meanpool_fused_supported(cols):
     return cols % 4 == 0 and (4 * cols + 4) * 4 <= 65536
 

@@ -989,3 +989,41 @@ def test_simce_tiled_grad_pass(dev, kopt, Mx, Ny, Nc, P, off, wr, wc):
         assert torch.equal(dx, ops.simce_grad(x, y, sc, lse_x, lse_y, wr, wc, inv_bg, label_offset=off, cache=cache)[0])
         out[mode] = dx
     assert torch.allclose(out[1], out[2], rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("rows,cols,act", [(64, 512, "celu"), (100, 256, "celu"), (33, 512, "softplus"), (257, 512, None),
+                                            (16, 1024, "celu"), (5, 120, None)])
+def test_layernorm_second_order_backward_vs_autograd(dev, rows, cols, act):
+    """clipk_layernorm_bwd2 (the backward of the LayerNorm(+activation) backward: what training THROUGH the transport
+    map T = dPsi/dx needs, triple_flow/2_icnn_core.py:181-211) against f64 torch autograd of the first backward."""
+    ops = _ops()
+    g_ = torch.Generator().manual_seed(rows + cols)
+    a = torch.randn(rows, cols, generator=g_) * 1.5 + 0.3
+    dy = torch.randn(rows, cols, generator=g_)
+    g = torch.randn(rows, cols, generator=g_)
+    gamma = torch.rand(cols, generator=g_) + 0.5
+    beta = torch.randn(cols, generator=g_) * 0.3
+    eps = 1e-5
+    ad, dyd, gd, gmd, btd = (t.double().requires_grad_(True) for t in (a, dy, g, gamma, beta))
+    mu = ad.mean(-1, keepdim=True)
+    r = torch.rsqrt(((ad - mu) ** 2).mean(-1, keepdim=True) + eps)
+    xh = (ad - mu) * r
+    n = xh * gmd + btd
+    y = n if act is None else (torch.nn.functional.celu(n) if act == "celu" else torch.nn.functional.softplus(n))
+    da, = torch.autograd.grad(y, ad, dyd, create_graph=True)              # the first backward, as autograd builds it
+    refs = torch.autograd.grad(da, [dyd, ad, gmd, btd], gd, allow_unused=True)
+    _, _, mean, rstd = ops.layernorm_fwd(a.to(dev), gamma.to(dev), beta.to(dev), eps, act=act)
+    da_k, _, _, _ = ops.layernorm_bwd(dy.to(dev), a.to(dev), gamma.to(dev), beta.to(dev), mean, rstd, act=act)
+    assert (da_k.cpu().double() - da.detach()).abs().max().item() < 1e-4
+    d_dy, d_a, d_gamma, d_beta = ops.layernorm_bwd2(g.to(dev), dy.to(dev), a.to(dev), gamma.to(dev), beta.to(dev), mean,
+                                                    rstd, act=act)
+    for name, got, ref in (("d_dy", d_dy, refs[0]), ("d_a", d_a, refs[1]), ("d_gamma", d_gamma, refs[2]),
+                           ("d_beta", d_beta, refs[3])):
+        ref = torch.zeros_like(got.cpu().double()) if ref is None else ref
+        err = (got.cpu().double() - ref).abs().max().item()
+        assert err < 2e-4 * max(1.0, ref.abs().max().item()), (name, err, ref.abs().max().item())
+    # accumulate into existing parameter gradients
+    dg0, db0 = torch.ones(cols, device=dev), torch.full((cols,), 2.0, device=dev)
+    ops.layernorm_bwd2(g.to(dev), dy.to(dev), a.to(dev), gamma.to(dev), beta.to(dev), mean, rstd, act=act, dgamma=dg0,
+                       dbeta=db0, accumulate=True)
+    assert torch.allclose(dg0, d_gamma + 1.0, rtol=1e-5, atol=1e-5) and torch.allclose(db0, d_beta + 2.0, rtol=1e-5, atol=1e-5)

@@ -28,6 +28,12 @@ CASES = [
     ("trimodal_loss", T.test_trimodal_loss_pairs_kernels_vs_f64, {}),
     ("packed_varlen", T.test_packed_varlen_path_equals_padded_path, {}),
     ("dropout_layer", T.test_dropout_layer_vs_masked_oracle, {}),
+    ("clip_opt_b128", T.test_clip_opt_b128_golden_loss_at_the_north_star_bar, {}),
+    ("c1_f32", T.test_clip_c1_exact_f32_linears_reproduce_the_fp32_reference, {}),
+    ("notebook_b32", T.test_notebook_model_b32_golden_loss_and_gradients, {}),
+    ("esm_integration", T.test_esm_integration_get_embeddings_golden, {}),
+    ("fifo_queue", T.test_cache_semantics_fifo_and_queue_loss_golden, {}),
+    ("from_config", T.test_protein_rna_clip_from_config_runs, {}),
 ]
 
 
