@@ -35,6 +35,14 @@ def relerr(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
 
 
+def bf16_weights(sd):
+    """The state_dict with every GEMM weight (2-D, or in_proj) rounded to bf16 and back: the MODEL the bf16-MFMA path
+    evaluates (north star: bf16 operands, f32 accumulate).  An f32 oracle on these weights isolates what is left -
+    activation rounding, summation order, the kernels themselves - from the perturbation the weight rounding makes to
+    the model, which is the same for every sample and therefore not averaged away by any batch size."""
+    return {k: (v.to(torch.bfloat16).float() if (v.dim() == 2 and v.is_floating_point()) else v) for k, v in sd.items()}
+
+
 def assert_grad_close(g, ref, name, cos_min=0.99, rel_max=0.25):
     """bf16-operand GEMMs: gradient DIRECTION must match tightly; single entries (sums with cancellation, ReLU
     decisions flipped by rounding) only loosely.  See DESIGN.md §precision."""
@@ -749,11 +757,11 @@ def test_clip_c1_exact_f32_linears_reproduce_the_fp32_reference(dev):
 def test_notebook_model_b32_golden_loss_and_gradients(dev):
     """VERDICT r02 #3a: the notebook model (rna_clip_codes.ipynb:1925-1954: batch-axis attention, NaN padding,
     position-0 pooling) at the notebook's batch size with ragged lengths: embeddings, loss and the direction of EVERY
-    parameter gradient that is not negligible.  Loss bar 3e-3: at these reduced widths (40 / 128) the rounding of the
-    WEIGHTS to bf16 alone moves the loss by 2e-3 (tests/ops_emulator.py with / without weight rounding: 2.0e-3 -> 2.0e-4;
-    activations, the residual stream and GEMM outputs contribute < 4e-4) - a perturbation of the model itself, which no
-    batch size averages away; the widths the reference trained (120 / 1280) sit at 1e-4 .. 1e-3
-    (profiles/r03/notebook_parity_*.txt, tests/test_gpu_configs.py)."""
+    parameter gradient that is not negligible.  Two loss bars: (i) 1e-3 against the oracle evaluated on the bf16-ROUNDED
+    weights - everything the kernels do; (ii) 5e-3 against the reference's own value: at these reduced widths (40 / 128)
+    the rounding of the weights to bf16 alone moves the loss by 2 - 3e-3 (tests/ops_emulator.py with / without weight
+    rounding: 2.0e-3 -> 2.0e-4), a perturbation of the model itself that no batch size averages away; the widths the
+    reference trained (120 / 1280) sit at 1e-4 .. 1e-3 (profiles/r03/notebook_parity_*.txt, tests/test_gpu_configs.py)."""
     import clip_dplm_amd as K
     z, sd = load("notebook_model_b32.npz")
     m = K.RNARBPCLIPModel(rna_dim=40, rbp_dim=128, projection_dim=64)
@@ -762,7 +770,11 @@ def test_notebook_model_b32_golden_loss_and_gradients(dev):
     ea, eb, loss = m(t(z, "rna", dev), t(z, "rbp", dev))
     assert (ea.cpu() - t(z, "rna_embed")).abs().max().item() < 0.02
     assert (eb.cpu() - t(z, "rbp_embed")).abs().max().item() < 0.02
-    assert abs(loss.item() - float(z["loss"])) < 3e-3, (loss.item(), float(z["loss"]))
+    from oracle import model_ref
+    with torch.no_grad():
+        _, _, lw = model_ref.rnarbp_clip_forward(bf16_weights(sd), t(z, "rna"), t(z, "rbp"))
+    assert abs(loss.item() - lw.item()) < 1e-3, (loss.item(), lw.item())               # (i) the kernels' arithmetic
+    assert abs(loss.item() - float(z["loss"])) < 5e-3, (loss.item(), float(z["loss"]))  # (ii) incl. bf16 weights
     loss.backward()
     gmax = max(t(z, "g:" + n).abs().max().item() for n, _ in m.named_parameters())
     worst = 1.0
@@ -773,7 +785,8 @@ def test_notebook_model_b32_golden_loss_and_gradients(dev):
         cos = torch.nn.functional.cosine_similarity(p.grad.detach().cpu().flatten(), ref.flatten(), dim=0).item()
         worst = min(worst, cos)
         assert cos > 0.99, (n, cos)
-    print(f"notebook b32: |dloss| = {abs(loss.item() - float(z['loss'])):.2e}, worst gradient cosine {worst:.5f}")
+    print(f"notebook b32: |dloss| vs reference {abs(loss.item() - float(z['loss'])):.2e}, vs oracle on bf16 weights "
+          f"{abs(loss.item() - lw.item()):.2e}, worst gradient cosine {worst:.5f}")
 
 
 def test_esm_integration_get_embeddings_golden(dev):

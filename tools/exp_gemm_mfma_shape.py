@@ -9,7 +9,9 @@ Both builds run WITHOUT the epilogue (option gemm_abl = 1): the main loop alone,
 build multiplies fragments fetched in the 16x16x32 lane layout: its products are garbage, its instruction mix is not).
 Per shape and arm, after >= 2 s of back-to-back launches (the clock the chip holds under THIS load): wall time per
 launch (HIP events, interleaved rounds), shader cycles per K-tile of workgroup 0 (s_memtime around its main loops) and
-the in-kernel clock (s_memtime / s_memrealtime), as tools/exp_wgrad_trace.py does for the weight-gradient kernel."""
+the in-kernel clock (s_memtime / s_memrealtime), as tools/exp_wgrad_trace.py does for the weight-gradient kernel.
+"pipe busy" = 2048 / (cycles per K-tile): a 256 x 256 x 64 K-tile is 8.39 MFLOP = 2048 cycles of a CU's four matrix pipes
+(1024 FLOP per cycle and SIMD for either MFMA shape)."""
 import ctypes as C
 import os
 import sys
@@ -67,7 +69,7 @@ for sname, M, N, K in SHAPES:
         cyc, ticks, nkt = trace.cpu().tolist()[:3]
         res[arm] = us
         print(f"{sname:18s} {('16x16x32' if arm == '16' else '32x32x16'):>10s} {us:10.1f} {2.0 * M * N * K / us / 1e6:8.0f} "
-              f"{cyc / max(nkt, 1):11.0f} {1024.0 * nkt / max(cyc, 1):10.3f} {cyc / max(ticks, 1) * 0.1:14.3f}", flush=True)
+              f"{cyc / max(nkt, 1):11.0f} {2048.0 * nkt / max(cyc, 1):10.3f} {cyc / max(ticks, 1) * 0.1:14.3f}", flush=True)
         lib.clipk_gemm_v3_set_trace(None)
     print(f"{'':18s} 32x32x16 / 16x16x32 wall = {res['32'] / res['16']:.3f}")
     del a, b, c
