@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libclipk.so")
 
-BF16, F32 = 0, 1
+BF16, F32, U8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_CELU, ACT_SOFTPLUS = 0, 1, 2, 3, 4
 ACT = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "gelu": ACT_GELU, "celu": ACT_CELU, "softplus": ACT_SOFTPLUS}
 
@@ -37,6 +37,7 @@ class GemmArgs(C.Structure):
         ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
         ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
         ("rope_L", C.c_int), ("rope_hd", C.c_int), ("rope_cols", C.c_int), ("rope_row0", C.c_int),
+        ("aux_dtype", C.c_int),
     ]
 
 

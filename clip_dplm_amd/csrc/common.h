@@ -124,6 +124,41 @@ __device__ __forceinline__ float act_grad(float x, int act) {
   return 1.f;
 }
 
+// ---- GELU'(u) as an 8-bit code: what the FFN keeps for its backward instead of the bf16 pre-activation u.
+// GELU' takes values in [-0.1290, 1.1290]; the code is the nearest of 256 levels over [-0.13, 1.13] (step 0.00494, error
+// <= 0.0025 absolute - the size of a bf16 rounding of a value near 1): half the bytes of u in the two store-bound FFN
+// epilogues, no erf in the backward one.  The forward value GELU(u) is untouched.
+constexpr float CLIPK_GD8_MIN = -0.13f, CLIPK_GD8_STEP = 1.26f / 255.0f, CLIPK_GD8_INV = 255.0f / 1.26f;
+__device__ __forceinline__ unsigned gelu_grad_code(float d) {                 // d = GELU'(u) -> 0 .. 255
+  float t = fmaf(d, CLIPK_GD8_INV, -CLIPK_GD8_MIN * CLIPK_GD8_INV + 0.5f);    // + 0.5: v_cvt_u32_f32 truncates
+  t = t < 0.f ? 0.f : (t > 255.f ? 255.f : t);
+  return (unsigned)t;
+}
+__device__ __forceinline__ float gelu_grad_decode(unsigned q) { return fmaf((float)q, CLIPK_GD8_STEP, CLIPK_GD8_MIN); }
+// eight codes -> two dwords (columns in byte order)
+__device__ __forceinline__ u32x2 gelu_grad_pack8(const float (&d)[8]) {
+  u32x2 w;
+  w[0] = gelu_grad_code(d[0]) | (gelu_grad_code(d[1]) << 8) | (gelu_grad_code(d[2]) << 16) | (gelu_grad_code(d[3]) << 24);
+  w[1] = gelu_grad_code(d[4]) | (gelu_grad_code(d[5]) << 8) | (gelu_grad_code(d[6]) << 16) | (gelu_grad_code(d[7]) << 24);
+  return w;
+}
+// GELU(x) and the code of GELU'(x) for two elements from ONE evaluation of erf / exp, the code's scale and offset folded
+// into the derivative's own two fmas: t = (Phi + x phi) * INV - MIN * INV, written into byte `b`, `b + 1` of `w` by
+// v_cvt_pk_u8_f32, which ROUNDS to nearest and saturates to 0 .. 255 (measured: with the + 0.5 of the truncating
+// v_cvt_u32_f32 path every code came out half a level high; the GPU test bounds the mean code error)
+__device__ __forceinline__ f32x2 gelu_erf2_code(f32x2 x, unsigned& w, int b) {
+  const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+  f32x2 erf_abs, e;
+  gelu_parts2(x, ax, erf_abs, e);
+  constexpr float C0 = 0.5f * CLIPK_GD8_INV - CLIPK_GD8_MIN * CLIPK_GD8_INV;
+  const f32x2 hs = {copysignf(0.5f * CLIPK_GD8_INV, x[0]), copysignf(0.5f * CLIPK_GD8_INV, x[1])};
+  const f32x2 cdf = __builtin_elementwise_fma(hs, erf_abs, splat2(C0));
+  const f32x2 t = __builtin_elementwise_fma(x * splat2(0.39894228040143267794f * CLIPK_GD8_INV), e, cdf);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(t[0], b, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(t[1], b + 1, w);
+  return __builtin_elementwise_fma(ax * splat2(0.5f), erf_abs, x * splat2(0.5f));
+}
+
 // second derivative of the activations the ICNN potential uses (2_icnn_core.py:121-127: CELU default, softplus): the
 // training branch back-propagates through T(x) = dPsi/dx, i.e. through act'
 __device__ __forceinline__ float act_grad2(float x, int act) {

@@ -24,6 +24,7 @@ struct EpiArgs {
   const unsigned short* dact_aux; long ldd; int dact;
   const void* residual; long ldr; int r_f32;
   float alpha;
+  int aux_u8;       // out_preact / dact_aux hold 8-bit GELU' codes (clipk.h aux_dtype) instead of the bf16 pre-activation
   int nt;           // 1: non-temporal (streaming) output stores (epi_args_from decides)
   unsigned drop_thr, drop_seed; float drop_scale;   // dropout after the activation (generic epilogue only); thr 0 = off
   const float* rope_cos; const float* rope_sin; int rope_L, rope_hd, rope_cols, rope_row0;   // EPI_ROPE only
@@ -38,20 +39,27 @@ enum {
   EPI_RES16 = 4,      // f32 out = acc (+bias) + bf16 residual   (post-LN layers: the residual is the bf16 LayerNorm output)
   EPI_PRES16 = 5,     // bf16 out = acc (+bias) + bf16 residual  (their input gradients: bf16 residual-path gradient)
   EPI_ROPE = 6,       // bf16 out = rotate-half RoPE of (acc + bias) on the first rope_cols columns, plain on the rest
+  EPI_GELU_D8 = 7,    // u8 GELU'(pre-activation) code out and bf16 GELU out (+bias)
+  EPI_DGELU8 = 8,     // bf16 out = acc * decode(u8 aux)
 };
 constexpr int EPI_UNSUPPORTED = -2;   // epi_mode_for: the request cannot be honoured by any epilogue
 
 // VMEM stores one wave issues in gemm_epilogue<MODE, NJ> (its loads are consumed inside): callers that keep LDS-DMA
 // in flight across the epilogue count them in their s_waitcnt vmcnt(N)
 constexpr int epi_stores(int mode, int nj) {
-  return (mode == EPI_PLAIN || mode == EPI_DGELU || mode == EPI_PRES16 || mode == EPI_ROPE) ? 2 * nj
-         : (mode == EPI_RES32 || mode == EPI_GELU_PRE || mode == EPI_RES16) ? 4 * nj : -1;
+  return (mode == EPI_PLAIN || mode == EPI_DGELU || mode == EPI_PRES16 || mode == EPI_ROPE || mode == EPI_DGELU8) ? 2 * nj
+         : (mode == EPI_RES32 || mode == EPI_GELU_PRE || mode == EPI_RES16 || mode == EPI_GELU_D8) ? 4 * nj : -1;
 }
 
 // which specialised mode (if any) matches a request
 static inline int epi_mode_for(const clipk_gemm_args* a) {
   const bool c_f32 = a->c_dtype == CLIPK_F32, has_res = a->residual != nullptr, has_aux = a->dact_aux != nullptr;
   const bool has_pre = a->out_preact != nullptr;
+  const bool aux8 = a->aux_dtype == CLIPK_U8;
+  if (aux8) {                                            // 8-bit GELU' codes: the FFN pair only
+    if (has_pre && (a->act != CLIPK_ACT_GELU || (a->ldp & 7))) return EPI_UNSUPPORTED;
+    if (has_aux && (a->dact != CLIPK_ACT_GELU || (a->ldd & 7))) return EPI_UNSUPPORTED;
+  }
   const long lim = 0x7fffffffL;                          // buffer-descriptor stores: byte extents must stay < 2 GiB
   if (a->rope_cos) {                                     // rotation exists in its straight-line mode only
     const int hd = a->rope_hd;
@@ -63,15 +71,16 @@ static inline int epi_mode_for(const clipk_gemm_args* a) {
   }
   if (a->drop_p > 0.f) return EPI_GENERIC;               // dropout lives in the run-time epilogue
   if (((long)(a->M - 1) * a->ldc + a->N) * (c_f32 ? 4 : 2) > lim) return EPI_GENERIC;
-  if (has_pre && ((long)(a->M - 1) * a->ldp + a->N) * 2 > lim) return EPI_GENERIC;
+  if (has_pre && ((long)(a->M - 1) * a->ldp + a->N) * (aux8 ? 1 : 2) > lim) return EPI_GENERIC;
   if (a->act == CLIPK_ACT_NONE && !has_aux && !has_res && !has_pre && !c_f32) return EPI_PLAIN;
   if (a->act == CLIPK_ACT_NONE && !has_aux && has_res && a->r_dtype == CLIPK_F32 && !has_pre && c_f32) return EPI_RES32;
   if (a->act == CLIPK_ACT_NONE && !has_aux && has_res && a->r_dtype == CLIPK_BF16 && !has_pre)
     return c_f32 ? EPI_RES16 : EPI_PRES16;
   // (without a pre-activation output — frozen encoders keep nothing for a backward — the same mode runs with a
   // zero-length descriptor for u: the hardware drops those stores)
-  if (a->act == CLIPK_ACT_GELU && !has_aux && !has_res && !c_f32) return EPI_GELU_PRE;
-  if (a->act == CLIPK_ACT_NONE && has_aux && a->dact == CLIPK_ACT_GELU && !has_res && !has_pre && !c_f32) return EPI_DGELU;
+  if (a->act == CLIPK_ACT_GELU && !has_aux && !has_res && !c_f32) return (aux8 && has_pre) ? EPI_GELU_D8 : EPI_GELU_PRE;
+  if (a->act == CLIPK_ACT_NONE && has_aux && a->dact == CLIPK_ACT_GELU && !has_res && !has_pre && !c_f32)
+    return aux8 ? EPI_DGELU8 : EPI_DGELU;
   return EPI_GENERIC;
 }
 
@@ -133,9 +142,10 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
     constexpr unsigned OOB = 0x80000000u;
     const int c_elt = (MODE == EPI_RES32 || MODE == EPI_RES16) ? 4 : 2;
     const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)(((long)(M - 1) * p.ldc + N) * c_elt), 0x00020000);
+    constexpr bool HAS_U = MODE == EPI_GELU_PRE || MODE == EPI_GELU_D8;
     const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (MODE == EPI_GELU_PRE && p.out_preact) ? (void*)p.out_preact : p.C, 0,
-        (MODE == EPI_GELU_PRE && p.out_preact) ? (int)(((long)(M - 1) * p.ldp + N) * 2) : 0, 0x00020000);
+        (HAS_U && p.out_preact) ? (void*)p.out_preact : p.C, 0,
+        (HAS_U && p.out_preact) ? (int)(((long)(M - 1) * p.ldp + N) * (MODE == EPI_GELU_D8 ? 1 : 2)) : 0, 0x00020000);
     constexpr int S = 2 * NJ;
     f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f};       // residual (RoPE: cosines) of the current slice
     f32x4 r2 = {0.f, 0.f, 0.f, 0.f}, r3 = {0.f, 0.f, 0.f, 0.f};       // RoPE: sines of the current slice
@@ -176,6 +186,10 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
         a1 = *reinterpret_cast<const f32x4*>(r + 4);
       }
       if constexpr (MODE == EPI_DGELU) b = *reinterpret_cast<const u32x4*>(p.dact_aux + (long)gm * p.ldd + gnc);
+      if constexpr (MODE == EPI_DGELU8) {                    // eight 1-byte codes
+        const u32x2 q = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned char*>(p.dact_aux) + (long)gm * p.ldd + gnc);
+        b = u32x4{q[0], q[1], 0u, 0u};
+      }
       if constexpr (MODE == EPI_RES16 || MODE == EPI_PRES16)
         b = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(p.residual) + (long)gm * p.ldr + gnc);
     };
@@ -284,6 +298,31 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
         const unsigned off = ok ? (unsigned)(((long)gm * p.ldc + gn) * 2) : OOB;
         epi_store(u, u_rsrc, offu, p.nt);
         epi_store(o, c_rsrc, off, p.nt);
+      } else if constexpr (MODE == EPI_GELU_D8) {
+        u32x4 o;
+        unsigned q0 = 0u, q1 = 0u;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x2 y = gelu_erf2_code(f32x2{v[2 * c], v[2 * c + 1]}, c < 2 ? q0 : q1, 2 * (c & 1));   // packed-f32 pipe
+          o[c] = pack_bf16x2(y[0], y[1]);
+        }
+        const u32x2 q = {q0, q1};
+        const unsigned offu = (ok && p.out_preact) ? (unsigned)((long)gm * p.ldp + gn) : OOB;
+        const unsigned off = ok ? (unsigned)(((long)gm * p.ldc + gn) * 2) : OOB;
+        if (p.nt) __builtin_amdgcn_raw_buffer_store_b64(q, u_rsrc, offu, 0, 2);
+        else __builtin_amdgcn_raw_buffer_store_b64(q, u_rsrc, offu, 0, 0);
+        epi_store(o, c_rsrc, off, p.nt);
+      } else if constexpr (MODE == EPI_DGELU8) {
+        u32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const unsigned w = ax[c >> 1] >> (16 * (c & 1));
+          v[2 * c] *= gelu_grad_decode(w & 0xffu);
+          v[2 * c + 1] *= gelu_grad_decode((w >> 8) & 0xffu);
+          o[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
+        }
+        const unsigned off = ok ? (unsigned)(((long)gm * p.ldc + gn) * 2) : OOB;
+        epi_store(o, c_rsrc, off, p.nt);
       } else {  // EPI_DGELU
         u32x4 o;
 #pragma unroll
@@ -314,10 +353,17 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
         }
         if (gm < M && gn < N) {
           if (p.out_preact) {
-            u32x4 o;
+            if (p.aux_u8) {
+              float d[8];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) o[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
-            *reinterpret_cast<u32x4*>(p.out_preact + (long)gm * p.ldp + gn) = o;
+              for (int c = 0; c < 8; ++c) d[c] = gelu_erf_grad(v[c]);
+              *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(p.out_preact) + (long)gm * p.ldp + gn) = gelu_grad_pack8(d);
+            } else {
+              u32x4 o;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) o[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
+              *reinterpret_cast<u32x4*>(p.out_preact + (long)gm * p.ldp + gn) = o;
+            }
           }
           if (p.act != CLIPK_ACT_NONE) {
 #pragma unroll
@@ -328,7 +374,11 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
 #pragma unroll
             for (int c = 0; c < 8; ++c) v[c] *= drop_mul(p.drop_seed, base + c, p.drop_thr, p.drop_scale);
           }
-          if (p.dact_aux) {
+          if (p.dact_aux && p.aux_u8) {
+            const u32x2 a = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned char*>(p.dact_aux) + (long)gm * p.ldd + gn);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] *= gelu_grad_decode((a[c >> 2] >> (8 * (c & 3))) & 0xffu);
+          } else if (p.dact_aux) {
             const u32x4 a = *reinterpret_cast<const u32x4*>(p.dact_aux + (long)gm * p.ldd + gn);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -378,6 +428,7 @@ static inline EpiArgs epi_args_from(const clipk_gemm_args* a) {
   e.dact_aux = (const unsigned short*)a->dact_aux; e.ldd = a->ldd; e.dact = a->dact;
   e.residual = a->residual; e.ldr = a->ldr; e.r_f32 = (a->r_dtype == CLIPK_F32);
   e.alpha = a->alpha;
+  e.aux_u8 = (a->aux_dtype == CLIPK_U8);
   // Streaming (non-temporal) output stores, option epi_nt = 1.  In the kernel microbenchmark they are worth 7 % on the
   // hot shapes (the output stream stops evicting operand panels from L2: esm qkv 256 -> 192 us; f32 residual outputs
   // get slower), in the training step nothing (96.8 vs 96.6 ms): there the consumer of the output runs next and finds

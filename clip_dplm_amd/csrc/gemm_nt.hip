@@ -229,6 +229,7 @@ extern "C" int clipk_gemm_nt(const clipk_gemm_args* a, void* stream) {
   if (!a || !a->A || !a->B || !a->C) return CLIPK_ERR_BAD_ARG;
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return CLIPK_ERR_BAD_ARG;
   if (!(a->drop_p >= 0.f) || a->drop_p >= 1.f) return CLIPK_ERR_BAD_ARG;      // nn.Dropout(p = 1) zeroes: not a mask
+  if (a->aux_dtype != CLIPK_BF16 && a->aux_dtype != CLIPK_U8) return CLIPK_ERR_BAD_ARG;
   const long c_elt = a->c_dtype == CLIPK_F32 ? 4 : 2, r_elt = a->r_dtype == CLIPK_F32 ? 4 : 2;
   long row_bytes = a->ldc * c_elt;
   if (a->out_preact && a->ldp * 2 > row_bytes) row_bytes = a->ldp * 2;
@@ -242,8 +243,9 @@ extern "C" int clipk_gemm_nt(const clipk_gemm_args* a, void* stream) {
     c.M = (int)((a->M - m0) < max_rows ? (a->M - m0) : max_rows);
     c.A = (const char*)a->A + m0 * a->lda * 2;
     c.C = (char*)a->C + m0 * a->ldc * c_elt;
-    if (a->out_preact) c.out_preact = (char*)a->out_preact + m0 * a->ldp * 2;
-    if (a->dact_aux) c.dact_aux = (const char*)a->dact_aux + m0 * a->ldd * 2;
+    const long aux_elt = a->aux_dtype == CLIPK_U8 ? 1 : 2;
+    if (a->out_preact) c.out_preact = (char*)a->out_preact + m0 * a->ldp * aux_elt;
+    if (a->dact_aux) c.dact_aux = (const char*)a->dact_aux + m0 * a->ldd * aux_elt;
     if (a->residual) c.residual = (const char*)a->residual + m0 * a->ldr * r_elt;
     c.rope_row0 = a->rope_row0 + (int)m0;                 // positions count from the first row of the whole problem
     // dropout masks are indexed by the global element position m * N + n: not supported across slabs
@@ -278,6 +280,7 @@ static int gemm_nt_one(const clipk_gemm_args* a, void* stream) {
     return clipk_gemm_nt_v3_launch(a, stream);
   if (!force_v1 && (a->K & 31) == 0) return clipk_gemm_nt_v2_launch(a, stream);
   if (a->rope_cos) return CLIPK_ERR_UNSUPPORTED;           // the generic-K kernel has no rotation
+  if (a->aux_dtype == CLIPK_U8 && (a->out_preact || a->dact_aux)) return CLIPK_ERR_UNSUPPORTED;   // ... and no 8-bit aux
   Params p;
   p.A = (const unsigned short*)a->A; p.lda = a->lda;
   p.B = (const unsigned short*)a->B; p.ldb = a->ldb;

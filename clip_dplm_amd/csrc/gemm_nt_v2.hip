@@ -199,6 +199,8 @@ extern "C" int clipk_gemm_nt_v2_launch(const clipk_gemm_args* a, void* stream) {
     else if (mode == EPI_RES16) hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, EPI_RES16>), grid, blk, lds, st, p);
     else if (mode == EPI_PRES16) hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, EPI_PRES16>), grid, blk, lds, st, p);
     else if (mode == EPI_ROPE) hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, EPI_ROPE>), grid, blk, lds, st, p);
+    else if (mode == EPI_GELU_D8) hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, EPI_GELU_D8>), grid, blk, lds, st, p);
+    else if (mode == EPI_DGELU8) hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, EPI_DGELU8>), grid, blk, lds, st, p);
     else hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1>), grid, blk, lds, st, p);
   }
   return clipk_check_launch();

@@ -167,6 +167,13 @@ def _varlen_prerot(meta):
     return PREROTATE_QK and seq is not None and rope is not None and ops.varlen_whole_head_applies(seq[1], D)
 
 
+# What the FFN keeps for its backward: the bf16 pre-activation u (GELU' recomputed from it), or - default - GELU'(u) itself
+# as 8-bit codes written by the fc1 epilogue next to GELU(u) (clipk.h aux_dtype): 1 instead of 2 bytes per hidden
+# element in the two store-bound FFN epilogues of every layer, no erf in the backward one.  The forward is untouched;
+# the backward's GELU' factor carries an absolute error <= 0.0025.  CLIPK_GELU_AUX=bf16 keeps the pre-activation.
+GELU_AUX_U8 = os.environ.get("CLIPK_GELU_AUX", "u8") != "bf16"
+
+
 def _esm_layer_fwd(x, p, meta, keep=True):
     """x: f32 [T,d].  p: dict of this layer's tensors.  Returns y f32 [T,d] and the saved activations."""
     B, L, H, D, mask, rope, eps, seq = meta
@@ -198,7 +205,7 @@ def _esm_layer_ffn_fwd(x, x2, p, eps, keep, att):
     h1, m1, r1, qkv, ctx, lse = att
     _, h2, m2, r2 = ops.layernorm_fwd(x2, p["ln2_w"], p["ln2_b"], eps, want_f32=False, want_bf16=True)
     if keep:
-        g, u = ops.gemm_nt(h2, p["fc1"].wb, bias=p["fc1"].b, act="gelu", out_preact=True)
+        g, u = ops.gemm_nt(h2, p["fc1"].wb, bias=p["fc1"].b, act="gelu", out_preact=True, aux_u8=GELU_AUX_U8)
     else:                                                  # frozen encoder: nothing is kept for a backward
         g, u = ops.gemm_nt(h2, p["fc1"].wb, bias=p["fc1"].b, act="gelu"), None
     y = ops.gemm_nt(g, p["fc2"].wb, bias=p["fc2"].b, residual=x2, out_dtype=torch.float32)
@@ -536,7 +543,8 @@ def _post_layer_fwd(x, xb, p, meta, dr=None):
     else:
         x1, x1b, m1, r1 = ops.layernorm_fwd(s1, p["n1_w"], p["n1_b"], eps, want_f32=True, want_bf16=True)
     if act == "gelu":
-        g, u = ops.gemm_nt(x1b, p["fc1"].wb, bias=p["fc1"].b, act="gelu", out_preact=True, dropout=df)
+        g, u = ops.gemm_nt(x1b, p["fc1"].wb, bias=p["fc1"].b, act="gelu", out_preact=True, dropout=df,
+                           aux_u8=GELU_AUX_U8 and df is None)
     else:
         g = ops.gemm_nt(x1b, p["fc1"].wb, bias=p["fc1"].b, act="relu", dropout=df)
         u = g                                    # relu'(pre) == relu'(relu(pre)); a dropped element has g = 0 either way

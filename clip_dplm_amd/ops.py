@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from . import _ffi
-from ._ffi import ACT, BF16, F32, GemmArgs, check, ptr
+from ._ffi import ACT, BF16, F32, U8, GemmArgs, check, ptr
 
 _WS: dict = {}
 
@@ -133,8 +133,10 @@ def workspace(nbytes: int, device, tag: str = "ws") -> torch.Tensor:
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, act=None,
             out_dtype=torch.bfloat16, residual: Optional[torch.Tensor] = None, out_preact: bool = False,
             dact_aux: Optional[torch.Tensor] = None, dact=None, alpha: float = 1.0,
-            out: Optional[torch.Tensor] = None, dropout=None, rope=None):
+            out: Optional[torch.Tensor] = None, dropout=None, rope=None, aux_u8: bool = False):
     """C = epilogue(a[M,K] @ b[N,K]^T) with a, b bf16.  Returns C (and the bf16 pre-activation if asked).
+    aux_u8 (act = "gelu", out_preact): the second output is GELU'(pre-activation) as 8-bit codes (uint8 [M, N]) instead of
+    the bf16 pre-activation; a uint8 `dact_aux` (dact = "gelu") is read as such codes (clipk.h aux_dtype).
     dropout = (p, seed): nn.Dropout on the value after the activation (before act'(aux) and the residual add).
     rope = (cos, sin, L, hd, cols): rotate-half RoPE (tables f32 [L, hd/2], position = row mod L) on the first `cols`
     output columns in the epilogue (ESM-2's fused qkv projection: cols = 2 * hidden)."""
@@ -145,7 +147,11 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
     M, K = a.shape
     N = b.shape[0]
     c = out if out is not None else torch.empty((M, N), dtype=out_dtype, device=a.device)
-    pre = torch.empty((M, N), dtype=torch.bfloat16, device=a.device) if out_preact else None
+    aux8 = bool(aux_u8 and out_preact) or (dact_aux is not None and dact_aux.dtype == torch.uint8)
+    if aux8:
+        assert (act == "gelu" or not out_preact) and (dact == "gelu" or dact_aux is None), "8-bit aux: GELU only"
+        assert dact_aux is None or dact_aux.dtype == torch.uint8
+    pre = torch.empty((M, N), dtype=torch.uint8 if aux8 else torch.bfloat16, device=a.device) if out_preact else None
     args = GemmArgs()
     args.A, args.lda = a.data_ptr(), a.stride(0)
     args.B, args.ldb = b.data_ptr(), b.stride(0)
@@ -161,6 +167,7 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
     else:
         args.residual, args.ldr, args.r_dtype = None, 0, 0
     args.alpha = alpha
+    args.aux_dtype = U8 if aux8 else BF16
     args.drop_p, args.drop_seed = (float(dropout[0]), int(dropout[1]) & 0xFFFFFFFF) if dropout else (0.0, 0)
     if rope is not None:
         cos, sin, rl, hd, cols = rope
@@ -172,12 +179,13 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
         args.rope_cos, args.rope_sin = None, None
         args.rope_L = args.rope_hd = args.rope_cols = args.rope_row0 = 0
     # algorithmic bytes: both operands once, every output / epilogue operand once
-    nb = 2.0 * (M * K + N * K) + M * N * (c.element_size() + (2 if out_preact else 0) + (2 if dact_aux is not None else 0)
+    nb = 2.0 * (M * K + N * K) + M * N * (c.element_size() + (pre.element_size() if out_preact else 0) +
+                                          (dact_aux.element_size() if dact_aux is not None else 0)
                                           + (residual.element_size() if residual is not None else 0))
     sub = None
     if _TIMER is not None:                                   # epilogue mode of this launch (bench.py: per-mode rates)
-        sub = ("dact_" + str(dact) if dact_aux is not None else ("act_" + str(act) if act else "linear")) + \
-              ("+preact" if out_preact else "") + ("+rope" if rope is not None else "") + \
+        sub = ("dact_" + str(dact) + ("8" if aux8 else "") if dact_aux is not None else ("act_" + str(act) if act else "linear")) + \
+              (("+dact8" if aux8 else "+preact") if out_preact else "") + ("+rope" if rope is not None else "") + \
               ("+res_" + ("f32" if residual.dtype == torch.float32 else "bf16") if residual is not None else "") + \
               ("+drop" if dropout else "") + ("->f32" if c.dtype == torch.float32 else "->bf16")
     check(_timed("gemm_nt", 2.0 * M * N * K, lambda: _lib().clipk_gemm_nt(C.byref(args), _stream()), nb, sub),

@@ -33,7 +33,7 @@ typedef enum clipk_status {
   CLIPK_ERR_LAUNCH = -3         /* hipGetLastError() != hipSuccess after the launch                 */
 } clipk_status;
 
-typedef enum clipk_dtype { CLIPK_BF16 = 0, CLIPK_F32 = 1 } clipk_dtype;
+typedef enum clipk_dtype { CLIPK_BF16 = 0, CLIPK_F32 = 1, CLIPK_U8 = 2 } clipk_dtype;
 typedef enum clipk_act { CLIPK_ACT_NONE = 0, CLIPK_ACT_RELU = 1, CLIPK_ACT_GELU = 2, CLIPK_ACT_CELU = 3,
                          CLIPK_ACT_SOFTPLUS = 4 } clipk_act;
 
@@ -88,6 +88,14 @@ typedef struct clipk_gemm_args {
    * off.  Requirements: bf16 output, no activation / residual / aux / dropout, rope_hd in {16, 32, 64},
    * rope_cols % rope_hd == 0, K % 32 == 0; anything else returns CLIPK_ERR_UNSUPPORTED (never silently unrotated). */
   const float* rope_cos; const float* rope_sin; int rope_L, rope_hd, rope_cols, rope_row0;
+  /* aux_dtype = CLIPK_U8 (act / dact must be GELU): the auxiliary tensor of the FFN pair is the DERIVATIVE GELU'(v) as an
+   * 8-bit code instead of the bf16 pre-activation v - out_preact receives u8 [M, N] codes (ldp in bytes, % 8 == 0),
+   * dact_aux is read as such codes and the product is multiplied by the decoded value: code = round((GELU'(v) + 0.13) *
+   * 255 / 1.26), 256 levels over [-0.13, 1.13] (GELU' lies in [-0.129, 1.129]), error <= 0.0025 - half the bytes of the
+   * pre-activation in the two store-bound FFN epilogues of EsmLayer / nn.TransformerEncoderLayer(activation = gelu)
+   * (modeling_esm.py:517-521; run1/configuration_hybrid_clip.py:75 hidden_act), nothing but the backward's GELU' factor
+   * is affected.  CLIPK_BF16 (0): the pre-activation itself, as before. */
+  int aux_dtype;
 } clipk_gemm_args;
 int clipk_gemm_nt(const clipk_gemm_args* args, void* stream);
 

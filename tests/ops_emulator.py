@@ -58,8 +58,16 @@ def drop_mult(p, seed, idx):
     return (drop_hash32(seed, idx) >= thr).float() / (1.0 - p)
 
 
+GD8_MIN, GD8_STEP = -0.13, 1.26 / 255.0
+
+
+def gelu_grad_code(x):
+    """clipk.h aux_dtype = U8: GELU'(x) -> nearest of 256 levels over [-0.13, 1.13]."""
+    return torch.clamp(torch.floor((_act_grad(x, "gelu") - GD8_MIN) / GD8_STEP + 0.5), 0, 255).to(torch.uint8)
+
+
 def gemm_nt(a, b, bias=None, act=None, out_dtype=BF, residual=None, out_preact=False, dact_aux=None, dact=None,
-            alpha=1.0, out=None, dropout=None, rope=None):
+            alpha=1.0, out=None, dropout=None, rope=None, aux_u8=False):
     v = (a.float() @ b.float().t()) * alpha
     if bias is not None:
         v = v + bias
@@ -72,12 +80,14 @@ def gemm_nt(a, b, bias=None, act=None, out_dtype=BF, residual=None, out_preact=F
         x = v[:, :cols].reshape(M_, cols // hd, hd)
         rot = torch.cat([-x[..., hd // 2:], x[..., :hd // 2]], -1)
         v = torch.cat([(x * c + rot * s_).reshape(M_, cols), v[:, cols:]], 1)
-    pre = v.to(BF) if out_preact else None
+    pre = (gelu_grad_code(v) if aux_u8 else v.to(BF)) if out_preact else None
     v = _act(v, act)
     if dropout:
         M_, N_ = v.shape
         v = v * drop_mult(dropout[0], dropout[1], torch.arange(M_ * N_, dtype=torch.int64).view(M_, N_))
-    if dact_aux is not None:
+    if dact_aux is not None and dact_aux.dtype == torch.uint8:
+        v = v * (dact_aux.float() * GD8_STEP + GD8_MIN)
+    elif dact_aux is not None:
         v = v * _act_grad(dact_aux.float(), dact)
     if residual is not None:
         v = v + residual.float()

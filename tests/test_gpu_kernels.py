@@ -126,6 +126,19 @@ def test_gemm_nt_specialised_epilogues(dev, kopt, kernel, M, N, K):
     gref, = torch.autograd.grad(F.gelu(auxf), auxf, torch.ones_like(auxf))
     d = ops.gemm_nt(a, b, dact_aux=aux, dact="gelu")
     assert torch.allclose(d.float(), ref * gref, **tol)
+    # GELU_D8 / DGELU8: the FFN pair's auxiliary as 8-bit codes of GELU'(pre-activation) (clipk.h aux_dtype)
+    g8, q = ops.gemm_nt(a, b, bias=bias, act="gelu", out_preact=True, aux_u8=True)
+    assert q.dtype == torch.uint8 and q.shape == (M, N)
+    assert torch.equal(g8, g)                                   # the forward value does not depend on the aux format
+    pre = (ref + bias).requires_grad_(True)
+    dref, = torch.autograd.grad(F.gelu(pre), pre, torch.ones_like(pre))
+    step, lo = 1.26 / 255.0, -0.13
+    dec = q.float() * step + lo
+    # the kernel's pre-activation differs from torch's f32 product by summation order only: codes within one level
+    assert (dec - dref).abs().max().item() <= 1.5 * step, (dec - dref).abs().max().item()
+    assert (dec - dref).abs().mean().item() <= 0.3 * step
+    d8 = ops.gemm_nt(a, b, dact_aux=q, dact="gelu")
+    assert torch.allclose(d8.float(), ref * dec, **tol)
     # nothing may be written outside [M, N]: run into a padded buffer and check the guard band
     big = torch.full((M + 8, N + 8), 7.0, dtype=torch.bfloat16, device=dev)
     ops.gemm_nt(a, b, bias=bias, out=big[:M, :N])
