@@ -18,7 +18,9 @@ $(LIB): $(OBJ)
 	@mkdir -p clip_dplm_amd/lib
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ)
 
-probes: tools/probes/probe_layouts tools/probes/probe_gather tools/probes/probe_store_shapes tools/probes/probe_store_vs_dma
+probes: tools/probes/probe_layouts tools/probes/probe_gather tools/probes/probe_store_shapes tools/probes/probe_store_vs_dma tools/probes/probe_mfma_valu
+tools/probes/probe_mfma_valu: tools/probes/probe_mfma_valu.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-value -o $@ $<
 tools/probes/probe_store_vs_dma: tools/probes/probe_store_vs_dma.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-value -o $@ $<
 # experiment build of the weight-gradient kernel with barrier cycle stamps (tools/exp_wgrad_trace.py)
@@ -34,6 +36,10 @@ tools/probes/libgemm_trace16.so: clip_dplm_amd/csrc/gemm_nt_v3.hip clip_dplm_amd
 	$(HIPCC) $(HIPFLAGS) -DCLIPK_EXPERIMENTS -DCLIPK_GEMM_TRACE -shared -o $@ clip_dplm_amd/csrc/gemm_nt_v3.hip clip_dplm_amd/csrc/core.hip
 tools/probes/libgemm_trace32.so: clip_dplm_amd/csrc/gemm_nt_v3.hip clip_dplm_amd/csrc/core.hip clip_dplm_amd/csrc/common.h clip_dplm_amd/csrc/gemm_epilogue.h
 	$(HIPCC) $(HIPFLAGS) -DCLIPK_EXPERIMENTS -DCLIPK_GEMM_TRACE -DCLIPK_GEMM_MFMA32 -shared -o $@ clip_dplm_amd/csrc/gemm_nt_v3.hip clip_dplm_amd/csrc/core.hip
+# experiment build of the whole library (timing ablations behind option gemm_abl; results garbage):
+#   BENCH_LIB=tools/probes/libclipk_exp.so BENCH_ABL="1 4" python3 tools/bench_kernels.py gemm
+tools/probes/libclipk_exp.so: $(SRC) $(wildcard clip_dplm_amd/csrc/*.h) include/clipk.h
+	$(HIPCC) $(HIPFLAGS) -DCLIPK_EXPERIMENTS -shared -o $@ $(SRC)
 tools/probes/probe_layouts: tools/probes/probe_layouts.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -Wno-unused-value -o $@ $<
 tools/probes/probe_gather: tools/probes/probe_gather.hip
@@ -42,6 +48,6 @@ tools/probes/probe_store_shapes: tools/probes/probe_store_shapes.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -Wno-unused-value -o $@ $<
 
 clean:
-	rm -rf build $(LIB) tools/probes/probe_layouts tools/probes/probe_gather tools/probes/probe_store_shapes tools/probes/probe_store_vs_dma
+	rm -rf build $(LIB) tools/probes/probe_layouts tools/probes/probe_gather tools/probes/probe_store_shapes tools/probes/probe_store_vs_dma tools/probes/probe_mfma_valu
 
 .PHONY: all clean probes

@@ -19,6 +19,7 @@
 
 extern "C" int clipk_gemm_nt_v2_launch(const clipk_gemm_args* a, void* stream);
 extern "C" int clipk_gemm_nt_v3_launch(const clipk_gemm_args* a, void* stream);
+extern "C" int clipk_gemm_nt_v4_launch(const clipk_gemm_args* a, void* stream);
 
 namespace {
 
@@ -276,6 +277,8 @@ static int gemm_nt_one(const clipk_gemm_args* a, void* stream) {
   const long tiles256 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
   const bool v3_ok = (a->K & 31) == 0 && a->K >= 160 && (long)a->M * a->lda * 2 < (1L << 32) &&
                      (long)a->N * a->ldb * 2 < (1L << 32);     // 32-bit buffer offsets
+  //   gemm_nt_v4.hip  persistent 128 x 256 tiles, two 4-wave workgroups per CU (option gemm_kernel = 4 only)
+  if (kmode == 4 && v3_ok && a->M >= 2048) return clipk_gemm_nt_v4_launch(a, stream);
   if (!force_v1 && v3_ok && ((v3mode == 1 && a->M >= 2048) || (v3mode < 0 && tiles256 >= 192)))
     return clipk_gemm_nt_v3_launch(a, stream);
   if (!force_v1 && (a->K & 31) == 0) return clipk_gemm_nt_v2_launch(a, stream);

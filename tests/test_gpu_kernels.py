@@ -51,12 +51,15 @@ def test_gemm_nt_plain(dev, M, N, K):
     assert torch.allclose(c16.float(), ref, rtol=1e-2, atol=1e-2)
 
 
-@pytest.mark.parametrize("kernel,M", [("v2", 384), ("v3", 2304)])
+_GEMM_KERNEL = {"v2": 2, "v3": 3, "v4": 4}      # option gemm_kernel: 128x128 | persistent 256x256 | persistent 128x256 x 2 per CU
+
+
+@pytest.mark.parametrize("kernel,M", [("v2", 384), ("v3", 2304), ("v4", 2304)])
 @pytest.mark.parametrize("act", [None, "relu", "gelu"])
 def test_gemm_nt_epilogue(dev, kopt, act, kernel, M):
     """run-time (generic) epilogue combinations — f32 out + residual + pre-activation, bf16 residual, act' — through
     all three tile structures"""
-    kopt("gemm_kernel", 3 if kernel == "v3" else 2)
+    kopt("gemm_kernel", _GEMM_KERNEL[kernel])
     ops = _ops()
     N, K = 256, 192
     a = _rand((M, K), dev, 3, dtype=torch.bfloat16)
@@ -86,7 +89,7 @@ def test_gemm_nt_epilogue(dev, kopt, act, kernel, M):
     assert torch.allclose(outd, (a.float() @ b.float().t()) * gref, rtol=1e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize("kernel", ["v2", "v3", "v2generic", "v3generic"])
+@pytest.mark.parametrize("kernel", ["v2", "v3", "v4", "v2generic", "v3generic", "v4generic"])
 @pytest.mark.parametrize("M,N,K", [(2048, 256, 128), (2500, 360, 160), (4096, 1440, 480), (2304, 480, 1920),
                                    (3000, 776, 192), (66000, 520, 480), (40000, 1000, 224)])
 def test_gemm_nt_specialised_epilogues(dev, kopt, kernel, M, N, K):
@@ -95,7 +98,7 @@ def test_gemm_nt_specialised_epilogues(dev, kopt, kernel, M, N, K):
     two largest shapes have 774 / 628 output tiles, i.e. every persistent workgroup walks 2-4 tiles: that covers the
     next-tile prefetch under the epilogue and the store-tolerant vmcnt bookkeeping."""
     ops = _ops()
-    kopt("gemm_kernel", 3 if kernel.startswith("v3") else 2)
+    kopt("gemm_kernel", _GEMM_KERNEL[kernel[:2]])
     if kernel.endswith("generic"):
         kopt("gemm_epi_generic", 1)
     a = _rand((M, K), dev, 11, dtype=torch.bfloat16)
@@ -900,7 +903,7 @@ def test_layernorm_meanpool_equals_layernorm_then_pool(dev, B, L, cols, masked, 
     assert torch.allclose(acc_g, dg + 1, rtol=1e-5, atol=1e-6) and torch.allclose(acc_b, db + 1, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("kernel,M", [("v2", 1000), ("v3", 2048 + 24)])
+@pytest.mark.parametrize("kernel,M", [("v2", 1000), ("v3", 2048 + 24), ("v4", 2048 + 24)])
 @pytest.mark.parametrize("H,D", [(3, 64), (4, 32), (8, 16)])
 def test_gemm_nt_rope_epilogue(dev, kopt, kernel, M, H, D):
     """RoPE in the qkv projection's epilogue (EPI_ROPE): q and k thirds rotated on the f32 value (product + bias)
@@ -908,7 +911,7 @@ def test_gemm_nt_rope_epilogue(dev, kopt, kernel, M, H, D):
     Reference: f32 product of the same bf16 operands + rotate-half (transformers modeling_esm.py:48-52,74-79)."""
     import ops_emulator
     ops = _ops()
-    kopt("gemm_kernel", 3 if kernel == "v3" else 2)
+    kopt("gemm_kernel", _GEMM_KERNEL[kernel])
     d, L, K = H * D, 250, 192
     a = _rand((M, K), dev, 91, dtype=torch.bfloat16)
     w = _rand((3 * d, K), dev, 92, 0.08, dtype=torch.bfloat16)

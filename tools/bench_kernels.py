@@ -16,10 +16,13 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get("BENCH_LIB"):          # an experiment build of the library (make tools/probes/libclipk_exp.so)
+    from clip_dplm_amd import _ffi  # noqa: E402
+    _ffi.LIB_PATH = os.path.join(ROOT, os.environ["BENCH_LIB"])
 from clip_dplm_amd import ops  # noqa: E402
 
 DEV = torch.device("cuda:0")
-T = 512 * 256            # tokens per step at B = 512, L = 256
+T = int(os.environ.get("BENCH_BATCH", "512")) * 256      # tokens per step at B = 512 (BENCH_BATCH), L = 256
 
 
 def timeit(fn, iters=5, rounds=5):
@@ -46,6 +49,9 @@ GEMM_SHAPES = [  # (name, M, N, K, epilogue)
     ("esm fc2", T, 480, 1920, "res32"), ("rna qkv", T, 2304, 768, "bias"), ("rna out", T, 768, 768, "res32"),
     ("rna fc1", T, 2048, 768, "gelu+pre"), ("rna fc2", T, 768, 2048, "res32"),
     ("esm d_fc2", T, 1920, 480, "dact"), ("rna d_qkv", T, 768, 2304, "res32"), ("esm d_qkv", T, 480, 1440, "bias"),
+    # round 3: GELU'(u) kept as 8-bit codes (the product path's FFN epilogues)
+    ("esm fc1", T, 1920, 480, "gelu+d8"), ("esm d_fc2", T, 1920, 480, "dact8"),
+    ("rna fc1", T, 2048, 768, "gelu+d8"), ("rna d_fc2", T, 2048, 768, "dact8"),
 ]
 
 
@@ -54,7 +60,8 @@ def bench_gemm():
     specialised straight-line epilogue, 256^2 phase-interleaved kernel (option gemm_kernel = 3).  Arms are dicts of
     libclipk options (ops.set_option); BENCH_NT / BENCH_NWG / BENCH_STAGGER / BENCH_ABL (the last needs a
     -DCLIPK_EXPERIMENTS build) add arms."""
-    arms = [("v2gen", {"gemm_epi_generic": 1, "gemm_kernel": 2}), ("v2", {"gemm_kernel": 2}), ("v3", {"gemm_kernel": 3})]
+    arms = [("v2gen", {"gemm_epi_generic": 1, "gemm_kernel": 2}), ("v2", {"gemm_kernel": 2}), ("v3", {"gemm_kernel": 3}),
+            ("v4", {"gemm_kernel": 4})]
     if os.environ.get("BENCH_NT"):
         arms.append(("v3nt1", {"gemm_kernel": 3, "epi_nt": 1}))
     for ab in os.environ.get("BENCH_ABL", "").split():
@@ -63,8 +70,18 @@ def bench_gemm():
         arms.append(("v3w" + nw, {"gemm_kernel": 3, "gemm_nwg": int(nw)}))
     for st in os.environ.get("BENCH_STAGGER", "").split():
         arms.append(("v3s" + st, {"gemm_kernel": 3, "gemm_stagger": int(st)}))
+    for ab in os.environ.get("BENCH_ABL4", "").split():
+        arms.append(("v4a" + ab, {"gemm_kernel": 4, "gemm_abl": int(ab)}))
+    for nw in os.environ.get("BENCH_NWG4", "").split():          # "256:1" = grid 256 (one workgroup per CU), ablation 1
+        g, _, ab = nw.partition(":")
+        arms.append(("v4w" + nw, {"gemm_kernel": 4, "gemm_nwg": int(g), "gemm_abl": int(ab or 0)}))
+    for st in os.environ.get("BENCH_STAGGER4", "").split():
+        arms.append(("v4s" + st, {"gemm_kernel": 4, "gemm_stagger": int(st)}))
+    if os.environ.get("BENCH_ARMS"):
+        keep = os.environ["BENCH_ARMS"].split()
+        arms = [a for a in arms if a[0] in keep or a[0].startswith(("v4s", "v4a", "v3a", "v4w"))]
     print(f"{'shape':12s} {'M':>7s} {'N':>5s} {'K':>5s} {'epi':9s} | " + " | ".join(f"{n:>5s} us  TF/s" for n, _ in arms)
-          + " | v2/v2gen v3/v2")
+          + " | v2/v2gen v3/v2 v3/v4")
     tot = {n: 0.0 for n, _ in arms}
     for name, M, N, K, epi in GEMM_SHAPES:
         a, b = rnd((M, K)), rnd((N, K), scale=0.05)
@@ -76,6 +93,10 @@ def bench_gemm():
             kw.update(act="gelu", out_preact=True)
         elif epi == "dact":
             kw = {"dact_aux": rnd((M, N)), "dact": "gelu"}
+        elif epi == "gelu+d8":
+            kw.update(act="gelu", out_preact=True, aux_u8=True)
+        elif epi == "dact8":
+            kw = {"dact_aux": torch.randint(0, 256, (M, N), device=DEV, dtype=torch.uint8), "dact": "gelu"}
         out = {}
         for n, opts in arms:
             ops.reset_options()
@@ -87,7 +108,8 @@ def bench_gemm():
         fl = 2.0 * M * N * K
         print(f"{name:12s} {M:7d} {N:5d} {K:5d} {epi:9s} | "
               + " | ".join(f"{out[n] * 1e3:7.1f} {fl / out[n] / 1e9:5.0f}" for n, _ in arms)
-              + f" | {out['v2gen'] / out['v2']:.2f}x {out['v2'] / out['v3']:.2f}x", flush=True)
+              + (f" | {out['v2gen'] / out['v2']:.2f}x {out['v2'] / out['v3']:.2f}x {out['v3'] / out['v4']:.2f}x"
+                 if all(k in out for k in ("v2gen", "v2", "v3", "v4")) else ""), flush=True)
         del a, b, kw
     ops.reset_options()
     print("sum: " + ", ".join(f"{n} {tot[n]:.2f} ms" for n, _ in arms))
