@@ -36,6 +36,9 @@ tools/probes/libgemm_trace16.so: clip_dplm_amd/csrc/gemm_nt_v3.hip clip_dplm_amd
 	$(HIPCC) $(HIPFLAGS) -DCLIPK_EXPERIMENTS -DCLIPK_GEMM_TRACE -shared -o $@ clip_dplm_amd/csrc/gemm_nt_v3.hip clip_dplm_amd/csrc/core.hip
 tools/probes/libgemm_trace32.so: clip_dplm_amd/csrc/gemm_nt_v3.hip clip_dplm_amd/csrc/core.hip clip_dplm_amd/csrc/common.h clip_dplm_amd/csrc/gemm_epilogue.h
 	$(HIPCC) $(HIPFLAGS) -DCLIPK_EXPERIMENTS -DCLIPK_GEMM_TRACE -DCLIPK_GEMM_MFMA32 -shared -o $@ clip_dplm_amd/csrc/gemm_nt_v3.hip clip_dplm_amd/csrc/core.hip
+# experiment build of the attention kernels with phase stamps in the whole-head backward (tools/exp_attn_trace.py)
+tools/probes/libattn_trace.so: clip_dplm_amd/csrc/attention.hip clip_dplm_amd/csrc/core.hip clip_dplm_amd/csrc/common.h
+	$(HIPCC) $(HIPFLAGS) -DCLIPK_ATTN_TRACE -shared -o $@ clip_dplm_amd/csrc/attention.hip clip_dplm_amd/csrc/core.hip
 # experiment build of the whole library (timing ablations behind option gemm_abl; results garbage):
 #   BENCH_LIB=tools/probes/libclipk_exp.so BENCH_ABL="1 4" python3 tools/bench_kernels.py gemm
 tools/probes/libclipk_exp.so: $(SRC) $(wildcard clip_dplm_amd/csrc/*.h) include/clipk.h

@@ -958,12 +958,31 @@ __device__ __forceinline__ bf16x8 tr_frag_off(const char* tile, int off) {
 }
 
 constexpr int FUSED_LMAX = 256;
+#ifdef CLIPK_ATTN_TRACE
+// experiment builds (tools/exp_attn_trace.py): shader-clock stamps (s_memtime) between the phases of the whole-head
+// backward, summed over the heads of workgroup 0 (thread 0) -> cycles per phase and head.  No output depends on them.
+__device__ unsigned long long* g_attn_trace = nullptr;
+// (the sums live in 11 x 8 bytes of LDS behind the kernel's own allocation: the sweep has no registers to spare)
+#define ATTN_STAMP(i)                                                                   \
+  do {                                                                                  \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                         \
+    if (tr_on) atomicAdd(&tr_lds[i], t_ - tr_t);                                        \
+    tr_t = t_;                                                                          \
+  } while (0)
+#else
+#define ATTN_STAMP(i) do { } while (0)
+#endif
 __host__ __device__ constexpr size_t lds_fused(int D) {
   // the bf16 dV image of the epilogue sits behind the dK image inside the dead Q / dO / dS^T region when both fit
   // (D <= 24), behind everything otherwise
   return (size_t)2 * FUSED_LMAX * 64 + 4 * 4096 + (size_t)FUSED_LMAX * (D + 4) * 4 + 2 * FUSED_LMAX * 4 +
          (D > 24 ? (size_t)FUSED_LMAX * 64 : 0);
 }
+#ifdef CLIPK_ATTN_TRACE
+constexpr size_t FUSED_TRACE_LDS = 128;
+#else
+constexpr size_t FUSED_TRACE_LDS = 0;
+#endif
 
 // one head's rows as this thread holds them between the loads and the LDS staging: chunk (tid & 3) of rows
 // (tid >> 2) + (threads / 4) * pass of K, V, Q, dO and O, this thread's lse and the mask bytes of its key columns
@@ -1058,12 +1077,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
   Regs R;
   int w = blockIdx.x;
   if (w < nheads) issue(w, R);
+#ifdef CLIPK_ATTN_TRACE
+  const bool tr_on = blockIdx.x == 0 && tid == 0 && g_attn_trace != nullptr;
+  unsigned long long* tr_lds = reinterpret_cast<unsigned long long*>(smem + lds_fused(D));
+  if (tid < 16) tr_lds[tid] = 0;
+  __syncthreads();
+  unsigned long long tr_t = __builtin_amdgcn_s_memtime();
+  const unsigned long long tr_r0 = __builtin_amdgcn_s_memrealtime(), tr_c0 = tr_t;
+#endif
 
   for (; w < nheads; w += gridDim.x) {
     int blk, h, b;
     work_item_at(w, 1, H, p.B, blk, h, b);
     int L = p.L;
     const long row0 = seq_rows(p, b, L);
+    ATTN_STAMP(7);                                         // (loop bookkeeping)
     if (L <= 0) {                                          // (workgroup-uniform) empty sequence of a packed batch
       issue(w + (int)gridDim.x < nheads ? w + (int)gridDim.x : w, R);
       continue;
@@ -1099,6 +1127,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
     if (tid < LQ)
       for (int i = 0; i < ILD; i += 4) *reinterpret_cast<f32x4*>(img + tid * ILD + i) = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
+    ATTN_STAMP(0);                                         // wait for the prefetched rows + K / V staging + delta + image zero
 
     bf16x8 kf[KTW], vf[KTW], ktf[DT][NCK];
     float kbias[KTW];
@@ -1122,6 +1151,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
     // under the sweep.  (Unconditional, see below; the last head of a workgroup re-requests its own rows.)
     if constexpr (NW == 8) issue(w + (int)gridDim.x < nheads ? w + (int)gridDim.x : w, R);
     __syncthreads();
+    ATTN_STAMP(1);                                         // fragments + Q / dO staging
 
     f32x4 dk[DT][KTW], dv[DT][KTW];
 #pragma unroll
@@ -1220,9 +1250,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
     // nobody consumes - because a branch here makes the compiler wait for vmcnt(0) at the first use of the tables
     // (on the not-taken path they are the youngest loads), which waits for the whole prefetch as well.
     // (Eight waves: the rows were requested before the sweep and have landed; the tables simply come now.)
+    ATTN_STAMP(2);                                         // the sweep
     RopeRow<D> T;
     if (ROPE) load_rope_row<D>(T, p.cosT, p.sinT, tq < L ? tq : L - 1);
     if constexpr (NW == 4) issue(w + (int)gridDim.x < nheads ? w + (int)gridDim.x : w, R);
+    ATTN_STAMP(3);                                         // issuing the next head's loads
 
     // ---- dQ rows from the image; dK~ (f32, RoPE^T wants f32 pairs) and dV (bf16) through images over the now dead
     // Q / dO / dS^T region
@@ -1241,6 +1273,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
           *reinterpret_cast<u32x2*>(dvimg + key * 64 + d * 2) = wv;
         }
     __syncthreads();
+    ATTN_STAMP(4);                                         // dK / dV images + barrier
     if (tq < L) {
       unsigned short* dqrow = p.dqkv + row0 * tokstride + (long)h * D + (unsigned int)tq * (unsigned int)tokstride;
       store_grad_row<ROPE, D>(img + tq * ILD, dqrow, T, p.scale);            // q_scale: once per element, here
@@ -1249,9 +1282,28 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
       for (int c = 0; c < cpr; ++c)
         *reinterpret_cast<u32x4*>(dqrow + 2 * H * D + 8 * c) = *reinterpret_cast<const u32x4*>(dvimg + tq * 64 + 16 * c);
     }
+    ATTN_STAMP(5);                                         // gradient rows: image reads, RoPE^T, stores issued
     __syncthreads();                                       // the images are read; the next head may stage over them
+    ATTN_STAMP(6);                                         // the closing barrier
+#ifdef CLIPK_ATTN_TRACE
+    if (tr_on) atomicAdd(&tr_lds[8], 1ull);
+#endif
   }
+#ifdef CLIPK_ATTN_TRACE
+  if (tr_on) {
+    for (int i = 0; i < 9; ++i) g_attn_trace[i] = tr_lds[i];
+    g_attn_trace[9] = __builtin_amdgcn_s_memtime() - tr_c0;
+    g_attn_trace[10] = __builtin_amdgcn_s_memrealtime() - tr_r0;
+  }
+#endif
 }
+#ifdef CLIPK_ATTN_TRACE
+}  // namespace
+extern "C" int clipk_attn_set_trace(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+namespace {
+#endif
 
 // =================================================================================================
 // backward, whole head in one workgroup, head dim 96 (the 6 x 768 RNA encoder: 8 heads of 96), 128 < L <= 256, rows
@@ -1845,7 +1897,7 @@ int launch_fwd(const AP& p, hipStream_t st) {
 
 template <bool ROPE, int D, int NW>
 void launch_fused_nw(const AP& p, hipStream_t st) {
-  constexpr size_t lds = lds_fused(D);
+  constexpr size_t lds = lds_fused(D) + FUSED_TRACE_LDS;
   static std::atomic<uint64_t> attr_set{0};
   clipk_once_per_device(attr_set, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused32_kernel<ROPE, D, NW>),
