@@ -962,6 +962,7 @@ constexpr int FUSED_LMAX = 256;
 // experiment builds (tools/exp_attn_trace.py): shader-clock stamps (s_memtime) between the phases of the whole-head
 // backward, summed over the heads of workgroup 0 (thread 0) -> cycles per phase and head.  No output depends on them.
 __device__ unsigned long long* g_attn_trace = nullptr;
+__device__ int g_attn_stagger = 0;       // experiment: the second workgroup of each CU starts this x ~3.9 us late
 // (the sums live in 11 x 8 bytes of LDS behind the kernel's own allocation: the sweep has no registers to spare)
 #define ATTN_STAMP(i)                                                                   \
   do {                                                                                  \
@@ -1082,6 +1083,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
   unsigned long long* tr_lds = reinterpret_cast<unsigned long long*>(smem + lds_fused(D));
   if (tid < 16) tr_lds[tid] = 0;
   __syncthreads();
+  if (g_attn_stagger > 0 && (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 0xF) != 0)     // HW_REG_HW_ID[3:0]: wave slot in the SIMD
+    for (int i = 0; i < g_attn_stagger; ++i) __builtin_amdgcn_s_sleep(127);
   unsigned long long tr_t = __builtin_amdgcn_s_memtime();
   const unsigned long long tr_r0 = __builtin_amdgcn_s_memrealtime(), tr_c0 = tr_t;
 #endif
@@ -1301,6 +1304,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
 }  // namespace
 extern "C" int clipk_attn_set_trace(void* buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+extern "C" int clipk_attn_set_stagger(int n) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stagger), &n, sizeof(n)) == hipSuccess ? 0 : -1;
 }
 namespace {
 #endif

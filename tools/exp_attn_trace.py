@@ -49,18 +49,31 @@ ref = ops.attn_bwd(qkv, out, dout, lse, B, L, H, D, rope=(cos, sin), q_scale=D *
 ref = ref[0] if isinstance(ref, (tuple, list)) else ref
 assert torch.equal(ref, dqkv), "the traced build must produce the product's gradients"
 assert lib.clipk_attn_set_trace(trace.data_ptr()) == 0
-s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 N = 20
-acc = torch.zeros(16, dtype=torch.float64)
-s.record()
-for _ in range(N):
-    launch()
-    torch.cuda.synchronize()
-    acc += trace.cpu().double()
-e.record()
-torch.cuda.synchronize()
+
+
+def traced(stagger):
+    lib.clipk_attn_set_stagger(stagger)
+    acc = torch.zeros(16, dtype=torch.float64)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    us = 0.0
+    for _ in range(N):
+        s.record()
+        launch()
+        e.record()
+        torch.cuda.synchronize()
+        us += s.elapsed_time(e) * 1e3 / N
+        acc += trace.cpu().double()
+    return (acc / N).tolist(), us
+
+
+# experiment: the second workgroup of every CU (by hardware wave slot) starts k x ~3.9 us late
+for k in [int(v) for v in os.environ.get("EXP_STAGGER", "").split()]:
+    tt, us = traced(k)
+    print(f"  start offset {k} x 3.9 us: {us:7.1f} us per launch; workgroup 0: {tt[9] / tt[8]:.0f} cycles per head, sweep {tt[2] / tt[8]:.0f}")
+t, us0 = traced(0)
 lib.clipk_attn_set_trace(None)
-t = (acc / N).tolist()
+print(f"  no offset: {us0:7.1f} us per launch")
 heads, cyc, ticks = t[8], t[9], t[10]
 ghz = cyc / max(ticks, 1) * 0.1
 names = ["wait for the prefetched rows + K/V staging + delta + dQ image zero (to the 1st barrier)",
