@@ -283,7 +283,7 @@ def test_large_tile_kernels_agree_with_small_tile_kernels_in_the_model(dev, kopt
     ids = torch.randint(4, 24, (B, L), generator=g).to(dev)
     rna = torch.randn(B, L, 768, generator=g).to(dev)
     res = {}
-    for tag, v in (("small", 2), ("large", 3)):
+    for tag, v in (("small", 2), ("large", 3), ("two_per_cu", 4)):       # 4: gemm_nt_v4 (+ the pipelined wgrad schedule)
         kopt("gemm_kernel", v)
         kopt("wgrad_kernel", v)
         m.zero_grad(set_to_none=True)
@@ -291,6 +291,7 @@ def test_large_tile_kernels_agree_with_small_tile_kernels_in_the_model(dev, kopt
         loss.backward()
         res[tag] = (loss.item(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
     assert abs(res["small"][0] - res["large"][0]) < 2e-4, (res["small"][0], res["large"][0])
+    assert abs(res["small"][0] - res["two_per_cu"][0]) < 2e-4, (res["small"][0], res["two_per_cu"][0])
     # and the large-tile path against the CPU oracle directly (loss bar 1e-3, as everywhere)
     from oracle import clip_ref, encoder_ref
     sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
@@ -303,12 +304,13 @@ def test_large_tile_kernels_agree_with_small_tile_kernels_in_the_model(dev, kopt
     ep = clip_ref.l2_normalize(clip_ref.projection_head(encoder_ref.pool(hp, ones, "mean"), sd, "protein_projection"))
     ref = clip_ref.clip_loss_symmetric((er @ ep.t()) * sd["logit_scale"].exp()).item()
     assert abs(res["large"][0] - ref) < 1e-3, (res["large"][0], ref)
-    for n, ga in res["small"][1].items():
-        gb = res["large"][1][n]
-        if ga.abs().max() < 1e-12:
-            continue
-        cos = torch.nn.functional.cosine_similarity(ga.flatten().double(), gb.flatten().double(), dim=0).item()
-        assert cos > 0.9999, (n, cos)
+    for other in ("large", "two_per_cu"):
+        for n, ga in res["small"][1].items():
+            gb = res[other][1][n]
+            if ga.abs().max() < 1e-12:
+                continue
+            cos = torch.nn.functional.cosine_similarity(ga.flatten().double(), gb.flatten().double(), dim=0).item()
+            assert cos > 0.9999, (other, n, cos)
 
 
 def test_fused_adamw_training_reduces_loss(dev):
