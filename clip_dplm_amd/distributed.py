@@ -22,6 +22,12 @@ def init_distributed(backend: str | None = None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_gpu = torch.cuda.is_available()
+    # Rehearsal on a box with fewer GPUs than ranks (CLIPK_REHEARSE_ONE_GPU=1, tests / tools only): every rank on cuda:0
+    # and gloo as the transport (RCCL refuses two ranks on one device).  Same kernels, same rank bookkeeping.
+    rehearse = (use_gpu and world > 1 and os.environ.get("CLIPK_REHEARSE_ONE_GPU") == "1"
+                and torch.cuda.device_count() < world)
+    if rehearse:
+        local, backend = 0, "gloo"
     device = torch.device(f"cuda:{local}") if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(device)
@@ -29,8 +35,9 @@ def init_distributed(backend: str | None = None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend=backend or ("nccl" if use_gpu else "gloo"), rank=rank, world_size=world,
-                                device_id=device if use_gpu else None)
+        be = backend or ("nccl" if use_gpu else "gloo")
+        dist.init_process_group(backend=be, rank=rank, world_size=world,
+                                device_id=device if (use_gpu and be == "nccl") else None)
     return rank, world, device
 
 
