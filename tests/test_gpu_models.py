@@ -887,3 +887,37 @@ def test_protein_rna_clip_from_config_runs(dev):
     assert torch.equal(la, lb)
     la.backward()
     assert all(torch.isfinite(p.grad).all() for p in a.parameters() if p.grad is not None)
+
+
+def test_training_with_8bit_gelu_codes_tracks_training_with_the_bf16_preactivation(dev, monkeypatch):
+    """The FFN keeps GELU'(u) as 8-bit codes for its backward (encoders.GELU_AUX_U8, clipk.h aux_dtype) instead of the
+    bf16 pre-activation.  The forward value is the same; the gradients differ by the code's rounding (<= 0.0025 on a factor
+    in [-0.13, 1.13], no bias).  Eight optimiser steps of the same model on the same batch with either format: identical
+    first loss, both going down, trajectories within 3e-3 of each other (AdamW turns ANY gradient perturbation into a
+    step of size ~lr on near-zero-gradient entries, so the comparison is made at a small learning rate and over few steps;
+    at lr = 2e-3 the two runs drift apart by 0.05 within six steps, as two summation orders would)."""
+    import clip_dplm_amd as K
+    from clip_dplm_amd import encoders
+    from clip_dplm_amd.encoders import ESM2_SHAPES
+    ESM2_SHAPES["test_aux"] = (2, 96, 4, 384)
+    B, L = 48, 64
+    g = torch.Generator().manual_seed(11)
+    ids = torch.randint(4, 24, (B, L), generator=g).to(dev)
+    rna = torch.randn(B, L, 64, generator=g).to(dev)
+    traj = {}
+    for u8 in (True, False):
+        monkeypatch.setattr(encoders, "GELU_AUX_U8", u8)
+        torch.manual_seed(0)
+        m = K.ProteinRNACLIP(esm="test_aux", rna_dim=64, rna_layers=2, rna_heads=8, rna_ffn=256, projection_dim=64).to(dev)
+        opt = K.FusedAdamW(m, lr=3e-4, weight_decay=0.01, max_grad_norm=1.0)
+        losses = []
+        for _ in range(8):
+            opt.zero_grad()
+            loss = m.loss(rna, ids)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        traj[u8] = losses
+    assert traj[True][0] == traj[False][0]                      # same forward
+    assert traj[True][-1] < traj[True][0] - 0.02 and traj[False][-1] < traj[False][0] - 0.02, (traj[True], traj[False])
+    assert max(abs(a - b) for a, b in zip(traj[True], traj[False])) < 3e-3, (traj[True], traj[False])
