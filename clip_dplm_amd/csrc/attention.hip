@@ -1643,6 +1643,332 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused96_kernel(const AP p) {
 }
 
 // =================================================================================================
+// The same backward with EIGHT waves (two per SIMD, 256 registers each): a wave owns 32 keys - half the fragments and
+// accumulators (144 resident registers instead of 288) - so that the second wave of a SIMD fills the first one's
+// dependency stalls (the 4-wave kernel keeps a SIMD 0.41 busy: one wave, every LDS / MFMA latency exposed).  The price
+// is LDS traffic: every wave reads the Q / dO fragments of the whole 32-query block for its 32 keys (twice the reads
+// per key) and there are eight dQ shares to add.  The shares meet pairwise: waves 4-7 run their dQ product FIRST and
+// write their shares, waves 0-3 run dV / dK first, then - after a barrier - their dQ product, add their partner's
+// share (the wave four above, the one they share a SIMD with) and write the pair's sum over it; all 512 threads add
+// the four pair sums in a fixed order.  Same LDS footprint as the 4-wave kernel, three barriers per step instead of
+// two, bitwise reproducible.  Everything else (staging, prefetch of the next head, write-out) as above.
+// Option attn_fused_waves = 8 selects it.  Measured (B = 1024, L = 256, profiles/r03/attn96_eight_waves_ab_v1.txt): 1173 us
+// against 1140 us for the 4-wave kernel - the second wave does not pay: at 256 registers the K fragments had to move to
+// LDS reads (resident they cost 150 / 59 spilled registers, each reload a vmcnt(0) inside the sweep: 2711 / 1292 us), and
+// the head's memory phases - K / V fragments and rows in, dK / dV rows out, ~12 of the ~36 us per head at the CU's share
+// of HBM - are the same in both kernels and overlap nothing in either.  Kept for A/B and as a test of the 4-wave one.
+// =================================================================================================
+__global__ __launch_bounds__(512, 1) void attn_bwd_fused96w8_kernel(const AP p) {
+  constexpr int D = 96, RS = Geo<96>::RS, KS = 3, DT = 6, NCH = 12, LQ = FUSED_LMAX, QB = F96_QB, ILD = D + 4;
+  constexpr int NT = 512, KTW = 2, KW = 32;                // per wave: two 16-key tiles = one 32-key chunk
+  constexpr int NKP = LQ * NCH / NT;                       // K-row chunk tasks per thread (6)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ktile = smem;                                      // [256][RS] K rows (transposed fragments); later dK / dV images
+  float* share = reinterpret_cast<float*>(smem + LQ * RS); // [4 wave pairs][32 q][ILD] f32
+  char* qd = smem + LQ * RS + 4 * QB * ILD * 4;            // [2 buffers][Q block | dO block][32][RS]
+  char* dst_all = qd + 4 * QB * RS;                        // [8 waves][32 keys][64 B]
+  float* lse_l = reinterpret_cast<float*>(dst_all + 4 * 4096);   // [256] lse * log2(e); +inf past the end
+  float* dl_l = lse_l + LQ;                                // [256] -delta
+  float* part = dl_l + LQ;                                 // [32][12] delta shares of the block being staged
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int H = p.H;
+  const long tokstride = 3L * H * D, ostride = (long)H * D;
+  const unsigned int HD = (unsigned int)(H * D);
+  const float c2 = p.scale * LOG2E;
+  const int nheads = p.B * H;
+
+  const unsigned short *lq = nullptr, *ldo = nullptr, *lo = nullptr;
+  int lL = 1;
+  auto point_at = [&](int w, int& L_, long& row0_, int& b_, int& h_) {
+    int blk_;
+    work_item_at(w, 1, H, p.B, blk_, h_, b_);
+    L_ = p.L;
+    row0_ = seq_rows(p, b_, L_);
+  };
+  // Q / dO / O block staging: 32 rows x 12 chunks = 384 (row, chunk) tasks per tensor, one per thread (threads >= 384
+  // repeat a task; their stores are skipped)
+  u32x4 cq, cd, co;
+  auto issue_block = [&](int j) {
+    const int t = tid + opaque_zero();
+    const int idl = t < QB * NCH ? t : t - 256;
+    const int r = idl / NCH, ch = idl - r * NCH;
+    int row = j * QB + r; row = row < lL ? row : lL - 1;
+    cq = *reinterpret_cast<const u32x4*>(lq + ((unsigned int)row * 3u * HD + 8u * ch));
+    cd = *reinterpret_cast<const u32x4*>(ldo + ((unsigned int)row * HD + 8u * ch));
+    co = *reinterpret_cast<const u32x4*>(lo + ((unsigned int)row * HD + 8u * ch));
+  };
+  auto store_block = [&](int j) {                          // -> buffer j & 1, delta shares -> part
+    const int t = tid + opaque_zero();
+    char* qt = qd + (j & 1) * (2 * QB * RS);
+    if (t < QB * NCH) {
+      const int r = t / NCH, ch = t - r * NCH;
+      *reinterpret_cast<u32x4*>(qt + r * RS + ch * 16) = cq;
+      *reinterpret_cast<u32x4*>(qt + QB * RS + r * RS + ch * 16) = cd;
+      float acc = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc += bf16_to_f32(co[e] & 0xffffu) * bf16_to_f32(cd[e] & 0xffffu);
+        acc += bf16_to_f32(co[e] >> 16) * bf16_to_f32(cd[e] >> 16);
+      }
+      part[t] = acc;
+    }
+  };
+  bf16x8 vf[KTW][KS];
+  float kbias[KTW], lse_r;
+  auto issue_head = [&](int w) {                           // sets lq / ldo / lo / lL to head w and requests its rows
+    int L_, b_, h_;
+    long row0_;
+    point_at(w, L_, row0_, b_, h_);
+    if (L_ <= 0) { L_ = 1; row0_ = row0_ > 0 ? row0_ - 1 : 0; }   // empty sequence: an in-range dummy row, never used
+    lL = L_;
+    lq = p.qkv + row0_ * tokstride + (long)h_ * D;
+    ldo = p.dout + row0_ * ostride + (long)h_ * D;
+    lo = p.out + row0_ * ostride + (long)h_ * D;
+#pragma unroll
+    for (int kt = 0; kt < KTW; ++kt) {
+      const int key = wid * KW + kt * 16 + li;
+      const int row = key < L_ ? key : L_ - 1;
+      kbias[kt] = (key < L_ && (!p.key_mask || p.key_mask[row0_ + row])) ? 0.f : -INFINITY;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const unsigned int off = (unsigned int)row * 3u * HD + (unsigned int)(ks * 32 + g * 8);
+        vf[kt][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lq + (off + 2u * HD)));
+      }
+    }
+    const int lr = tid < LQ ? tid : LQ - 1;
+    lse_r = p.lse[stat_at(p, b_, h_, H, L_, row0_, lr < L_ ? lr : L_ - 1)];
+    issue_block(0);
+  };
+
+  const int trow = 4 * g + (li >> 2), tcolb = 8 * (li & 3);
+  char* dst = dst_all + wid * 2048;
+  int off_dw[2];                                           // dS^T write: key row li of a 16-key tile, queries qq*16 + 4g ..
+#pragma unroll
+  for (int qq = 0; qq < 2; ++qq) off_dw[qq] = swz64(li, qq * 2 + (g >> 1)) + 8 * (g & 1);
+  const bool lower = wid < 4;                              // (wave-uniform) waves 0-3 add their partner's share
+  float* sh = share + (wid & 3) * (QB * ILD);              // the pair's slot
+
+  int w = blockIdx.x;
+  if (w < nheads) issue_head(w);
+  for (; w < nheads; w += gridDim.x) {
+    int L, b, h;
+    long row0;
+    point_at(w, L, row0, b, h);
+    const int wnext = w + (int)gridDim.x < nheads ? w + (int)gridDim.x : w;   // last head: re-request its own rows
+    if (L <= 0) {                                          // (workgroup-uniform) empty sequence of a packed batch
+      issue_head(wnext);
+      continue;
+    }
+    const int nblk = (L + QB - 1) / QB;
+    const auto finish_delta = [&](int j) {                 // after the barrier that follows store_block(j)
+      if (tid < QB) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) acc += part[tid * NCH + c];
+        const int q = j * QB + tid;
+        const bool ok = q < L;
+        dl_l[q] = ok ? -acc : 0.f;                         // NEGATED: the dP accumulators start from it
+        if (ok) p.delta[stat_at(p, b, h, H, L, row0, q)] = acc;
+      }
+    };
+    // ---- K rows -> LDS for the transposed fragments, block 0 -> buffer 0, lse
+    {
+      const int t = tid + opaque_zero();
+      const unsigned short* kb_ = p.qkv + row0 * tokstride + (long)h * D + HD;
+      u32x4 kr[NKP];
+#pragma unroll
+      for (int ps = 0; ps < NKP; ++ps) {
+        const int idl = ps * NT + t;
+        const int r = idl / NCH, ch = idl - r * NCH;
+        kr[ps] = *reinterpret_cast<const u32x4*>(kb_ + ((unsigned int)(r < L ? r : L - 1) * 3u * HD + 8u * ch));
+      }
+#pragma unroll
+      for (int ps = 0; ps < NKP; ++ps) {
+        const int idl = ps * NT + t;
+        const int r = idl / NCH, ch = idl - r * NCH;
+        *reinterpret_cast<u32x4*>(ktile + r * RS + ch * 16) = kr[ps];
+      }
+    }
+    if (tid < LQ) lse_l[tid] = tid < L ? lse_r * LOG2E : INFINITY;       // p = 2^-inf = 0 past the end
+    store_block(0);
+    __syncthreads();
+    finish_delta(0);
+    __syncthreads();
+
+    f32x4 dk[DT][KTW], dv[DT][KTW];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int kt = 0; kt < KTW; ++kt) { dk[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt][kt] = dk[dt][kt]; }
+    const bool wave_live = wid * KW < L;                   // this wave owns at least one real key
+    unsigned short* dqb = p.dqkv + row0 * tokstride + (long)h * D;
+
+#pragma unroll 1
+    for (int j = 0; j < nblk; ++j) {
+      // UNCONDITIONAL (the last step re-requests its own block and stages it into the idle buffer): with `if (j + 1 <
+      // nblk)` around the request and around the staging hipcc cannot pair the two branches, assumes the loads may
+      // still be in flight at the next request and waits vmcnt(0) there - for the block it has just asked for
+      issue_block(j + 1 < nblk ? j + 1 : j);
+      const char* qt_ = qd + (j & 1) * (2 * QB * RS);
+      const char* dt_ = qt_ + QB * RS;
+      u32x2 pk[2][KTW], dsk[2][KTW];
+      if (wave_live) {
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+          const f32x4 nd = *reinterpret_cast<const f32x4*>(dl_l + j * QB + qq * 16 + 4 * g);
+          f32x4 s[KTW], dp[KTW];
+#pragma unroll
+          for (int kt = 0; kt < KTW; ++kt) { s[kt] = f32x4{kbias[kt], kbias[kt], kbias[kt], kbias[kt]}; dp[kt] = nd; }
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 qa = row_frag(qt_, RS, qq * 16 + li, ks, lane);
+            const bf16x8 da = row_frag(dt_, RS, qq * 16 + li, ks, lane);
+#pragma unroll
+            for (int kt = 0; kt < KTW; ++kt) {
+              s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, row_frag(ktile, RS, wid * KW + kt * 16 + li, ks, lane), s[kt], 0, 0, 0);
+              dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kt][ks], dp[kt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);             // (fragments of one k-step at a time: the SIMD's other wave hides the reads)
+          }
+          const f32x4 ls = *reinterpret_cast<const f32x4*>(lse_l + j * QB + qq * 16 + 4 * g);
+#pragma unroll
+          for (int kt = 0; kt < KTW; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float pv = fast_exp2(s[kt][r] * c2 - ls[r]);
+              s[kt][r] = pv;                               // P
+              dp[kt][r] = pv * dp[kt][r];                  // dS = P (dP - delta)
+            }
+            pk[qq][kt] = u32x2{pack_bf16x2(s[kt][0], s[kt][1]), pack_bf16x2(s[kt][2], s[kt][3])};
+            dsk[qq][kt] = u32x2{pack_bf16x2(dp[kt][0], dp[kt][1]), pack_bf16x2(dp[kt][2], dp[kt][3])};
+          }
+          __builtin_amdgcn_sched_barrier(0);               // one 16-query tile at a time: the second one's 16 accumulator
+        }                                                  // registers reuse the first one's
+        // dS^T -> the wave's private [32 keys][32 queries] tile
+#pragma unroll
+        for (int kt = 0; kt < KTW; ++kt)
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq)
+            *reinterpret_cast<u32x2*>(dst + kt * 1024 + off_dw[qq]) = dsk[qq][kt];
+      }
+      // dV^T[d][key] += dO^T[d][32 q] P[32 q][key], dK^T += Q^T dS
+      const auto dvdk = [&]() {
+        if (wave_live) {
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const bf16x8 dot_f = tr_frag(dt_, RS, trow, dt * 32 + tcolb);     // dO^T[d tile][32 q]
+            const bf16x8 qt_f = tr_frag(qt_, RS, trow, dt * 32 + tcolb);      // Q^T
+#pragma unroll
+            for (int kt = 0; kt < KTW; ++kt) {
+              const bf16x8 pbf = __builtin_bit_cast(bf16x8, u32x4{pk[0][kt][0], pk[0][kt][1], pk[1][kt][0], pk[1][kt][1]});
+              const bf16x8 dsf = __builtin_bit_cast(bf16x8, u32x4{dsk[0][kt][0], dsk[0][kt][1], dsk[1][kt][0], dsk[1][kt][1]});
+              dv[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_f, pbf, dv[dt][kt], 0, 0, 0);
+              dk[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_f, dsf, dk[dt][kt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      };
+      __builtin_amdgcn_sched_barrier(0);
+      dvdk();
+      __builtin_amdgcn_sched_barrier(0);
+      // dQ^T[d][q] = K^T[d][this wave's 32 keys] dS^T[32 keys][q] for both 16-query tiles, kept in registers: the upper
+      // waves write theirs to the pair's slot, the lower ones add their partner's after the barrier and write the sum
+      // back.  (ONE instruction stream for both halves: with the halves running dV / dK and dQ in opposite orders hipcc
+      // spilled 150 registers, the K / V fragments among them, and every reload inside the sweep is a vmcnt(0).)
+      f32x4 dq[2][DT];
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) dq[qq][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (wave_live) {
+          const bf16x8 dsb = tr_frag_off(dst, swz64(trow, qq * 2 + ((li & 3) >> 1)) + 8 * (li & 1));
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const bf16x8 ktf = tr_frag(ktile, RS, wid * KW + trow, dt * 32 + tcolb);
+            dq[qq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsb, dq[qq][dt], 0, 0, 0);
+          }
+        }
+      }
+      if (!lower) {
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt)
+            *reinterpret_cast<f32x4*>(sh + (qq * 16 + li) * ILD + dt * 16 + 4 * g) = dq[qq][dt];
+      }
+      __syncthreads();                                     // the upper waves' shares are in the slots
+      if (lower) {
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            float* at = sh + (qq * 16 + li) * ILD + dt * 16 + 4 * g;
+            *reinterpret_cast<f32x4*>(at) = *reinterpret_cast<const f32x4*>(at) + dq[qq][dt];
+          }
+      }
+      store_block(j + 1);                                  // the other buffer
+      __syncthreads();
+      // ---- sum the four pair sums in slot order, scale, round, store: thread t < 384 -> query t / 12, 8 head dims
+      if (tid < QB * NCH) {
+        const int r = tid / NCH, c0 = (tid - r * NCH) * 8;
+        f32x4 a[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(share + r * ILD + c0 + 4 * i);
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) a[i] += *reinterpret_cast<const f32x4*>(share + ww * (QB * ILD) + r * ILD + c0 + 4 * i);
+        const int q = j * QB + r;
+        if (q < L) {
+          u32x4 w4;
+          w4[0] = pack_bf16x2(a[0][0] * p.scale, a[0][1] * p.scale);
+          w4[1] = pack_bf16x2(a[0][2] * p.scale, a[0][3] * p.scale);
+          w4[2] = pack_bf16x2(a[1][0] * p.scale, a[1][1] * p.scale);
+          w4[3] = pack_bf16x2(a[1][2] * p.scale, a[1][3] * p.scale);
+          *reinterpret_cast<u32x4*>(dqb + (unsigned int)q * 3u * HD + c0) = w4;
+        }
+      }
+      if (j + 1 < nblk) finish_delta(j + 1);
+      __syncthreads();
+    }
+
+    // ---- the next head's rows: K / V fragment registers are free now; they land under the write-out below
+    issue_head(wnext);
+
+    // ---- dK^T (x scale) and dV^T accumulators -> bf16 [key][d] images (one after the other, over the K rows) -> rows
+#pragma unroll 1
+    for (int which = 0; which < 2; ++which) {
+#pragma unroll
+      for (int kt = 0; kt < KTW; ++kt)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const f32x4 v = which == 0 ? dk[dt][kt] * p.scale : dv[dt][kt];
+          u32x2 wv;
+          wv[0] = pack_bf16x2(v[0], v[1]);
+          wv[1] = pack_bf16x2(v[2], v[3]);
+          *reinterpret_cast<u32x2*>(ktile + (wid * KW + kt * 16 + li) * RS + (dt * 16 + 4 * g) * 2) = wv;
+        }
+      __syncthreads();
+      {
+        const int t = tid + opaque_zero();
+#pragma unroll
+        for (int ps = 0; ps < NKP; ++ps) {
+          const int idl = ps * NT + t;
+          const int r = idl / NCH, ch = idl - r * NCH;
+          if (r < L)
+            *reinterpret_cast<u32x4*>(dqb + ((unsigned int)r * 3u * HD + (unsigned int)(which + 1) * HD + 8u * ch)) =
+                *reinterpret_cast<const u32x4*>(ktile + r * RS + ch * 16);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// =================================================================================================
 // forward, whole head in one workgroup (head dim <= 32, 128 < L <= 256, rows that need no rotation): all 256 K and V
 // rows are staged ONCE per head (the general kernel's two 128-query workgroups each stage all of them) and stay in
 // LDS while the four waves take two passes of 32 queries each.  Same tiles, same 64-key sub-block order and the
@@ -1928,6 +2254,12 @@ inline void launch_fused96(const AP& p, hipStream_t st) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused96_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int nheads = p.B * p.H, cus = attn_cu_count();
+  if (clipk_opt_get(OPT_ATTN_FUSED_WAVES) == 8) {             // eight waves, 32 keys each (same LDS footprint)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused96w8_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attn_bwd_fused96w8_kernel, dim3(nheads < cus ? nheads : cus), dim3(512), lds, st, p);
+    return;
+  }
   hipLaunchKernelGGL(attn_bwd_fused96_kernel, dim3(nheads < cus ? nheads : cus), dim3(256), lds, st, p);
 }
 

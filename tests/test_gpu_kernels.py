@@ -483,12 +483,15 @@ def test_attention_bwd_whole_head_vs_two_kernel(dev, B, L, H, D, use_rope, waves
     assert (g1 - g2).abs().max().item() / denom < 8e-3       # one bf16 ulp of the largest gradient
 
 
+@pytest.mark.parametrize("waves", [4, 8])
 @pytest.mark.parametrize("B,L,H", [(8, 256, 8), (3, 190, 4), (2, 129, 2), (5, 255, 3), (1, 256, 1), (16, 233, 8)])
-def test_attention_bwd_whole_head_hd96_vs_two_kernel(dev, B, L, H, kopt):
+def test_attention_bwd_whole_head_hd96_vs_two_kernel(dev, B, L, H, waves, kopt):
     """The whole-head backward for the RNA encoder's heads (hd 96, 128 < L <= 256: one workgroup per head, every operand
     read once, 5 products) against the dQ + dK/dV pair and against f32 autograd: ragged lengths + key padding, the
-    delta = rowsum(dO * O) side output, bitwise reproducibility."""
+    delta = rowsum(dO * O) side output, bitwise reproducibility.  waves: four waves of 64 keys or eight of 32
+    (option attn_fused_waves)."""
     ops = _ops()
+    kopt("attn_fused_waves", waves)
     D = 96
     qkv = _rand((B * L, 3 * H * D), dev, 170, 1.0, dtype=torch.bfloat16)
     dout = _rand((B * L, H * D), dev, 171, 1.0, dtype=torch.bfloat16)
@@ -730,11 +733,13 @@ def test_attention_varlen_equals_padded_with_mask(dev, H, D, use_rope, lens):
     assert (gk.float() - gr).abs().max().item() < 8e-3 * max(1.0, gr.abs().max().item())
 
 
+@pytest.mark.parametrize("waves", [4, 8])
 @pytest.mark.parametrize("H,lens", [(8, [256, 131, 40, 200, 1, 129]), (2, [255, 64, 256])])
-def test_attention_varlen_whole_head_hd96(dev, kopt, H, lens):
+def test_attention_varlen_whole_head_hd96(dev, kopt, H, lens, waves):
     """Packed batches whose longest sequence fits the hd-96 whole-head backward (one workgroup per (sequence, head), rows
     and length from cu_seqlens) against the general varlen kernels."""
     ops = _ops()
+    kopt("attn_fused_waves", waves)
     D = 96
     B, Lm, T = len(lens), max(lens), sum(lens)
     g = torch.Generator().manual_seed(T + D)
