@@ -40,6 +40,7 @@ struct AP {
   const unsigned short* dout; float* delta; unsigned short* dqkv;
   int B, L, H, D;
   float scale;
+  int row_stores;   // whole-head kernels: 1 = gradient / rotated rows leave four lanes to a row from LDS, 0 = one thread per row
   int pre_rot;      // backward: q / k in `qkv` are already rotated (clipk_rope_qk): stage them as they are, the
                     // gradients still leave through RoPE^T
   // packed variable-length batches (current/rna_clip_codes.ipynb:1726-1736: sequences of 30..2542 tokens): sequence b
@@ -1277,15 +1278,44 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
         }
     __syncthreads();
     ATTN_STAMP(4);                                         // dK / dV images + barrier
-    if (tq < L) {
-      unsigned short* dqrow = p.dqkv + row0 * tokstride + (long)h * D + (unsigned int)tq * (unsigned int)tokstride;
-      store_grad_row<ROPE, D>(img + tq * ILD, dqrow, T, p.scale);            // q_scale: once per element, here
-      store_grad_row<ROPE, D>(img2 + tq * ILD, dqrow + H * D, T, p.scale);
+    // RoPE^T, scale and rounding by the row's owner, IN PLACE (the bf16 row over the start of its own f32 row; the
+    // row is read whole before it is written) ...
+    if (!p.row_stores) {                                   // (workgroup-uniform; kept for A/B: option attn_row_stores = 0)
+      if (tq < L) {
+        unsigned short* dqrow = p.dqkv + row0 * tokstride + (long)h * D + (unsigned int)tq * (unsigned int)tokstride;
+        store_grad_row<ROPE, D>(img + tq * ILD, dqrow, T, p.scale);
+        store_grad_row<ROPE, D>(img2 + tq * ILD, dqrow + H * D, T, p.scale);
 #pragma unroll
-      for (int c = 0; c < cpr; ++c)
-        *reinterpret_cast<u32x4*>(dqrow + 2 * H * D + 8 * c) = *reinterpret_cast<const u32x4*>(dvimg + tq * 64 + 16 * c);
+        for (int c = 0; c < cpr; ++c)
+          *reinterpret_cast<u32x4*>(dqrow + 2 * H * D + 8 * c) = *reinterpret_cast<const u32x4*>(dvimg + tq * 64 + 16 * c);
+      }
+    } else {
+    if (tq < L) {
+      store_grad_row<ROPE, D>(img + tq * ILD, reinterpret_cast<unsigned short*>(img + tq * ILD), T, p.scale);   // q_scale: once, here
+      store_grad_row<ROPE, D>(img2 + tq * ILD, reinterpret_cast<unsigned short*>(img2 + tq * ILD), T, p.scale);
     }
-    ATTN_STAMP(5);                                         // gradient rows: image reads, RoPE^T, stores issued
+    __syncthreads();
+    // ... and the rows leave four lanes to a row, as they came: a wave instruction covers 16 rows x 2 D bytes.  (One
+    // thread per row - 64 lines per store instruction - kept the address path busy for 2 us per head and stood in
+    // the way of the other workgroup's loads.)
+    {
+      unsigned short* dqb = p.dqkv + row0 * tokstride + (long)h * D;
+      if (ci < cpr) {
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) {
+          const int row = ps * (NT / 4) + r0;
+          if (row < L) {
+            unsigned short* drow = dqb + (unsigned int)row * (unsigned int)tokstride + 8 * ci;
+            *reinterpret_cast<u32x4*>(drow) = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(img + row * ILD) + 16 * ci);
+            *reinterpret_cast<u32x4*>(drow + H * D) =
+                *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(img2 + row * ILD) + 16 * ci);
+            *reinterpret_cast<u32x4*>(drow + 2 * H * D) = *reinterpret_cast<const u32x4*>(dvimg + row * 64 + 16 * ci);
+          }
+        }
+      }
+    }
+    }
+    ATTN_STAMP(5);                                         // gradient rows: RoPE^T in place, barrier, row stores issued
     __syncthreads();                                       // the images are read; the next head may stage over them
     ATTN_STAMP(6);                                         // the closing barrier
 #ifdef CLIPK_ATTN_TRACE
@@ -2041,7 +2071,7 @@ __global__ __launch_bounds__(256, ROT ? 3 : 4) void attn_fwd_whole32_kernel(cons
         *reinterpret_cast<u32x4*>(ktile + swz64(tid, i)) = rk.c[i];
         *reinterpret_cast<u32x4*>(qtile + swz64(tid, i)) = rq.c[i];
       }
-      if (tid < L) {
+      if (!p.row_stores && tid < L) {                      // (kept for A/B: option attn_row_stores = 0)
         unsigned short* wq = const_cast<unsigned short*>(qb) + (unsigned int)tid * 3u * HD;
 #pragma unroll
         for (int i = 0; i < cpr; ++i) {
@@ -2055,6 +2085,24 @@ __global__ __launch_bounds__(256, ROT ? 3 : 4) void attn_fwd_whole32_kernel(cons
     }
   }
   __syncthreads();
+  if (ROT && p.row_stores) {
+    // (option attn_row_stores & 2, off by default) the rotated rows go back in place from the LDS tiles, four lanes to a
+    // row.  Measured SLOWER than the owner's stores before the barrier (526 vs 498 us at B = 1024): those overlap the rest
+    // of the staging, these delay the sweep
+    const int ci = tid & 3, r0 = tid >> 2;
+    if (ci < cpr) {
+      unsigned short* qw = const_cast<unsigned short*>(p.qkv) + row0 * 3 * (long)(H * D) + (long)h * D;
+      const unsigned int HD = (unsigned int)(H * D);
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int row = ps * 64 + r0;
+        if (row < L) {
+          *reinterpret_cast<u32x4*>(qw + ((unsigned int)row * 3u * HD + 8u * ci)) = *reinterpret_cast<const u32x4*>(qtile + swz64(row, ci));
+          *reinterpret_cast<u32x4*>(qw + ((unsigned int)row * 3u * HD + HD + 8u * ci)) = *reinterpret_cast<const u32x4*>(ktile + swz64(row, ci));
+        }
+      }
+    }
+  }
 
   const int trow = 4 * g + (li >> 2);
   const int off_rf = swz64(li, g);
@@ -2188,7 +2236,9 @@ template <int DP> constexpr size_t lds_dkv() {
 template <int D, bool ROT>
 void launch_fwd_whole(const AP& p, hipStream_t st) {
   constexpr int lds = (ROT ? 3 : 2) * FUSED_LMAX * 64 + 256;
-  hipLaunchKernelGGL((attn_fwd_whole32_kernel<D, ROT>), dim3(p.H * p.B), dim3(256), lds, st, p);
+  AP q = p;
+  q.row_stores = (clipk_opt_get(OPT_ATTN_ROW_STORES) & 2) != 0;   // forward: measured slower (526 vs 498 us), off by default
+  hipLaunchKernelGGL((attn_fwd_whole32_kernel<D, ROT>), dim3(p.H * p.B), dim3(256), lds, st, q);
 }
 inline bool whole_fwd_applies(int L, int D) {
   return clipk_opt_get(OPT_ATTN_WHOLE_FWD) != 0 && L > 128 && L <= FUSED_LMAX && (D == 16 || D == 24 || D == 32);
@@ -2237,7 +2287,9 @@ void launch_fused_nw(const AP& p, hipStream_t st) {
   });
   int nwg = (NW == 4 ? 2 : 1) * attn_cu_count();          // persistent: the resident workgroups walk the heads
   if (nwg > p.H * p.B) nwg = p.H * p.B;
-  hipLaunchKernelGGL((attn_bwd_fused32_kernel<ROPE, D, NW>), dim3(nwg), dim3(64 * NW), lds, st, p);
+  AP q = p;
+  q.row_stores = (clipk_opt_get(OPT_ATTN_ROW_STORES) & 1) != 0;   // backward: 881 -> 863 us
+  hipLaunchKernelGGL((attn_bwd_fused32_kernel<ROPE, D, NW>), dim3(nwg), dim3(64 * NW), lds, st, q);
 }
 template <bool ROPE, int D>
 void launch_fused(const AP& p, hipStream_t st) {
