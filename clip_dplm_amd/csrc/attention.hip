@@ -1257,6 +1257,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
     ATTN_STAMP(2);                                         // the sweep
     RopeRow<D> T;
     if (ROPE) load_rope_row<D>(T, p.cosT, p.sinT, tq < L ? tq : L - 1);
+    // (asking for the head in two instalments around the LDS work of the write-out changed nothing: 850 vs 853 us)
     if constexpr (NW == 4) issue(w + (int)gridDim.x < nheads ? w + (int)gridDim.x : w, R);
     ATTN_STAMP(3);                                         // issuing the next head's loads
 
@@ -1280,16 +1281,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
     ATTN_STAMP(4);                                         // dK / dV images + barrier
     // RoPE^T, scale and rounding by the row's owner, IN PLACE (the bf16 row over the start of its own f32 row; the
     // row is read whole before it is written) ...
-    if (!p.row_stores) {                                   // (workgroup-uniform; kept for A/B: option attn_row_stores = 0)
-      if (tq < L) {
-        unsigned short* dqrow = p.dqkv + row0 * tokstride + (long)h * D + (unsigned int)tq * (unsigned int)tokstride;
-        store_grad_row<ROPE, D>(img + tq * ILD, dqrow, T, p.scale);
-        store_grad_row<ROPE, D>(img2 + tq * ILD, dqrow + H * D, T, p.scale);
-#pragma unroll
-        for (int c = 0; c < cpr; ++c)
-          *reinterpret_cast<u32x4*>(dqrow + 2 * H * D + 8 * c) = *reinterpret_cast<const u32x4*>(dvimg + tq * 64 + 16 * c);
-      }
-    } else {
     if (tq < L) {
       store_grad_row<ROPE, D>(img + tq * ILD, reinterpret_cast<unsigned short*>(img + tq * ILD), T, p.scale);   // q_scale: once, here
       store_grad_row<ROPE, D>(img2 + tq * ILD, reinterpret_cast<unsigned short*>(img2 + tq * ILD), T, p.scale);
@@ -1297,7 +1288,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
     __syncthreads();
     // ... and the rows leave four lanes to a row, as they came: a wave instruction covers 16 rows x 2 D bytes.  (One
     // thread per row - 64 lines per store instruction - kept the address path busy for 2 us per head and stood in
-    // the way of the other workgroup's loads.)
+    // the way of the other workgroup's loads: 881 -> 863 us per layer at B = 1024, profiles/r03/attn_row_stores_ab_v1.txt.)
     {
       unsigned short* dqb = p.dqkv + row0 * tokstride + (long)h * D;
       if (ci < cpr) {
@@ -1313,7 +1304,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
           }
         }
       }
-    }
     }
     ATTN_STAMP(5);                                         // gradient rows: RoPE^T in place, barrier, row stores issued
     __syncthreads();                                       // the images are read; the next head may stage over them
@@ -2287,9 +2277,7 @@ void launch_fused_nw(const AP& p, hipStream_t st) {
   });
   int nwg = (NW == 4 ? 2 : 1) * attn_cu_count();          // persistent: the resident workgroups walk the heads
   if (nwg > p.H * p.B) nwg = p.H * p.B;
-  AP q = p;
-  q.row_stores = (clipk_opt_get(OPT_ATTN_ROW_STORES) & 1) != 0;   // backward: 881 -> 863 us
-  hipLaunchKernelGGL((attn_bwd_fused32_kernel<ROPE, D, NW>), dim3(nwg), dim3(64 * NW), lds, st, q);
+  hipLaunchKernelGGL((attn_bwd_fused32_kernel<ROPE, D, NW>), dim3(nwg), dim3(64 * NW), lds, st, p);
 }
 template <bool ROPE, int D>
 void launch_fused(const AP& p, hipStream_t st) {

@@ -26,7 +26,7 @@ enum clipk_opt {
   OPT_WGRAD_SPLITS,        // v3 weight-gradient kernel: M splits (0 = about one workgroup per CU)
   OPT_SIMCE_KERNEL,        // -1 auto (tiled LSE pass for >= 64 queries), 1 first-generation kernel, 2 tiled
   OPT_GEMM_ABL,            // CLIPK_EXPERIMENTS builds only: timing ablations that change results
-  OPT_ATTN_ROW_STORES,     // whole-head attention kernels, rows leave four lanes to a row from LDS: bit 0 backward (default on), bit 1 forward (off)
+  OPT_ATTN_ROW_STORES,     // whole-head forward: 2 = rotated q / k rows written back four lanes to a row from LDS (measured slower; default off)
   OPT_COUNT
 };
 int clipk_opt_get(int which);      // core.hip

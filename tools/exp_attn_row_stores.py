@@ -41,8 +41,7 @@ def fwd(flag):
     return e0.elapsed_time(e1) * 1e3 / len(bufs), (bufs[0].clone(), o[0].clone(), o[1].clone())
 
 
-def bwd(flag, n=16):
-    ops.set_option("attn_row_stores", flag)
+def bwd(flag, n=16):                     # (the backward's own A/B branch is gone: both arms run the kept kernel)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):
