@@ -1665,18 +1665,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused96_kernel(const AP p) {
 // =================================================================================================
 // The same backward with EIGHT waves (two per SIMD, 256 registers each): a wave owns 32 keys - half the fragments and
 // accumulators (144 resident registers instead of 288) - so that the second wave of a SIMD fills the first one's
-// dependency stalls (the 4-wave kernel keeps a SIMD 0.41 busy: one wave, every LDS / MFMA latency exposed).  The price
-// is LDS traffic: every wave reads the Q / dO fragments of the whole 32-query block for its 32 keys (twice the reads
-// per key) and there are eight dQ shares to add.  The shares meet pairwise: waves 4-7 run their dQ product FIRST and
-// write their shares, waves 0-3 run dV / dK first, then - after a barrier - their dQ product, add their partner's
-// share (the wave four above, the one they share a SIMD with) and write the pair's sum over it; all 512 threads add
-// the four pair sums in a fixed order.  Same LDS footprint as the 4-wave kernel, three barriers per step instead of
-// two, bitwise reproducible.  Everything else (staging, prefetch of the next head, write-out) as above.
-// Option attn_fused_waves = 8 selects it.  Measured (B = 1024, L = 256, profiles/r03/attn96_eight_waves_ab_v1.txt): 1173 us
-// against 1140 us for the 4-wave kernel - the second wave does not pay: at 256 registers the K fragments had to move to
-// LDS reads (resident they cost 150 / 59 spilled registers, each reload a vmcnt(0) inside the sweep: 2711 / 1292 us), and
-// the head's memory phases - K / V fragments and rows in, dK / dV rows out, ~12 of the ~36 us per head at the CU's share
-// of HBM - are the same in both kernels and overlap nothing in either.  Kept for A/B and as a test of the 4-wave one.
+// dependency stalls (the 4-wave kernel keeps a SIMD 0.41 busy: one wave, every LDS / MFMA latency exposed).  Every wave
+// reads the Q / dO fragments of the whole 32-query block for its 32 keys (twice the LDS reads per key of the 4-wave
+// kernel), so dQ is NOT summed from per-wave shares here: after a barrier the waves compute complete (d tile, query tile)
+// outputs over all keys from the eight dS^T tiles (12 tiles: two each for waves 0-3, one each for waves 4-7 = three per
+// SIMD).  Same LDS layout as the 4-wave kernel (the shares' region holds one 32-row bf16 image), three barriers per
+// step, bitwise reproducible.  Everything else (staging, prefetch of the next head, write-out) as above.
+// The default for hd 96 (option attn_fused_waves = 4 keeps the 4-wave kernel): 1018 against 1132 us per layer at B = 1024 -
+// with per-wave dQ shares added pairwise it was 1173 (profiles/r03/attn96_eight_waves_ab_v1.txt).
 // =================================================================================================
 __global__ __launch_bounds__(512, 1) void attn_bwd_fused96w8_kernel(const AP p) {
   constexpr int D = 96, RS = Geo<96>::RS, KS = 3, DT = 6, NCH = 12, LQ = FUSED_LMAX, QB = F96_QB, ILD = D + 4;
@@ -1684,7 +1680,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused96w8_kernel(const AP p) 
   constexpr int NKP = LQ * NCH / NT;                       // K-row chunk tasks per thread (6)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ktile = smem;                                      // [256][RS] K rows (transposed fragments); later dK / dV images
-  float* share = reinterpret_cast<float*>(smem + LQ * RS); // [4 wave pairs][32 q][ILD] f32
+  char* dqimg = smem + LQ * RS;                            // [32 q][RS] bf16 dQ rows of the step (where the 4-wave kernel keeps its shares)
   char* qd = smem + LQ * RS + 4 * QB * ILD * 4;            // [2 buffers][Q block | dO block][32][RS]
   char* dst_all = qd + 4 * QB * RS;                        // [8 waves][32 keys][64 B]
   float* lse_l = reinterpret_cast<float*>(dst_all + 4 * 4096);   // [256] lse * log2(e); +inf past the end
@@ -1736,6 +1732,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused96w8_kernel(const AP p) 
     }
   };
   bf16x8 vf[KTW][KS];
+  u32x4 kr[NKP];                                           // the head's K rows, chunk per lane, on their way to LDS
   float kbias[KTW], lse_r;
   auto issue_head = [&](int w) {                           // sets lq / ldo / lo / lL to head w and requests its rows
     int L_, b_, h_;
@@ -1759,6 +1756,17 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused96w8_kernel(const AP p) 
     }
     const int lr = tid < LQ ? tid : LQ - 1;
     lse_r = p.lse[stat_at(p, b_, h_, H, L_, row0_, lr < L_ ? lr : L_ - 1)];
+    // the K rows for the transposed (and, in this kernel, the row) fragments: requested HERE, with the rest of the head,
+    // so that they land under the previous head's write-out instead of at the top of this one
+    {
+      const int t = tid + opaque_zero();
+#pragma unroll
+      for (int ps = 0; ps < NKP; ++ps) {
+        const int idl = ps * NT + t;
+        const int r = idl / NCH, ch = idl - r * NCH;
+        kr[ps] = *reinterpret_cast<const u32x4*>(lq + HD + ((unsigned int)(r < L_ ? r : L_ - 1) * 3u * HD + 8u * ch));
+      }
+    }
     issue_block(0);
   };
 
@@ -1767,8 +1775,6 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused96w8_kernel(const AP p) 
   int off_dw[2];                                           // dS^T write: key row li of a 16-key tile, queries qq*16 + 4g ..
 #pragma unroll
   for (int qq = 0; qq < 2; ++qq) off_dw[qq] = swz64(li, qq * 2 + (g >> 1)) + 8 * (g & 1);
-  const bool lower = wid < 4;                              // (wave-uniform) waves 0-3 add their partner's share
-  float* sh = share + (wid & 3) * (QB * ILD);              // the pair's slot
 
   int w = blockIdx.x;
   if (w < nheads) issue_head(w);
@@ -1796,14 +1802,6 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused96w8_kernel(const AP p) 
     // ---- K rows -> LDS for the transposed fragments, block 0 -> buffer 0, lse
     {
       const int t = tid + opaque_zero();
-      const unsigned short* kb_ = p.qkv + row0 * tokstride + (long)h * D + HD;
-      u32x4 kr[NKP];
-#pragma unroll
-      for (int ps = 0; ps < NKP; ++ps) {
-        const int idl = ps * NT + t;
-        const int r = idl / NCH, ch = idl - r * NCH;
-        kr[ps] = *reinterpret_cast<const u32x4*>(kb_ + ((unsigned int)(r < L ? r : L - 1) * 3u * HD + 8u * ch));
-      }
 #pragma unroll
       for (int ps = 0; ps < NKP; ++ps) {
         const int idl = ps * NT + t;
@@ -1894,62 +1892,45 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused96w8_kernel(const AP p) 
       __builtin_amdgcn_sched_barrier(0);
       dvdk();
       __builtin_amdgcn_sched_barrier(0);
-      // dQ^T[d][q] = K^T[d][this wave's 32 keys] dS^T[32 keys][q] for both 16-query tiles, kept in registers: the upper
-      // waves write theirs to the pair's slot, the lower ones add their partner's after the barrier and write the sum
-      // back.  (ONE instruction stream for both halves: with the halves running dV / dK and dQ in opposite orders hipcc
-      // spilled 150 registers, the K / V fragments among them, and every reload inside the sweep is a vmcnt(0).)
-      f32x4 dq[2][DT];
-#pragma unroll
-      for (int qq = 0; qq < 2; ++qq) {
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) dq[qq][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (wave_live) {
-          const bf16x8 dsb = tr_frag_off(dst, swz64(trow, qq * 2 + ((li & 3) >> 1)) + 8 * (li & 1));
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) {
-            const bf16x8 ktf = tr_frag(ktile, RS, wid * KW + trow, dt * 32 + tcolb);
-            dq[qq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsb, dq[qq][dt], 0, 0, 0);
-          }
-        }
-      }
-      if (!lower) {
-#pragma unroll
-        for (int qq = 0; qq < 2; ++qq)
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt)
-            *reinterpret_cast<f32x4*>(sh + (qq * 16 + li) * ILD + dt * 16 + 4 * g) = dq[qq][dt];
-      }
-      __syncthreads();                                     // the upper waves' shares are in the slots
-      if (lower) {
-#pragma unroll
-        for (int qq = 0; qq < 2; ++qq)
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) {
-            float* at = sh + (qq * 16 + li) * ILD + dt * 16 + 4 * g;
-            *reinterpret_cast<f32x4*>(at) = *reinterpret_cast<const f32x4*>(at) + dq[qq][dt];
-          }
-      }
       store_block(j + 1);                                  // the other buffer
-      __syncthreads();
-      // ---- sum the four pair sums in slot order, scale, round, store: thread t < 384 -> query t / 12, 8 head dims
-      if (tid < QB * NCH) {
-        const int r = tid / NCH, c0 = (tid - r * NCH) * 8;
-        f32x4 a[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(share + r * ILD + c0 + 4 * i);
-#pragma unroll
-        for (int ww = 1; ww < 4; ++ww)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) a[i] += *reinterpret_cast<const f32x4*>(share + ww * (QB * ILD) + r * ILD + c0 + 4 * i);
-        const int q = j * QB + r;
-        if (q < L) {
-          u32x4 w4;
-          w4[0] = pack_bf16x2(a[0][0] * p.scale, a[0][1] * p.scale);
-          w4[1] = pack_bf16x2(a[0][2] * p.scale, a[0][3] * p.scale);
-          w4[2] = pack_bf16x2(a[1][0] * p.scale, a[1][1] * p.scale);
-          w4[3] = pack_bf16x2(a[1][2] * p.scale, a[1][3] * p.scale);
-          *reinterpret_cast<u32x4*>(dqb + (unsigned int)q * 3u * HD + c0) = w4;
+      __syncthreads();                                     // every wave's dS^T tile is written
+      // dQ^T = K^T dS^T as COMPLETE (d tile, 16-query tile) outputs over all keys: waves 0-3 take d tiles 0-3 (both query
+      // tiles), waves 4-7 d tiles 4 / 5 (one query tile each) - three tiles per SIMD - reading the K^T fragments of the
+      // staged K rows and the dS^T tile of the wave that owns each 32-key chunk.  No shares, no sums over waves: the
+      // accumulator IS the gradient; it goes (scaled, bf16) into a [32 q][RS] image and leaves as whole rows.
+      {
+        const int nck = (L + 31) >> 5;                     // 32-key chunks that hold a real key (dead waves wrote nothing)
+        const int dt0 = wid < 4 ? wid : 4 + ((wid - 4) >> 1);
+        const int nq = wid < 4 ? 2 : 1, q0t = wid < 4 ? 0 : (wid & 1);
+        f32x4 dq[2];
+        dq[0] = f32x4{0.f, 0.f, 0.f, 0.f}; dq[1] = dq[0];
+        for (int c = 0; c < nck; ++c) {
+          const bf16x8 ktf = tr_frag(ktile, RS, c * 32 + trow, dt0 * 32 + tcolb);
+          const char* dsc = dst_all + c * 2048;
+          const bf16x8 dsb0 = tr_frag_off(dsc, swz64(trow, q0t * 2 + ((li & 3) >> 1)) + 8 * (li & 1));
+          dq[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsb0, dq[0], 0, 0, 0);
+          if (nq == 2) {                                   // (wave-uniform)
+            const bf16x8 dsb1 = tr_frag_off(dsc, swz64(trow, 2 + ((li & 3) >> 1)) + 8 * (li & 1));
+            dq[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsb1, dq[1], 0, 0, 0);
+          }
         }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          if (t < nq) {
+            const f32x4 v = dq[t] * p.scale;
+            u32x2 wv;
+            wv[0] = pack_bf16x2(v[0], v[1]);
+            wv[1] = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<u32x2*>(dqimg + ((q0t + t) * 16 + li) * RS + (dt0 * 16 + 4 * g) * 2) = wv;
+          }
+      }
+      __syncthreads();
+      // ---- dQ rows: thread t < 384 -> query t / 12, one 16-byte chunk
+      if (tid < QB * NCH) {
+        const int r = tid / NCH, ch = tid - r * NCH;
+        const int q = j * QB + r;
+        if (q < L)
+          *reinterpret_cast<u32x4*>(dqb + (unsigned int)q * 3u * HD + 8 * ch) = *reinterpret_cast<const u32x4*>(dqimg + r * RS + ch * 16);
       }
       if (j + 1 < nblk) finish_delta(j + 1);
       __syncthreads();
@@ -2284,7 +2265,7 @@ void launch_fused(const AP& p, hipStream_t st) {
   // 4 waves (default) or 8 (option attn_fused_waves = 8).  Measured, ESM-2-35M shape, warm, interleaved rounds: 435 us
   // with 4 waves, 585 us with 8 - the gather does run under the sweep, but with ONE workgroup per CU every barrier
   // (eight per head in the sweep, six around it) stalls the whole CU and the steps are half as long.
-  if (clipk_opt_get(OPT_ATTN_FUSED_WAVES) == 8) launch_fused_nw<ROPE, D, 8>(p, st);
+  if (clipk_opt_get(OPT_ATTN_FUSED_WAVES) == 8) launch_fused_nw<ROPE, D, 8>(p, st);   // (0 = auto: four waves here)
   else launch_fused_nw<ROPE, D, 4>(p, st);
 }
 
@@ -2294,7 +2275,7 @@ inline void launch_fused96(const AP& p, hipStream_t st) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused96_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int nheads = p.B * p.H, cus = attn_cu_count();
-  if (clipk_opt_get(OPT_ATTN_FUSED_WAVES) == 8) {             // eight waves, 32 keys each (same LDS footprint)
+  if (clipk_opt_get(OPT_ATTN_FUSED_WAVES) != 4) {             // default: eight waves of 32 keys (1018 vs 1132 us per layer at B = 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused96w8_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(attn_bwd_fused96w8_kernel, dim3(nheads < cus ? nheads : cus), dim3(512), lds, st, p);

@@ -22,7 +22,7 @@ enum clipk_opt {
   OPT_WGRAD_KERNEL,        // -1 auto, 2 128x128 kernel, 3 256x256 kernel (8-phase schedule), 4 256x256 software-pipelined
   OPT_ATTN_WHOLE_FWD,      // -1 auto, 0 off, 1 on: whole-head forward for short heads
   OPT_ATTN_FUSED_BWD,      // -1 auto, 0 off, 1 on: whole-head backward for short heads
-  OPT_ATTN_FUSED_WAVES,    // 4 (default) or 8 waves per workgroup in the whole-head backward
+  OPT_ATTN_FUSED_WAVES,    // waves per workgroup in the whole-head backward: 0 auto (hd <= 32: 4, hd 96: 8), 4, 8
   OPT_WGRAD_SPLITS,        // v3 weight-gradient kernel: M splits (0 = about one workgroup per CU)
   OPT_SIMCE_KERNEL,        // -1 auto (tiled LSE pass for >= 64 queries), 1 first-generation kernel, 2 tiled
   OPT_GEMM_ABL,            // CLIPK_EXPERIMENTS builds only: timing ablations that change results
