@@ -1778,10 +1778,19 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused96w8_kernel(const AP p) 
 
   int w = blockIdx.x;
   if (w < nheads) issue_head(w);
+#ifdef CLIPK_ATTN_TRACE
+  const bool tr_on = blockIdx.x == 0 && tid == 0 && g_attn_trace != nullptr;
+  unsigned long long* tr_lds = reinterpret_cast<unsigned long long*>(smem + lds_fused96());
+  if (tid < 16) tr_lds[tid] = 0;
+  __syncthreads();
+  unsigned long long tr_t = __builtin_amdgcn_s_memtime();
+  const unsigned long long tr_r0 = __builtin_amdgcn_s_memrealtime(), tr_c0 = tr_t;
+#endif
   for (; w < nheads; w += gridDim.x) {
     int L, b, h;
     long row0;
     point_at(w, L, row0, b, h);
+    ATTN_STAMP(7);                                         // (loop bookkeeping)
     const int wnext = w + (int)gridDim.x < nheads ? w + (int)gridDim.x : w;   // last head: re-request its own rows
     if (L <= 0) {                                          // (workgroup-uniform) empty sequence of a packed batch
       issue_head(wnext);
@@ -1814,6 +1823,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused96w8_kernel(const AP p) 
     __syncthreads();
     finish_delta(0);
     __syncthreads();
+    ATTN_STAMP(0);                                         // wait for the head's rows, K rows -> LDS, block 0, delta (2 barriers)
 
     f32x4 dk[DT][KTW], dv[DT][KTW];
 #pragma unroll
@@ -1832,6 +1842,10 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused96w8_kernel(const AP p) 
       const char* qt_ = qd + (j & 1) * (2 * QB * RS);
       const char* dt_ = qt_ + QB * RS;
       u32x2 pk[2][KTW], dsk[2][KTW];
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+        for (int kt = 0; kt < KTW; ++kt) { pk[qq][kt] = u32x2{0u, 0u}; dsk[qq][kt] = pk[qq][kt]; }
       if (wave_live) {
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq) {
@@ -1864,13 +1878,14 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused96w8_kernel(const AP p) 
           }
           __builtin_amdgcn_sched_barrier(0);               // one 16-query tile at a time: the second one's 16 accumulator
         }                                                  // registers reuse the first one's
-        // dS^T -> the wave's private [32 keys][32 queries] tile
-#pragma unroll
-        for (int kt = 0; kt < KTW; ++kt)
-#pragma unroll
-          for (int qq = 0; qq < 2; ++qq)
-            *reinterpret_cast<u32x2*>(dst + kt * 1024 + off_dw[qq]) = dsk[qq][kt];
       }
+      // dS^T -> the wave's private [32 keys][32 queries] tile (zeros from a wave without keys: the dQ tiles below read
+      // all eight tiles)
+#pragma unroll
+      for (int kt = 0; kt < KTW; ++kt)
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq)
+          *reinterpret_cast<u32x2*>(dst + kt * 1024 + off_dw[qq]) = dsk[qq][kt];
       // dV^T[d][key] += dO^T[d][32 q] P[32 q][key], dK^T += Q^T dS
       const auto dvdk = [&]() {
         if (wave_live) {
@@ -1893,18 +1908,22 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused96w8_kernel(const AP p) 
       dvdk();
       __builtin_amdgcn_sched_barrier(0);
       store_block(j + 1);                                  // the other buffer
+      ATTN_STAMP(1);                                       // step: S / dP, softmax, dS^T, dV / dK, staging of the next block
       __syncthreads();                                     // every wave's dS^T tile is written
+      ATTN_STAMP(4);                                       // step: the barrier after it
       // dQ^T = K^T dS^T as COMPLETE (d tile, 16-query tile) outputs over all keys: waves 0-3 take d tiles 0-3 (both query
       // tiles), waves 4-7 d tiles 4 / 5 (one query tile each) - three tiles per SIMD - reading the K^T fragments of the
       // staged K rows and the dS^T tile of the wave that owns each 32-key chunk.  No shares, no sums over waves: the
       // accumulator IS the gradient; it goes (scaled, bf16) into a [32 q][RS] image and leaves as whole rows.
       {
-        const int nck = (L + 31) >> 5;                     // 32-key chunks that hold a real key (dead waves wrote nothing)
         const int dt0 = wid < 4 ? wid : 4 + ((wid - 4) >> 1);
         const int nq = wid < 4 ? 2 : 1, q0t = wid < 4 ? 0 : (wid & 1);
         f32x4 dq[2];
         dq[0] = f32x4{0.f, 0.f, 0.f, 0.f}; dq[1] = dq[0];
-        for (int c = 0; c < nck; ++c) {
+        // all eight 32-key chunks, unrolled (a chunk past the end multiplies clamped K rows by a zero dS^T tile): as a
+        // run-time loop over the live chunks every fragment read waited out its own LDS latency - 3160 cycles per step
+#pragma unroll
+        for (int c = 0; c < LQ / 32; ++c) {
           const bf16x8 ktf = tr_frag(ktile, RS, c * 32 + trow, dt0 * 32 + tcolb);
           const char* dsc = dst_all + c * 2048;
           const bf16x8 dsb0 = tr_frag_off(dsc, swz64(trow, q0t * 2 + ((li & 3) >> 1)) + 8 * (li & 1));
@@ -1934,10 +1953,12 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused96w8_kernel(const AP p) 
       }
       if (j + 1 < nblk) finish_delta(j + 1);
       __syncthreads();
+      ATTN_STAMP(2);                                       // step: dQ tiles, barrier, dQ rows, delta, barrier
     }
 
     // ---- the next head's rows: K / V fragment registers are free now; they land under the write-out below
     issue_head(wnext);
+    ATTN_STAMP(3);                                         // issuing the next head's loads
 
     // ---- dK^T (x scale) and dV^T accumulators -> bf16 [key][d] images (one after the other, over the K rows) -> rows
 #pragma unroll 1
@@ -1966,7 +1987,18 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused96w8_kernel(const AP p) 
       }
       __syncthreads();
     }
+    ATTN_STAMP(5);                                         // dK / dV images, barriers, row stores
+#ifdef CLIPK_ATTN_TRACE
+    if (tr_on) atomicAdd(&tr_lds[8], 1ull);
+#endif
   }
+#ifdef CLIPK_ATTN_TRACE
+  if (tr_on) {
+    for (int i = 0; i < 9; ++i) g_attn_trace[i] = tr_lds[i];
+    g_attn_trace[9] = __builtin_amdgcn_s_memtime() - tr_c0;
+    g_attn_trace[10] = __builtin_amdgcn_s_memrealtime() - tr_r0;
+  }
+#endif
 }
 
 // =================================================================================================
@@ -2277,8 +2309,8 @@ inline void launch_fused96(const AP& p, hipStream_t st) {
   const int nheads = p.B * p.H, cus = attn_cu_count();
   if (clipk_opt_get(OPT_ATTN_FUSED_WAVES) != 4) {             // default: eight waves of 32 keys (1018 vs 1132 us per layer at B = 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused96w8_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(attn_bwd_fused96w8_kernel, dim3(nheads < cus ? nheads : cus), dim3(512), lds, st, p);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + FUSED_TRACE_LDS));
+    hipLaunchKernelGGL(attn_bwd_fused96w8_kernel, dim3(nheads < cus ? nheads : cus), dim3(512), lds + FUSED_TRACE_LDS, st, p);
     return;
   }
   hipLaunchKernelGGL(attn_bwd_fused96_kernel, dim3(nheads < cus ? nheads : cus), dim3(256), lds, st, p);
