@@ -1671,7 +1671,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused96_kernel(const AP p) {
 // outputs over all keys from the eight dS^T tiles (12 tiles: two each for waves 0-3, one each for waves 4-7 = three per
 // SIMD).  Same LDS layout as the 4-wave kernel (the shares' region holds one 32-row bf16 image), three barriers per
 // step, bitwise reproducible.  Everything else (staging, prefetch of the next head, write-out) as above.
-// The default for hd 96 (option attn_fused_waves = 4 keeps the 4-wave kernel): 1018 against 1132 us per layer at B = 1024 -
+// The default for hd 96 (option attn_fused_waves = 4 keeps the 4-wave kernel): 948 against 1132 us per layer at B = 1024 -
 // with per-wave dQ shares added pairwise it was 1173 (profiles/r03/attn96_eight_waves_ab_v1.txt).
 // =================================================================================================
 __global__ __launch_bounds__(512, 1) void attn_bwd_fused96w8_kernel(const AP p) {
@@ -2307,7 +2307,7 @@ inline void launch_fused96(const AP& p, hipStream_t st) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused96_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int nheads = p.B * p.H, cus = attn_cu_count();
-  if (clipk_opt_get(OPT_ATTN_FUSED_WAVES) != 4) {             // default: eight waves of 32 keys (1018 vs 1132 us per layer at B = 1024)
+  if (clipk_opt_get(OPT_ATTN_FUSED_WAVES) != 4) {             // default: eight waves of 32 keys (948 vs 1132 us per layer at B = 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused96w8_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + FUSED_TRACE_LDS));
     hipLaunchKernelGGL(attn_bwd_fused96w8_kernel, dim3(nheads < cus ? nheads : cus), dim3(512), lds + FUSED_TRACE_LDS, st, p);
