@@ -1,0 +1,386 @@
+// attention_f32.hip — exact-f32 multi-head self-attention, forward and backward, for the models whose caller is fp32.
+//
+// Reference arithmetic replaced: nn.MultiheadAttention inside nn.TransformerEncoderLayer as the notebook models call it
+// WITHOUT autocast (current/rna_clip_codes.ipynb:1911-1954, current/tf_clip_codes (1).ipynb:13056-13072): f32 q / k / v,
+// f32 scores, f32 softmax, f32 P·V.  Those models pool ONE position (`enc[:, 0]`, ipynb:1948-1949) of a stack whose
+// attention mixes the batch axis, so after the position-0 slice their attention problem is tiny - one "sequence" of B
+// samples per head - and what matters is that no operand is rounded to bf16 (a bf16-rounded weight perturbs the model
+// identically for every sample and no batch size averages that away: DESIGN.md §3.3).
+//
+// gfx950 design: the f32 matrix pipe (v_mfma_f32_32x32x2_f32) and the packed-f32 vector pipe have the same 157 TFLOP/s
+// peak on this part, so these kernels use plain VALU fmas in a fixed order (bitwise reproducible, no atomics) and spend
+// their care on the LDS access pattern instead of on MFMA fragment layouts:
+//   * scores: lane = key.  A 64-key block of K (and V) sits in LDS as rows of S = 4 * (odd) floats, so that the 64
+//     lanes' ds_read_b128 of their own row hit disjoint bank groups (16 lanes x 4 banks per pass); the query rows are
+//     read as wave-uniform (broadcast) b128.  Four query rows per wave share every K read: 5 LDS reads per 16 fmas;
+//   * online softmax per query row with wave-wide max / sum (DPP butterflies), statistics in f32, accurate expf;
+//   * P·V (and every "sum over rows of an LDS tile" product of the backward): lane = head-dim column d, the
+//     probabilities of the wave's four query rows come back from LDS as one broadcast b128 per key, the V row is read
+//     by consecutive lanes (conflict-free);
+//   * backward = a dQ kernel (16 queries per workgroup, sweeping keys; also writes delta = rowsum(dO * O)) and a dK/dV
+//     kernel (16 keys per workgroup, sweeping queries), each recomputing P from q, k and the saved log-sum-exp: 7
+//     products instead of 5, no float atomics, one fixed summation order;
+//   * dropout on the probabilities uses the SAME counter-based mask and element index as the bf16 kernels
+//     (attention.hip attn_drop), so a model switched between the two arithmetics drops the same elements.
+// Head dims up to 192 (any value, no multiple-of-8 rule: the notebook's 120 / 8 = 15 runs unpadded).
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+struct AF {
+  const float* qkv; const uint8_t* key_mask; float* out; float* lse;
+  const float* dout; float* delta; float* dqkv;
+  int B, L, H, D;
+  float scale;
+  unsigned drop_thr, drop_seed; float drop_scale;
+};
+
+constexpr int KB = 64;        // keys (dQ / forward) or queries (dK/dV) per LDS block = one per lane
+constexpr int RB = 16;        // rows owned by a workgroup: 4 waves x 4 rows
+constexpr int NW = 4, RW = 4;
+
+__host__ __device__ inline int row_stride(int D) { return 4 * ((((D + 3) >> 2)) | 1); }   // floats; S / 4 odd
+
+__device__ __forceinline__ float drop_at(const AF& p, long qrow, int h, int key) {
+  return drop_mul(p.drop_seed, ((unsigned long long)qrow * p.H + h) * (unsigned long long)p.L + key, p.drop_thr, p.drop_scale);
+}
+
+// rows [r0, r0 + nrows) of one head-slice of a [B*L, ld] f32 tensor -> LDS rows of stride S, columns >= D and rows past
+// the sequence zero-filled; consecutive threads on consecutive columns (coalesced 4-byte loads: head slices of odd head
+// dims are not 16-byte aligned).  mul: scale applied on the way (q * q_scale).
+__device__ __forceinline__ void stage_rows(float* dst, const float* src, long ld, long row0, int r0, int nrows, int L, int D,
+                                           int S, float mul, int tid) {
+  const int lpr_log = D <= 16 ? 4 : (D <= 32 ? 5 : 6);
+  const int tx = tid & ((1 << lpr_log) - 1), ty = tid >> lpr_log, rows_per_pass = 256 >> lpr_log;
+  for (int j = ty; j < nrows; j += rows_per_pass) {
+    const int r = r0 + j;
+    const float* s = src + (row0 + (r < L ? r : 0)) * ld;
+    for (int d = tx; d < S; d += (1 << lpr_log)) dst[j * S + d] = (r < L && d < D) ? s[d] * mul : 0.f;
+  }
+}
+
+// acc[r] += <rowsA[r] (wave-uniform rows, broadcast reads), rowB (this lane's row)> over the padded head dim, d ascending
+__device__ __forceinline__ void dot4(const float* rowsA, const float* rowB, int S, int D4, float (&acc)[RW]) {
+  for (int d = 0; d < D4; d += 4) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(rowB + d);
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(rowsA + r * S + d);
+      acc[r] = fmaf(a[0], b[0], acc[r]);
+      acc[r] = fmaf(a[1], b[1], acc[r]);
+      acc[r] = fmaf(a[2], b[2], acc[r]);
+      acc[r] = fmaf(a[3], b[3], acc[r]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward: workgroup = 16 queries of one (batch, head); wave w owns queries q0 + 4w .. + 3
+template <int DT>
+__global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const AF p) {
+  extern __shared__ float smem[];
+  const int L = p.L, H = p.H, D = p.D, S = row_stride(D), D4 = (D + 3) & ~3;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * RB;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const long ld = 3L * H * D, row0 = (long)b * L;
+  float* Ks = smem;                        // [KB][S]
+  float* Vs = Ks + KB * S;                 // [KB][S]
+  float* Qs = Vs + KB * S;                 // [RB][S], pre-multiplied by q_scale
+  float* Ps = Qs + RB * S;                 // [NW][KB][RW]
+  stage_rows(Qs, p.qkv + (long)h * D, ld, row0, q0, RB, L, D, S, p.scale, tid);
+  float m[RW], l[RW], acc[RW][DT];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    m[r] = -INFINITY; l[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) acc[r][t] = 0.f;
+  }
+  for (int k0 = 0; k0 < L; k0 += KB) {
+    __syncthreads();                                        // previous block's readers are done (and Qs is written)
+    stage_rows(Ks, p.qkv + (long)(H + h) * D, ld, row0, k0, KB, L, D, S, 1.f, tid);
+    stage_rows(Vs, p.qkv + (long)(2 * H + h) * D, ld, row0, k0, KB, L, D, S, 1.f, tid);
+    __syncthreads();
+    const int key = k0 + lane;
+    const bool valid = key < L && (!p.key_mask || p.key_mask[row0 + key]);
+    float s[RW] = {0.f, 0.f, 0.f, 0.f};
+    dot4(Qs + w * RW * S, Ks + lane * S, S, D4, s);
+    f32x4 pt;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const float sv = valid ? s[r] : -INFINITY;
+      const float m_new = fmaxf(m[r], wave_max(sv));
+      float pv = 0.f;
+      if (m_new != -INFINITY) {                             // wave-uniform
+        const float corr = expf(m[r] - m_new);              // m = -inf: 0
+        pv = expf(sv - m_new);
+        l[r] = fmaf(l[r], corr, wave_sum(pv));
+#pragma unroll
+        for (int t = 0; t < DT; ++t) acc[r][t] *= corr;
+        m[r] = m_new;
+      }
+      if (p.drop_thr) pv *= drop_at(p, row0 + q0 + w * RW + r, h, key);
+      pt[r] = pv;
+    }
+    *reinterpret_cast<f32x4*>(Ps + (w * KB + lane) * RW) = pt;
+    __syncthreads();
+    const int nk = L - k0 < KB ? L - k0 : KB;
+    for (int j = 0; j < nk; ++j) {
+      const f32x4 pj = *reinterpret_cast<const f32x4*>(Ps + (w * KB + j) * RW);
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const int d = lane + 64 * t;
+        const float v = Vs[j * S + (d < D ? d : 0)];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) acc[r][t] = fmaf(pj[r], v, acc[r][t]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int q = q0 + w * RW + r;
+    if (q >= L) continue;
+    const float inv = l[r] > 0.f ? 1.0f / l[r] : 0.f;       // every key masked: zero row, lse = -inf (as attention.hip)
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      const int d = lane + 64 * t;
+      if (d < D) p.out[(row0 + q) * ((long)H * D) + (long)h * D + d] = acc[r][t] * inv;
+    }
+    if (lane == 0) p.lse[((long)b * H + h) * L + q] = l[r] > 0.f ? m[r] + logf(l[r]) : -INFINITY;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward, dQ (+ delta): same ownership as the forward
+template <int DT>
+__global__ __launch_bounds__(256) void attn_f32_bwd_dq_kernel(const AF p) {
+  extern __shared__ float smem[];
+  const int L = p.L, H = p.H, D = p.D, S = row_stride(D), D4 = (D + 3) & ~3;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * RB;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const long ld = 3L * H * D, ldo = (long)H * D, row0 = (long)b * L;
+  float* Ks = smem;
+  float* Vs = Ks + KB * S;
+  float* Qs = Vs + KB * S;                 // [RB][S] q * q_scale
+  float* Gs = Qs + RB * S;                 // [RB][S] dO
+  float* Ds = Gs + RB * S;                 // [NW][KB][RW] dS
+  stage_rows(Qs, p.qkv + (long)h * D, ld, row0, q0, RB, L, D, S, p.scale, tid);
+  stage_rows(Gs, p.dout + (long)h * D, ldo, row0, q0, RB, L, D, S, 1.f, tid);
+  float lse[RW], delta[RW], dq[RW][DT];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int q = q0 + w * RW + r;
+    float part = 0.f;
+    if (q < L) {
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const int d = lane + 64 * t;
+        if (d < D) {
+          const long o = (row0 + q) * ldo + (long)h * D + d;
+          part = fmaf(p.dout[o], p.out[o], part);
+        }
+      }
+    }
+    delta[r] = wave_sum(part);
+    lse[r] = q < L ? p.lse[((long)b * H + h) * L + q] : -INFINITY;
+    if (lane == 0 && q < L) p.delta[((long)b * H + h) * L + q] = delta[r];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) dq[r][t] = 0.f;
+  }
+  for (int k0 = 0; k0 < L; k0 += KB) {
+    __syncthreads();
+    stage_rows(Ks, p.qkv + (long)(H + h) * D, ld, row0, k0, KB, L, D, S, 1.f, tid);
+    stage_rows(Vs, p.qkv + (long)(2 * H + h) * D, ld, row0, k0, KB, L, D, S, 1.f, tid);
+    __syncthreads();
+    const int key = k0 + lane;
+    const bool valid = key < L && (!p.key_mask || p.key_mask[row0 + key]);
+    float s[RW] = {0.f, 0.f, 0.f, 0.f}, dp[RW] = {0.f, 0.f, 0.f, 0.f};
+    dot4(Qs + w * RW * S, Ks + lane * S, S, D4, s);
+    dot4(Gs + w * RW * S, Vs + lane * S, S, D4, dp);
+    f32x4 dst;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const float pv = (valid && lse[r] != -INFINITY) ? expf(s[r] - lse[r]) : 0.f;
+      const float dm = p.drop_thr ? drop_at(p, row0 + q0 + w * RW + r, h, key) : 1.f;
+      dst[r] = pv * fmaf(dp[r], dm, -delta[r]);              // dS = P o (dP~ - delta)
+    }
+    *reinterpret_cast<f32x4*>(Ds + (w * KB + lane) * RW) = dst;
+    __syncthreads();
+    const int nk = L - k0 < KB ? L - k0 : KB;
+    for (int j = 0; j < nk; ++j) {
+      const f32x4 dj = *reinterpret_cast<const f32x4*>(Ds + (w * KB + j) * RW);
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const int d = lane + 64 * t;
+        const float kv = Ks[j * S + (d < D ? d : 0)];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) dq[r][t] = fmaf(dj[r], kv, dq[r][t]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int q = q0 + w * RW + r;
+    if (q >= L) continue;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      const int d = lane + 64 * t;
+      if (d < D) p.dqkv[(row0 + q) * ld + (long)h * D + d] = dq[r][t] * p.scale;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward, dK / dV: workgroup = 16 keys of one (batch, head), sweeping 64-query blocks (lane = query); needs delta
+template <int DT>
+__global__ __launch_bounds__(256) void attn_f32_bwd_dkv_kernel(const AF p) {
+  extern __shared__ float smem[];
+  const int L = p.L, H = p.H, D = p.D, S = row_stride(D), D4 = (D + 3) & ~3;
+  const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * RB;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const long ld = 3L * H * D, ldo = (long)H * D, row0 = (long)b * L;
+  float* Qs = smem;                        // [KB][S] q * q_scale
+  float* Gs = Qs + KB * S;                 // [KB][S] dO
+  float* Kr = Gs + KB * S;                 // [RB][S]
+  float* Vr = Kr + RB * S;                 // [RB][S]
+  float* Ps = Vr + RB * S;                 // [NW][KB][RW] P~
+  float* Ds = Ps + NW * KB * RW;           // [NW][KB][RW] dS
+  stage_rows(Kr, p.qkv + (long)(H + h) * D, ld, row0, k0, RB, L, D, S, 1.f, tid);
+  stage_rows(Vr, p.qkv + (long)(2 * H + h) * D, ld, row0, k0, RB, L, D, S, 1.f, tid);
+  bool kvalid[RW];
+  float dk[RW][DT], dv[RW][DT];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int key = k0 + w * RW + r;
+    kvalid[r] = key < L && (!p.key_mask || p.key_mask[row0 + key]);
+#pragma unroll
+    for (int t = 0; t < DT; ++t) { dk[r][t] = 0.f; dv[r][t] = 0.f; }
+  }
+  for (int q0 = 0; q0 < L; q0 += KB) {
+    __syncthreads();
+    stage_rows(Qs, p.qkv + (long)h * D, ld, row0, q0, KB, L, D, S, p.scale, tid);
+    stage_rows(Gs, p.dout + (long)h * D, ldo, row0, q0, KB, L, D, S, 1.f, tid);
+    __syncthreads();
+    const int q = q0 + lane;
+    const float lse = q < L ? p.lse[((long)b * H + h) * L + q] : -INFINITY;
+    const float delta = q < L ? p.delta[((long)b * H + h) * L + q] : 0.f;
+    float s[RW] = {0.f, 0.f, 0.f, 0.f}, dp[RW] = {0.f, 0.f, 0.f, 0.f};
+    dot4(Kr + w * RW * S, Qs + lane * S, S, D4, s);
+    dot4(Vr + w * RW * S, Gs + lane * S, S, D4, dp);
+    f32x4 pt, dst;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      const float pv = (kvalid[r] && lse != -INFINITY) ? expf(s[r] - lse) : 0.f;
+      const float dm = p.drop_thr ? drop_at(p, row0 + q, h, k0 + w * RW + r) : 1.f;
+      pt[r] = pv * dm;
+      dst[r] = pv * fmaf(dp[r], dm, -delta);
+    }
+    *reinterpret_cast<f32x4*>(Ps + (w * KB + lane) * RW) = pt;
+    *reinterpret_cast<f32x4*>(Ds + (w * KB + lane) * RW) = dst;
+    __syncthreads();
+    const int nq = L - q0 < KB ? L - q0 : KB;
+    for (int i = 0; i < nq; ++i) {
+      const f32x4 pi = *reinterpret_cast<const f32x4*>(Ps + (w * KB + i) * RW);
+      const f32x4 di = *reinterpret_cast<const f32x4*>(Ds + (w * KB + i) * RW);
+#pragma unroll
+      for (int t = 0; t < DT; ++t) {
+        const int d = lane + 64 * t;
+        const int dd = d < D ? d : 0;
+        const float g = Gs[i * S + dd], qv = Qs[i * S + dd];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+          dv[r][t] = fmaf(pi[r], g, dv[r][t]);
+          dk[r][t] = fmaf(di[r], qv, dk[r][t]);              // Qs holds q * q_scale: d s / d k
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int key = k0 + w * RW + r;
+    if (key >= L) continue;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      const int d = lane + 64 * t;
+      if (d < D) {
+        p.dqkv[(row0 + key) * ld + (long)(H + h) * D + d] = dk[r][t];
+        p.dqkv[(row0 + key) * ld + (long)(2 * H + h) * D + d] = dv[r][t];
+      }
+    }
+  }
+}
+
+size_t lds_fwd(int D) { return (size_t)(2 * KB * row_stride(D) + RB * row_stride(D) + NW * KB * RW) * 4; }
+size_t lds_dq(int D) { return (size_t)(2 * KB * row_stride(D) + 2 * RB * row_stride(D) + NW * KB * RW) * 4; }
+size_t lds_dkv(int D) { return (size_t)(2 * KB * row_stride(D) + 2 * RB * row_stride(D) + 2 * NW * KB * RW) * 4; }
+
+template <typename K>
+int launch(K kern, std::atomic<uint64_t>& once, const AF& p, size_t lds, hipStream_t st) {
+  clipk_once_per_device(once, [&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  const dim3 grid((unsigned)((p.L + RB - 1) / RB), (unsigned)p.H, (unsigned)p.B);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  return clipk_check_launch();
+}
+
+int set_dropout(AF& p, float dropout_p, unsigned seed) {
+  if (!(dropout_p >= 0.f) || dropout_p >= 1.f) return CLIPK_ERR_BAD_ARG;
+  p.drop_thr = 0; p.drop_seed = 0; p.drop_scale = 1.f;
+  if (dropout_p == 0.f) return CLIPK_OK;
+  const double t = (double)dropout_p * 4294967296.0;
+  p.drop_thr = t < 1.0 ? 1u : (t >= 4294967295.0 ? 4294967295u : (unsigned)t);
+  p.drop_seed = seed;
+  p.drop_scale = 1.0f / (1.0f - dropout_p);
+  return CLIPK_OK;
+}
+
+int check(const void* qkv, int B, int L, int H, int D) {
+  if (!qkv || B <= 0 || L <= 0 || H <= 0 || D <= 0) return CLIPK_ERR_BAD_ARG;
+  if (D > 192 || H > 65535 || B > 65535) return CLIPK_ERR_UNSUPPORTED;
+  if (!aligned16(qkv)) return CLIPK_ERR_BAD_ARG;
+  return CLIPK_OK;
+}
+
+}  // namespace
+
+extern "C" int clipk_attn_f32_fwd(const float* qkv, const uint8_t* key_mask, float* out, float* lse, int B, int L, int H,
+                                  int D, float q_scale, float dropout_p, uint32_t dropout_seed, void* stream) {
+  int rc = check(qkv, B, L, H, D);
+  if (rc) return rc;
+  if (!out || !lse) return CLIPK_ERR_BAD_ARG;
+  AF p{};
+  p.qkv = qkv; p.key_mask = key_mask; p.out = out; p.lse = lse; p.B = B; p.L = L; p.H = H; p.D = D; p.scale = q_scale;
+  rc = set_dropout(p, dropout_p, dropout_seed);
+  if (rc) return rc;
+  static std::atomic<uint64_t> o1{0}, o2{0}, o3{0};
+  hipStream_t st = (hipStream_t)stream;
+  if (D <= 64) return launch(attn_f32_fwd_kernel<1>, o1, p, lds_fwd(D), st);
+  if (D <= 128) return launch(attn_f32_fwd_kernel<2>, o2, p, lds_fwd(D), st);
+  return launch(attn_f32_fwd_kernel<3>, o3, p, lds_fwd(D), st);
+}
+
+extern "C" int clipk_attn_f32_bwd(const float* qkv, const uint8_t* key_mask, const float* out, const float* dout,
+                                  const float* lse, float* delta, float* dqkv, int B, int L, int H, int D, float q_scale,
+                                  float dropout_p, uint32_t dropout_seed, void* stream) {
+  int rc = check(qkv, B, L, H, D);
+  if (rc) return rc;
+  if (!out || !dout || !lse || !delta || !dqkv) return CLIPK_ERR_BAD_ARG;
+  AF p{};
+  p.qkv = qkv; p.key_mask = key_mask; p.out = const_cast<float*>(out); p.lse = const_cast<float*>(lse);
+  p.dout = dout; p.delta = delta; p.dqkv = dqkv; p.B = B; p.L = L; p.H = H; p.D = D; p.scale = q_scale;
+  rc = set_dropout(p, dropout_p, dropout_seed);
+  if (rc) return rc;
+  static std::atomic<uint64_t> a1{0}, a2{0}, a3{0}, b1{0}, b2{0}, b3{0};
+  hipStream_t st = (hipStream_t)stream;
+  if (D <= 64) {
+    rc = launch(attn_f32_bwd_dq_kernel<1>, a1, p, lds_dq(D), st);
+    return rc ? rc : launch(attn_f32_bwd_dkv_kernel<1>, b1, p, lds_dkv(D), st);
+  }
+  if (D <= 128) {
+    rc = launch(attn_f32_bwd_dq_kernel<2>, a2, p, lds_dq(D), st);
+    return rc ? rc : launch(attn_f32_bwd_dkv_kernel<2>, b2, p, lds_dkv(D), st);
+  }
+  rc = launch(attn_f32_bwd_dq_kernel<3>, a3, p, lds_dq(D), st);
+  return rc ? rc : launch(attn_f32_bwd_dkv_kernel<3>, b3, p, lds_dkv(D), st);
+}

@@ -114,6 +114,17 @@ __global__ void axpby_dev_kernel(const float* a, const float* b, const float* s,
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) y[i] = a[i] + sc * b[i];
 }
 
+// y = x * keep(seed, i) / (1 - p) (+ addend): nn.Dropout on an f32 tensor with the kernels' counter-based mask (index =
+// the element's row-major position), optionally followed by the residual add it sits in front of
+__global__ void dropout_f32_kernel(const float* x, const float* addend, float* y, long n, unsigned thr, unsigned seed,
+                                   float scale) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float v = x[i] * drop_mul(seed, (unsigned long long)i, thr, scale);
+    y[i] = addend ? v + addend[i] : v;
+  }
+}
+
 // out_bf16 = dy * act'(aux): the activation backward between two Linear layers (dy f32 or bf16)
 template <bool DYBF16>
 __global__ void dact_kernel(const void* dy, const unsigned short* aux, int act, unsigned short* out, long n) {
@@ -491,6 +502,16 @@ extern "C" int clipk_dact(const void* dy, int dy_dtype, const void* aux_bf16, in
 extern "C" int clipk_axpby_dev(const float* a, const float* b, const float* s, float* y, int64_t n, void* stream) {
   if (!a || !b || !s || !y || n <= 0) return CLIPK_ERR_BAD_ARG;
   hipLaunchKernelGGL(axpby_dev_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, a, b, s, y, (long)n);
+  return clipk_check_launch();
+}
+
+extern "C" int clipk_dropout_f32(const float* x, const float* addend, float* y, int64_t n, float p, uint32_t seed,
+                                 void* stream) {
+  if (!x || !y || n <= 0 || !(p >= 0.f) || p >= 1.f) return CLIPK_ERR_BAD_ARG;
+  const double t = (double)p * 4294967296.0;
+  const unsigned thr = p == 0.f ? 0u : (t < 1.0 ? 1u : (t >= 4294967295.0 ? 4294967295u : (unsigned)t));
+  hipLaunchKernelGGL(dropout_f32_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, x, addend, y,
+                     (long)n, thr, seed, 1.0f / (1.0f - p));
   return clipk_check_launch();
 }
 

@@ -205,7 +205,8 @@ def _esm_layer_ffn_fwd(x, x2, p, eps, keep, att):
     h1, m1, r1, qkv, ctx, lse = att
     _, h2, m2, r2 = ops.layernorm_fwd(x2, p["ln2_w"], p["ln2_b"], eps, want_f32=False, want_bf16=True)
     if keep:
-        g, u = ops.gemm_nt(h2, p["fc1"].wb, bias=p["fc1"].b, act="gelu", out_preact=True, aux_u8=GELU_AUX_U8)
+        g, u = ops.gemm_nt(h2, p["fc1"].wb, bias=p["fc1"].b, act="gelu", out_preact=True,
+                           aux_u8=GELU_AUX_U8 and ops.gelu_aux_u8_applies(h2.shape[1], p["fc1"].wb.shape[0]))
     else:                                                  # frozen encoder: nothing is kept for a backward
         g, u = ops.gemm_nt(h2, p["fc1"].wb, bias=p["fc1"].b, act="gelu"), None
     y = ops.gemm_nt(g, p["fc2"].wb, bias=p["fc2"].b, residual=x2, out_dtype=torch.float32)
@@ -544,7 +545,8 @@ def _post_layer_fwd(x, xb, p, meta, dr=None):
         x1, x1b, m1, r1 = ops.layernorm_fwd(s1, p["n1_w"], p["n1_b"], eps, want_f32=True, want_bf16=True)
     if act == "gelu":
         g, u = ops.gemm_nt(x1b, p["fc1"].wb, bias=p["fc1"].b, act="gelu", out_preact=True, dropout=df,
-                           aux_u8=GELU_AUX_U8 and df is None)
+                           aux_u8=GELU_AUX_U8 and df is None
+                           and ops.gelu_aux_u8_applies(x1b.shape[1], p["fc1"].wb.shape[0]))
     else:
         g = ops.gemm_nt(x1b, p["fc1"].wb, bias=p["fc1"].b, act="relu", dropout=df)
         u = g                                    # relu'(pre) == relu'(relu(pre)); a dropped element has g = 0 either way
@@ -692,13 +694,22 @@ class TransformerSeqEncoder(nn.Module):
     """
 
     grad_bucket = True          # see ESM2Encoder
+    takes_precision = True      # KF.set_linear_precision reaches this stack
 
     def __init__(self, embed_dim=768, num_layers=6, nhead=8, dim_feedforward=2048, activation="gelu",
-                 layer_norm_eps=1e-12, final_eps=None, dropout: float = 0.0, residual_dtype: str = "bf16"):
+                 layer_norm_eps=1e-12, final_eps=None, dropout: float = 0.0, residual_dtype: str = "bf16",
+                 precision: str = "bf16"):
         super().__init__()
         if residual_dtype not in ("bf16", "f32"):
             raise ValueError(f"residual_dtype must be 'bf16' or 'f32', got {residual_dtype!r}")
+        if precision not in ("bf16", "f32"):
+            raise ValueError(f"precision must be 'bf16' or 'f32', got {precision!r}")
         self.residual_dtype = residual_dtype
+        # "bf16": bf16-MFMA GEMMs / attention, f32 statistics (the north-star arithmetic of the BASELINE towers).
+        # "f32": every Linear on the exact-f32 MFMA GEMM, attention on attention_f32.hip, f32 LayerNorms and residual
+        # adds - the arithmetic of the reference's un-autocast callers (rna_clip_codes.ipynb:2061-2089); the default of
+        # the position-0-pooled notebook / tri-modal models, whose encoders see B rows once the dead positions are gone.
+        self.precision = precision
         self.embed_dim, self.num_layers, self.nhead = embed_dim, num_layers, nhead
         # nn.TransformerEncoderLayer's dropout (rna_clip_codes.ipynb:1915 uses 0.1): attention probabilities, out_proj
         # output, FFN activation, linear2 output.  In training mode each site draws a counter-based mask inside the
@@ -743,11 +754,43 @@ class TransformerSeqEncoder(nn.Module):
         """Masked mean over the positions of forward()'s output, [B, E]: final LayerNorm + mean in one kernel."""
         return self.forward(x, src_key_padding_mask, _pool=True)
 
+    def _forward_f32(self, x, mask_u8, B, L, drop, pool_out):
+        """The stack in exact f32 (precision = "f32"): per layer qkv Linear -> attention -> out_proj + residual ->
+        LayerNorm -> linear1 -> activation -> linear2 + residual -> LayerNorm, every product on clipk_gemm_f32 (residual
+        adds in its epilogue) and clipk_attn_f32_*; un-padded head dim (120 / 8 = 15 runs as it is).  Dropout sites and
+        mask indices are those of the bf16 stack (same seeds -> same dropped elements)."""
+        E, H = self.embed_dim, self.nhead
+        D = E // H
+        h = x.reshape(B * L, E).float().contiguous()
+        for i, l in enumerate(self.layers):
+            a = l.self_attn
+            dr = None if drop is None else [(drop[0], sd) for sd in drop[1][i]]      # attn, drop1, ffn, drop2
+            qkv = KF.linear_f32(h, a.in_proj_weight, a.in_proj_bias)
+            ctx = KF.attention_f32(qkv, B, L, H, D, mask_u8, float(D) ** -0.5, dr[0] if dr else None)
+            if dr:
+                s1 = KF.dropout_f32(KF.linear_f32(ctx, a.out_proj.weight, a.out_proj.bias), dr[1], addend=h)
+            else:
+                s1 = KF.linear_f32(ctx, a.out_proj.weight, a.out_proj.bias, addend=h)
+            x1 = KF.layer_norm(s1, l.norm1.weight, l.norm1.bias, self.eps)
+            g = KF.ActFn.apply(KF.linear_f32(x1, l.linear1.weight, l.linear1.bias), self.activation)
+            if dr:
+                g = KF.dropout_f32(g, dr[2])
+                s2 = KF.dropout_f32(KF.linear_f32(g, l.linear2.weight, l.linear2.bias), dr[3], addend=x1)
+            else:
+                s2 = KF.linear_f32(g, l.linear2.weight, l.linear2.bias, addend=x1)
+            h = KF.layer_norm(s2, l.norm2.weight, l.norm2.bias, self.eps)
+        y = KF.layer_norm(h, self.layernorm.weight, self.layernorm.bias, self.final_eps).view(B, L, E)
+        if pool_out:
+            return pool(y, None if mask_u8 is None else mask_u8.view(B, L), "mean")
+        return y
+
     def forward(self, x, src_key_padding_mask=None, _pool=False):
         B, L, E = x.shape
         mask_u8 = None
         if src_key_padding_mask is not None:
             mask_u8 = (~src_key_padding_mask.bool()).to(torch.uint8).contiguous()      # kernels take 1 = valid
+        if self.precision == "f32":
+            return self._forward_f32(x, mask_u8, B, L, self._draw_dropout(), bool(_pool))
         y = PostLNStackFn.apply(self, x.reshape(B * L, E), mask_u8, B, L, None, self._draw_dropout(), bool(_pool),
                                 *self._flat_params())
         return y if _pool else y.view(B, L, E)
@@ -766,6 +809,9 @@ class TransformerSeqEncoder(nn.Module):
         key-padding mask, row for row, without any padded row going through a kernel."""
         T, E = x.shape
         B = cu_seqlens.numel() - 1
+        if self.precision == "f32":
+            raise NotImplementedError("packed variable-length batches run on the bf16 kernels only (precision='bf16'): "
+                                      "the exact-f32 attention kernels take padded [B, L] batches")
         return PostLNStackFn.apply(self, x, None, B, int(max_len), (cu_seqlens.contiguous(), int(max_len)),
                                    self._draw_dropout(), False, *self._flat_params())
 

@@ -22,6 +22,11 @@ def mark_weights_dirty() -> None:
     _WEIGHT_EPOCH += 1
 
 
+def weight_epoch() -> int:
+    """Counter of out-of-band parameter updates (mark_weights_dirty): part of every derived-operand cache key."""
+    return _WEIGHT_EPOCH
+
+
 def _cache_key(w: torch.Tensor, version=None):
     """Identity + version of a master weight.  For a fused zero-copy view of several Parameters (ESM's qkv:
     torch.as_strided of the flat buffer, whose own _version never moves) the caller passes the sum of the source
@@ -34,18 +39,26 @@ def _cache_key(w: torch.Tensor, version=None):
 class WeightCache:
     """bf16 W [N,K] and W^T [K,N] of an f32 master weight, refreshed lazily (or all at once, refresh_weight_caches)."""
 
-    __slots__ = ("wb", "wtb", "key", "src", "src_version", "__weakref__")
+    __slots__ = ("wb", "wtb", "key", "src", "src_version", "derived", "__weakref__")
 
     def __init__(self):
         self.wb = self.wtb = None
         self.key = None
         self.src = None                      # the master weight this cache was last built from
         self.src_version = None              # callable -> version token of a fused view's source Parameters (or None)
+        self.derived = False                 # src is a per-call COPY (torch.cat / pad of Parameters), not their storage
         _CACHES.add(self)
 
     def get(self, w: torch.Tensor, version_fn=None):
         self.src_version = version_fn
-        key = _cache_key(w, None if version_fn is None else version_fn())
+        ver = None if version_fn is None else version_fn()
+        # A version_fn operand is either a zero-copy view of its source Parameters (ESM's fused qkv: same storage, the
+        # batched refresh may re-read it) or a copy rebuilt per call (cat / pad): the copy of an EARLIER call holds
+        # earlier weights, so refresh_weight_caches must never rebuild from it (ADVICE r03: a no_grad forward left a
+        # leaf copy in `src`, the next optimiser step refreshed from it and stamped the new key on stale data).
+        self.derived = ver is not None and w.data_ptr() not in {v[0] for v in ver if isinstance(v, tuple)}
+        key = _cache_key(w, ver)
+        self.src = w                         # always the operand of THIS call, hit or miss
         if key != self.key:
             src = w.detach()
             if not src.is_contiguous():
@@ -61,20 +74,28 @@ _CACHES = weakref.WeakSet()
 _BATCH_DESC = {}                             # (device, pointer tuple) -> int64 [n, 5] device descriptor table
 
 
-def refresh_weight_caches() -> int:
-    """Rebuild every stale bf16 copy in ONE kernel launch on the current stream.  Called by FusedAdamW.step() right
-    after the update: the lazy path costs one launch per weight (76 in the config-2 model) at the next forward.
-    Covers caches that already have their buffers and a contiguous leaf master weight; the rest stay lazy."""
+def _stale_caches(require_cuda: bool = True):
+    """(cache, master weight, new key) of every cache the batched refresh may rebuild: buffers in place, a contiguous
+    leaf master weight that IS the parameters' storage (never a per-call copy: `derived`), key out of date."""
     todo = []
     for c in list(_CACHES):
         w = c.src
-        if w is None or c.wb is None or c.wtb is None or not w.is_cuda or not w.is_leaf or not w.is_contiguous():
+        if w is None or c.derived or c.wb is None or c.wtb is None or (require_cuda and not w.is_cuda) \
+                or not w.is_leaf or not w.is_contiguous():
             continue
         if w.dim() != 2 or c.wb.shape != w.shape:
             continue
         key = _cache_key(w, None if c.src_version is None else c.src_version())
         if key != c.key:
             todo.append((c, w, key))
+    return todo
+
+
+def refresh_weight_caches() -> int:
+    """Rebuild every stale bf16 copy in ONE kernel launch on the current stream.  Called by FusedAdamW.step() right
+    after the update: the lazy path costs one launch per weight (76 in the config-2 model) at the next forward.
+    Covers caches that already have their buffers and a contiguous leaf master weight; the rest stay lazy."""
+    todo = _stale_caches()
     if not todo:
         return 0
     by_dev = {}
@@ -135,15 +156,17 @@ class LinearFn(torch.autograd.Function):
 
 
 class LinearF32Fn(torch.autograd.Function):
-    """y = x W^T + b in EXACT f32 (clipk_gemm_f32: f32-input MFMA, bitwise an fmaf chain) — the arithmetic of the
-    reference's own fp32 callers (old/ablation.py:9-18 runs old/clip.py without autocast).  Opt-in per Linear
+    """y = x W^T + b (+ addend) in EXACT f32 (clipk_gemm_f32: f32-input MFMA, bitwise an fmaf chain) — the arithmetic of
+    the reference's own fp32 callers (old/ablation.py:9-18 runs old/clip.py without autocast; the notebook models of
+    rna_clip_codes.ipynb:1925-1954 likewise).  `addend` [M, N]: the residual the Linear's output is added to
+    (x + out_proj(ctx), x + linear2(h) of nn.TransformerEncoderLayer) in the GEMM's epilogue.  Opt-in per Linear
     (`KLinear.precision = "f32"`, `set_linear_precision`); the bf16-MFMA LinearFn is the default."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, addend=None):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return ops.gemm_f32(x, weight, bias=bias)
+        return ops.gemm_f32(x, weight, bias=bias, addend=None if addend is None else addend.contiguous())
 
     @staticmethod
     def backward(ctx, dy):
@@ -154,7 +177,55 @@ class LinearF32Fn(torch.autograd.Function):
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.pool_fwd(dy, 1, dy.shape[0], None, 1).reshape(-1) * float(dy.shape[0])   # column sum
-        return dx, dw, db
+        return dx, dw, db, (dy if len(ctx.needs_input_grad) > 3 and ctx.needs_input_grad[3] else None)
+
+
+def linear_f32(x, weight, bias=None, addend=None):
+    """Exact-f32 Linear on 2-D rows (+ fused residual add)."""
+    return LinearF32Fn.apply(x.float().contiguous(), weight, bias, addend)
+
+
+class AttnF32Fn(torch.autograd.Function):
+    """Self-attention on a fused f32 qkv tensor [B*L, 3*H*D] -> [B*L, H*D] in exact f32 (attention_f32.hip)."""
+
+    @staticmethod
+    def forward(ctx, qkv, B, L, H, D, key_mask, q_scale, dropout):
+        qkv = qkv.contiguous()
+        out, lse = ops.attn_f32_fwd(qkv, B, L, H, D, key_mask=key_mask, q_scale=q_scale, dropout=dropout)
+        ctx.meta = (B, L, H, D, key_mask, q_scale, dropout)
+        ctx.save_for_backward(qkv, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        B, L, H, D, key_mask, q_scale, dropout = ctx.meta
+        dqkv = ops.attn_f32_bwd(qkv, out, dout.contiguous(), lse, B, L, H, D, key_mask=key_mask, q_scale=q_scale,
+                                dropout=dropout)
+        return dqkv, None, None, None, None, None, None, None
+
+
+def attention_f32(qkv, B, L, H, D, key_mask=None, q_scale=1.0, dropout=None):
+    return AttnF32Fn.apply(qkv, B, L, H, D, key_mask, q_scale, dropout)
+
+
+class DropoutF32Fn(torch.autograd.Function):
+    """x * keep / (1 - p) (+ addend) with the kernels' counter-based mask (nothing stored: the backward re-draws it)."""
+
+    @staticmethod
+    def forward(ctx, x, dropout, addend=None):
+        ctx.dropout = dropout
+        return ops.dropout_f32(x.contiguous(), dropout, None if addend is None else addend.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = ops.dropout_f32(dy, ctx.dropout) if ctx.needs_input_grad[0] else None
+        return dx, None, (dy if len(ctx.needs_input_grad) > 2 and ctx.needs_input_grad[2] else None)
+
+
+def dropout_f32(x, dropout, addend=None):
+    return DropoutF32Fn.apply(x, dropout, addend)
 
 
 def params_version(*params):
@@ -168,7 +239,7 @@ def linear(x, weight, bias, cache: WeightCache, act=None, out_dtype=torch.float3
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])
     if precision == "f32":
-        y = LinearF32Fn.apply(x2.float().contiguous(), weight, bias)
+        y = LinearF32Fn.apply(x2.float().contiguous(), weight, bias, None)
         if act is not None:
             y = ActFn.apply(y, act)                       # (out_dtype is a bf16-path hint: an f32 Linear stays f32)
     else:
@@ -177,13 +248,15 @@ def linear(x, weight, bias, cache: WeightCache, act=None, out_dtype=torch.float3
 
 
 def set_linear_precision(module: torch.nn.Module, precision: str = "bf16") -> torch.nn.Module:
-    """Select the arithmetic of every kernel-backed Linear under `module`: "bf16" (default: bf16 operands, f32
-    accumulate, the north-star arithmetic) or "f32" (exact-f32 MFMA: the MLP towers and heads of old/clip.py then
-    reproduce the reference's fp32 forward to ~1e-6).  Transformer stacks keep their bf16 GEMMs."""
+    """Select the arithmetic of every kernel-backed Linear under `module`: "bf16" (default of the BASELINE towers: bf16
+    operands, f32 accumulate, the north-star arithmetic) or "f32" (exact-f32 MFMA: the MLP towers and heads of
+    old/clip.py then reproduce the reference's fp32 forward to ~1e-6).  Post-LN transformer stacks
+    (`TransformerSeqEncoder`) follow: "f32" runs their Linears, attention, LayerNorms and residual adds in f32
+    (attention_f32.hip) - the default of the position-0-pooled notebook / tri-modal models.  The ESM-2 stack is bf16 only."""
     if precision not in ("bf16", "f32"):
         raise ValueError(f"precision must be 'bf16' or 'f32', got {precision!r}")
     for m in module.modules():
-        if hasattr(m, "_cache") and isinstance(m, torch.nn.Linear):
+        if (hasattr(m, "_cache") and isinstance(m, torch.nn.Linear)) or getattr(m, "takes_precision", False):
             m.precision = precision
     return module
 

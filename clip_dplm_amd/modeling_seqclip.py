@@ -37,32 +37,47 @@ class RNARBPCLIPProjectionHead(OptimizedProjectionHead):
 
 
 class RNARBPCLIPEncoder(TransformerSeqEncoder):
-    """rna_clip_codes.ipynb:1911-1923: 3 x nn.TransformerEncoderLayer(d, nhead=8, ffn=4d) + LayerNorm."""
+    """rna_clip_codes.ipynb:1911-1923: 3 x nn.TransformerEncoderLayer(d, nhead=8, ffn=4d) + LayerNorm.
+    precision: "f32" (default: the notebook trains it without autocast, ipynb:2061-2089) or "bf16" (bf16-MFMA kernels)."""
 
-    def __init__(self, embed_dim, num_layers=3, dropout: float = 0.1):
+    def __init__(self, embed_dim, num_layers=3, dropout: float = 0.1, precision: str = "f32"):
         # position-0 pooling (no averaging over rows): keep the residual stream in f32 (encoders.POSTLN_BF16_RESIDUAL)
         super().__init__(embed_dim=embed_dim, num_layers=num_layers, nhead=8, dim_feedforward=embed_dim * 4,
-                         activation="relu", layer_norm_eps=1e-5, final_eps=1e-5, dropout=dropout, residual_dtype="f32")
+                         activation="relu", layer_norm_eps=1e-5, final_eps=1e-5, dropout=dropout, residual_dtype="f32",
+                         precision=precision)
 
 
 class RNARBPCLIPModel(nn.Module):
-    """rna_clip_codes.ipynb:1925-1954."""
+    """rna_clip_codes.ipynb:1925-1954.
 
-    def __init__(self, rna_dim=120, rbp_dim=1280, projection_dim=512, dropout: float = 0.1):
+    MI355X-first treatment of the model's batch-axis attention: the notebook hands [B, L, D] to
+    batch_first=False layers, so attention mixes the B samples AT EACH POSITION, the FFN / LayerNorms are per token, and
+    only `enc[:, 0]` is read (ipynb:1944-1949) - positions 1 .. L-1 (up to 2541 of 2542) never reach the embeddings, the
+    loss or any parameter gradient.  `_encode` therefore slices to position 0 BEFORE the encoder (exact: same embeds, loss
+    and gradients; `RNARBPCLIPEncoder.forward` itself still returns every position it is given), and with B rows left
+    the whole model runs in exact f32 by default (`precision="f32"`: the reference trains it in fp32; a bf16-rounded
+    weight alone moved the loss by 2e-3, DESIGN.md §3.3).  `precision="bf16"` keeps the bf16-MFMA kernels;
+    `slice_first_position=False` encodes every position as the notebook does (tests compare the two)."""
+
+    def __init__(self, rna_dim=120, rbp_dim=1280, projection_dim=512, dropout: float = 0.1, precision: str = "f32",
+                 slice_first_position: bool = True):
         super().__init__()
         # `dropout` is the notebook's nn.TransformerEncoderLayer default (0.1): in train() mode the post-LN stack
         # applies it at the layer's four sites with counter-based masks (TransformerSeqEncoder, DESIGN.md §5); parity
         # and benchmark runs use eval() or dropout=0.0.
-        self.rna_encoder = RNARBPCLIPEncoder(rna_dim, dropout=dropout)
-        self.rbp_encoder = RNARBPCLIPEncoder(rbp_dim, dropout=dropout)
+        self.rna_encoder = RNARBPCLIPEncoder(rna_dim, dropout=dropout, precision=precision)
+        self.rbp_encoder = RNARBPCLIPEncoder(rbp_dim, dropout=dropout, precision=precision)
         self.rna_projection = RNARBPCLIPProjectionHead(rna_dim, projection_dim)
         self.rbp_projection = RNARBPCLIPProjectionHead(rbp_dim, projection_dim)
         self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
+        self.slice_first_position = bool(slice_first_position)
+        KF.set_linear_precision(self, precision)
 
-    @staticmethod
-    def _encode(encoder, emb):
+    def _encode(self, encoder, emb):
         # The notebook hands (B, L, D) to batch_first=False layers with the mask transposed to (L, B): attention
         # mixes the B samples at each position.  Same arithmetic here: positions become the kernel's batch axis.
+        if self.slice_first_position:
+            emb = emb[:, :1]                                              # position 0 is all `enc[:, 0]` depends on
         valid = create_padding_mask(emb)                                  # [B, L]
         x = torch.nan_to_num(emb, 0.0).transpose(0, 1).contiguous()       # [L, B, D]
         y = encoder(x, src_key_padding_mask=~valid.transpose(0, 1))       # keys = samples

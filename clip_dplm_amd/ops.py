@@ -193,6 +193,15 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
     return (c, pre) if out_preact else c
 
 
+def gelu_aux_u8_applies(k_in: int, n_ffn: int) -> bool:
+    """Shapes for which the 8-bit GELU' code can be the FFN pair's saved operand: the specialised epilogues need the
+    LDS-DMA main loop (K % 32 == 0; the generic-K kernel returns CLIPK_ERR_UNSUPPORTED for CLIPK_U8, gemm_nt.hip) and
+    code rows of whole 8-byte chunks (ldp / ldd % 8 == 0).  Both GEMMs of the pair - fc1 forward [M, n_ffn] and the
+    fc2 input gradient [M, n_ffn] - contract over k_in = the model width.  Other widths (the notebook's 120) keep the
+    bf16 pre-activation."""
+    return k_in % 32 == 0 and n_ffn % 8 == 0
+
+
 def gemm_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: Optional[torch.Tensor] = None,
                dbias: Optional[torch.Tensor] = None, accumulate: bool = False, want_bias: bool = False):
     """dW[N,K] (+)= dy[M,N]^T @ x[M,K] (f32), optionally db[N] = colsum(dy)."""
@@ -629,6 +638,42 @@ def attn_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=None, rope=None, q_scale=
                                                H, D, float(q_scale), int(bool(prerotated)), *_drop(dropout),
                                                _stream())), "clipk_attn_bwd")
     return dqkv
+
+
+def attn_f32_fwd(qkv, B, L, H, D, key_mask=None, q_scale=1.0, dropout=None):
+    """Exact-f32 self-attention (clipk_attn_f32_fwd): qkv f32 [B*L, 3*H*D] -> out f32 [B*L, H*D], lse f32 [B, H, L]."""
+    _need_cuda(qkv, key_mask)
+    assert qkv.dtype == torch.float32 and qkv.is_contiguous() and qkv.shape == (B * L, 3 * H * D)
+    out = torch.empty((B * L, H * D), dtype=torch.float32, device=qkv.device)
+    lse = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
+    check(_timed("attn_f32_fwd", 4.0 * B * H * L * L * D,
+                 lambda: _lib().clipk_attn_f32_fwd(qkv.data_ptr(), ptr(key_mask), out.data_ptr(), lse.data_ptr(), B, L, H,
+                                                   D, float(q_scale), *_drop(dropout), _stream())), "clipk_attn_f32_fwd")
+    return out, lse
+
+
+def attn_f32_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=None, q_scale=1.0, dropout=None):
+    _need_cuda(qkv, out, dout, lse, key_mask)
+    assert qkv.dtype == torch.float32 and dout.dtype == torch.float32 and dout.is_contiguous() and out.is_contiguous()
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
+    check(_timed("attn_f32_bwd", 14.0 * B * H * L * L * D,
+                 lambda: _lib().clipk_attn_f32_bwd(qkv.data_ptr(), ptr(key_mask), out.data_ptr(), dout.data_ptr(),
+                                                   lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), B, L, H, D,
+                                                   float(q_scale), *_drop(dropout), _stream())), "clipk_attn_f32_bwd")
+    return dqkv
+
+
+def dropout_f32(x, dropout, addend=None):
+    """x * keep / (1 - p) (+ addend) with the kernels' counter-based mask over x's row-major element index."""
+    _need_cuda(x, addend)
+    assert x.dtype == torch.float32 and x.is_contiguous() and (addend is None or (addend.is_contiguous() and
+                                                                                  addend.shape == x.shape))
+    y = torch.empty_like(x)
+    p_, seed = _drop(dropout)
+    check(_lib().clipk_dropout_f32(x.data_ptr(), ptr(addend), y.data_ptr(), x.numel(), p_, seed, _stream()),
+          "clipk_dropout_f32")
+    return y
 
 
 def attn_varlen_fwd(qkv, cu_seqlens, max_len, H, D, rope=None, q_scale=1.0, dropout=None):

@@ -313,6 +313,26 @@ int clipk_attn_fwd_rot(void* qkv, const uint8_t* key_mask, const float* rope_cos
                        void* out, float* lse, int B, int L, int H, int D, float q_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Exact-f32 multi-head self-attention (f32 q / k / v, f32 scores, f32 softmax, f32 P·V; VALU fmas in a fixed order) for
+ * the models the reference runs WITHOUT autocast: nn.MultiheadAttention inside the nn.TransformerEncoderLayer stacks of
+ * RNARBPCLIPModel (current/rna_clip_codes.ipynb:1911-1954) and of the tri-modal ContrastiveModel
+ * (current/tf_clip_codes (1).ipynb:13056-13072,13113-13176).  Layouts as clipk_attn_fwd / clipk_attn_bwd with f32
+ * tensors: qkv [B*L, 3*H*D], out / dout [B*L, H*D], dqkv [B*L, 3*H*D], lse / delta [B, H, L]; key_mask u8 [B, L]
+ * (1 = valid) or NULL; same dropout mask (hash, element index) as the bf16 kernels.  Any D in 1..192 (no multiple-of-8
+ * rule: the notebook's 120 / 8 = 15 runs unpadded).  A row whose keys are all masked gives a zero output row and
+ * lse = -inf, as clipk_attn_fwd. */
+int clipk_attn_f32_fwd(const float* qkv, const uint8_t* key_mask, float* out, float* lse, int B, int L, int H, int D,
+                       float q_scale, float dropout_p, uint32_t dropout_seed, void* stream);
+int clipk_attn_f32_bwd(const float* qkv, const uint8_t* key_mask, const float* out, const float* dout, const float* lse,
+                       float* delta /* scratch [B,H,L] */, float* dqkv, int B, int L, int H, int D, float q_scale,
+                       float dropout_p, uint32_t dropout_seed, void* stream);
+/* y[i] = x[i] * keep(seed, i) / (1 - p) (+ addend[i]): nn.Dropout on an f32 tensor (out_proj / linear2 outputs in front
+ * of their residual add, the FFN activation: nn.TransformerEncoderLayer(dropout = p), rna_clip_codes.ipynb:1915) with
+ * the counter-based mask of the GEMM epilogues (element index = row-major position); the backward is the same call on
+ * the gradient.  addend may be NULL; y may alias x. */
+int clipk_dropout_f32(const float* x, const float* addend, float* y, int64_t n, float p, uint32_t seed, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Token embedding (ESM-2): x[t,:] = table[ids[t],:] * scale[b] * mask[t], with the token-dropout
  * rescale (modeling_esm.py:252-268) folded into row_scale[B] by the caller.  f32 out.
  */

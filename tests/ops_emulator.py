@@ -68,6 +68,10 @@ def gelu_grad_code(x):
 
 def gemm_nt(a, b, bias=None, act=None, out_dtype=BF, residual=None, out_preact=False, dact_aux=None, dact=None,
             alpha=1.0, out=None, dropout=None, rope=None, aux_u8=False):
+    aux8 = bool(aux_u8 and out_preact) or (dact_aux is not None and dact_aux.dtype == torch.uint8)
+    if aux8 and (a.shape[1] % 32 or b.shape[0] % 8):      # as the kernels: generic-K GEMM has no 8-bit aux (gemm_nt.hip)
+        raise RuntimeError("clipk_gemm_nt failed: unsupported shape for the gfx950 kernels (emulated: u8 aux needs "
+                           "K % 32 == 0 and N % 8 == 0)")
     v = (a.float() @ b.float().t()) * alpha
     if bias is not None:
         v = v + bias
@@ -96,6 +100,10 @@ def gemm_nt(a, b, bias=None, act=None, out_dtype=BF, residual=None, out_preact=F
         out.copy_(c)
         c = out
     return (c, pre) if out_preact else c
+
+
+def gelu_aux_u8_applies(k_in, n_ffn):
+    return k_in % 32 == 0 and n_ffn % 8 == 0
 
 
 def gemm_wgrad(dy, x, dw=None, dbias=None, accumulate=False, want_bias=False):
@@ -397,6 +405,24 @@ def attn_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=None, rope=None, q_scale=
             o, _ = _attn_math(q, B, L, H, D, key_mask, rope, q_scale, dropout, row0, Lstride)
             g, = torch.autograd.grad(o, q, dout.float())
     return g.to(BF)
+
+
+def attn_f32_fwd(qkv, B, L, H, D, key_mask=None, q_scale=1.0, dropout=None):
+    o, lse = _attn_math(qkv, B, L, H, D, key_mask, None, q_scale, dropout)
+    return torch.nan_to_num(o, nan=0.0), lse               # kernels: a fully masked row gives zeros
+
+
+def attn_f32_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=None, q_scale=1.0, dropout=None):
+    with torch.enable_grad():
+        q = qkv.detach().requires_grad_(True)
+        o, _ = _attn_math(q, B, L, H, D, key_mask, None, q_scale, dropout)
+        g, = torch.autograd.grad(o, q, dout)
+    return g
+
+
+def dropout_f32(x, dropout, addend=None):
+    y = x * drop_mult(dropout[0], dropout[1], torch.arange(x.numel(), dtype=torch.int64).view(x.shape))
+    return y if addend is None else y + addend
 
 
 def _segments(cu):

@@ -311,14 +311,12 @@ def test_c5_icnn_factory_dims_vs_oracle(dev, B):
 
 # ------------------------------------------------------------------------------ the notebook model at its own dims
 def test_notebook_model_at_its_own_dims_vs_oracle(dev):
-    """VERDICT r02 #3a / missing #5: the ONE variant the reference trained (current/rna_clip_codes.ipynb:2312-2360:
-    71,646,299 parameters, RNA features [32, L, 120] -> head dim 15 (zero-padded to 16 in the kernels), RBP features
-    [32, 557-2542, 1280] -> head dim 160, 3 post-LN layers each, projection 512) at B = 32 with L_rbp = 600 and ragged
-    NaN padding, against the CPU oracle (pinned to the reference by notebook_model(_b32).npz at reduced widths): loss and
-    gradient directions at both ends of both towers.  Loss bars: 1e-3 against the oracle on the bf16-ROUNDED weights (what
-    the kernels do: activation rounding, summation order) and 2e-3 against the oracle on the f32 weights: the rounding of
-    the weights perturbs the model itself, identically for every sample, and this model pools ONE position - nothing
-    averages it; measured over six seeds / batch sizes 32 - 128: 4e-5 .. 1.05e-3 (profiles/r03/notebook_parity_*.txt)."""
+    """the ONE variant the reference trained (current/rna_clip_codes.ipynb:2312-2360: 71,646,299 parameters,
+    RNA features [32, L, 120] -> head dim 15, RBP features [32, 557-2542, 1280] -> head dim 160, 3 post-LN layers each,
+    projection 512) at B = 32 with L_rbp = 600 and ragged NaN padding, against the CPU oracle computing EVERY position as
+    the notebook does (pinned to the reference by notebook_model(_b32).npz at reduced widths).  The product slices to
+    position 0 and runs in exact f32: loss at the north-star bar 1e-3 (measured ~1e-6), embeddings and gradients at f32
+    level.  The optional bf16 kernels are printed beside it as a diagnostic (round 3: 1.3e-4 .. 1.05e-3 over six seeds)."""
     import clip_dplm_amd as K
     from oracle import model_ref
     torch.manual_seed(0)
@@ -346,17 +344,18 @@ def test_notebook_model_at_its_own_dims_vs_oracle(dev):
     oa, ob, ref = model_ref.rnarbp_clip_forward(sdr, rna, rbp)
     ref.backward()
     err = abs(loss.item() - ref.item())
-    from test_gpu_models import bf16_weights
+    mb = K.RNARBPCLIPModel(rna_dim=120, rbp_dim=1280, projection_dim=512, precision="bf16").eval()
+    mb.load_state_dict(sd)
+    mb = mb.to(dev)
     with torch.no_grad():
-        _, _, lw = model_ref.rnarbp_clip_forward(bf16_weights(sd), rna, rbp)
-    errw = abs(loss.item() - lw.item())
-    print(f"notebook own dims: loss_gpu={loss.item():.6f} loss_oracle={ref.item():.6f} |diff|={err:.2e}; vs the oracle on "
-          f"bf16-rounded weights |diff|={errw:.2e}")
-    assert errw < 1e-3, errw
-    assert err < 2e-3, err
-    assert (ea.cpu() - oa.detach()).abs().max().item() < 0.02 and (eb.cpu() - ob.detach()).abs().max().item() < 0.02
+        _, _, lb = mb(rna.to(dev), rbp.to(dev))
+    print(f"notebook own dims: loss_gpu={loss.item():.6f} loss_oracle={ref.item():.6f} |diff|={err:.2e}; optional bf16 "
+          f"kernels (diagnostic) |diff|={abs(lb.item() - ref.item()):.2e}")
+    assert err < 1e-4, err                                                       # bar: 1e-3
+    assert (ea.cpu() - oa.detach()).abs().max().item() < 1e-4 and (eb.cpu() - ob.detach()).abs().max().item() < 1e-4
     got = dict(m.named_parameters())
     for n in names:
-        c = _cos(got[n].grad, sdr[n].grad) if n != "logit_scale" else 1.0
-        assert c > 0.99, (n, c)
-    assert abs(got["logit_scale"].grad.item() - sdr["logit_scale"].grad.item()) < 0.05 * abs(sdr["logit_scale"].grad.item()) + 1e-4
+        r = sdr[n].grad
+        e = (got[n].grad.cpu() - r).abs().max().item() / max(r.abs().max().item(), 1e-12)
+        assert e < 1e-3, (n, e)
+    assert abs(lb.item() - ref.item()) < 2e-2

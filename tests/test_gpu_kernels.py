@@ -1048,3 +1048,85 @@ def test_layernorm_second_order_backward_vs_autograd(dev, rows, cols, act):
     ops.layernorm_bwd2(g.to(dev), dy.to(dev), a.to(dev), gamma.to(dev), beta.to(dev), mean, rstd, act=act, dgamma=dg0,
                        dbeta=db0, accumulate=True)
     assert torch.allclose(dg0, d_gamma + 1.0, rtol=1e-5, atol=1e-5) and torch.allclose(db0, d_beta + 2.0, rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ exact-f32 attention
+@pytest.mark.parametrize("B,L,H,D,use_mask", [
+    (1, 32, 8, 15, False),      # the notebook's RNA tower after the position-0 slice: one "sequence" of B = 32, 120 / 8
+    (1, 32, 8, 160, False),     # its RBP tower: 1280 / 8
+    (1, 64, 8, 64, True),       # tri-modal encoders (512 / 8), isolated cells masked as keys
+    (3, 130, 4, 96, True),      # several sequences, > 2 key blocks, ragged tail
+    (2, 300, 2, 24, True),
+    (5, 1, 3, 8, False),        # a single key
+    (2, 77, 2, 192, False),     # the largest head dim
+])
+def test_attention_f32_fwd_bwd_vs_f64(dev, B, L, H, D, use_mask):
+    """clipk_attn_f32_fwd / _bwd against f64 torch on the same inputs: output, lse and dqkv at f32 rounding level."""
+    from clip_dplm_amd import ops
+    g = torch.Generator().manual_seed(L * 7 + D)
+    qkv = torch.randn(B * L, 3 * H * D, generator=g).to(dev)
+    dout = torch.randn(B * L, H * D, generator=g).to(dev)
+    mask = None
+    if use_mask:
+        lens = torch.randint(max(1, L // 3), L + 1, (B,), generator=g)
+        mask = (torch.arange(L)[None] < lens[:, None])
+        mask[0, :] = True
+        if L > 4:
+            mask[0, 2] = False                                             # a hole, not only a tail
+        mask = mask.to(torch.uint8).to(dev)
+    scale = D ** -0.5
+    out, lse = ops.attn_f32_fwd(qkv, B, L, H, D, key_mask=mask, q_scale=scale)
+    dqkv = ops.attn_f32_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=mask, q_scale=scale)
+    q64 = qkv.double().requires_grad_(True)
+    ref, lse_ref = _attn_ref(q64, B, L, H, D, mask, None, scale)
+    ref.backward(dout.double())
+    assert (out.double() - ref).abs().max().item() < 2e-5
+    assert (lse.double() - lse_ref).abs().max().item() < 2e-5
+    assert (dqkv.double() - q64.grad).abs().max().item() < 2e-5 * max(1.0, q64.grad.abs().max().item())
+    out2, lse2 = ops.attn_f32_fwd(qkv, B, L, H, D, key_mask=mask, q_scale=scale)
+    assert torch.equal(out, out2) and torch.equal(lse, lse2)              # fixed summation order
+    assert torch.equal(dqkv, ops.attn_f32_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=mask, q_scale=scale))
+
+
+def test_attention_f32_fully_masked_sequence_and_dropout(dev):
+    """A sequence whose keys are all masked gives zero rows / lse = -inf / zero gradients (as clipk_attn_fwd); dropout on
+    the probabilities draws the bf16 kernels' mask (same hash, same element index), checked against torch with the mask
+    rebuilt in integer arithmetic (tests/ops_emulator.py)."""
+    from clip_dplm_amd import ops
+    import ops_emulator as E
+    B, L, H, D = 3, 70, 4, 15
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(B * L, 3 * H * D, generator=g).to(dev)
+    dout = torch.randn(B * L, H * D, generator=g).to(dev)
+    mask = torch.ones(B, L, dtype=torch.uint8)
+    mask[1] = 0
+    mask[2, 50:] = 0
+    mask = mask.to(dev)
+    out, lse = ops.attn_f32_fwd(qkv, B, L, H, D, key_mask=mask, q_scale=0.3)
+    assert out.view(B, L, -1)[1].abs().max().item() == 0.0 and torch.isinf(lse[1]).all()
+    dqkv = ops.attn_f32_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=mask, q_scale=0.3)
+    assert torch.isfinite(dqkv).all() and dqkv.view(B, L, -1)[1].abs().max().item() == 0.0
+    drop = (0.2, 1234567)
+    out, lse = ops.attn_f32_fwd(qkv, B, L, H, D, key_mask=None, q_scale=0.3, dropout=drop)
+    dqkv = ops.attn_f32_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=None, q_scale=0.3, dropout=drop)
+    qc = qkv.cpu().double().requires_grad_(True)
+    ref, _ = E._attn_math(qc, B, L, H, D, None, None, 0.3, drop)
+    ref.backward(dout.cpu().double())
+    assert (out.cpu().double() - ref).abs().max().item() < 2e-5
+    assert (dqkv.cpu().double() - qc.grad).abs().max().item() < 2e-5 * max(1.0, qc.grad.abs().max().item())
+
+
+def test_dropout_f32_kernel_matches_the_epilogue_mask(dev):
+    from clip_dplm_amd import ops
+    import ops_emulator as E
+    x = torch.randn(37, 120, device=dev)
+    a = torch.randn(37, 120, device=dev)
+    y = ops.dropout_f32(x, (0.1, 99), addend=a)
+    ref = E.dropout_f32(x.cpu(), (0.1, 99), addend=a.cpu())
+    assert torch.equal(y.cpu(), ref)
+    # the same elements a GEMM epilogue drops (index m * N + n): identity weight, f32 out
+    eye = torch.eye(128, device=dev).to(torch.bfloat16)
+    xb = torch.randn(64, 128, device=dev).to(torch.bfloat16)
+    yg = ops.gemm_nt(xb, eye, out_dtype=torch.float32, dropout=(0.1, 99))
+    yd = ops.dropout_f32(xb.float(), (0.1, 99))
+    assert torch.equal(yg == 0, yd == 0)

@@ -154,19 +154,92 @@ def test_transformer_layer_golden(dev, act):
             assert_grad_close(p.grad, sdo["l." + n[len("layers.0."):]].grad, n)
 
 
-def test_notebook_model_golden(dev):
-    """RNARBPCLIPModel (rna_clip_codes.ipynb:1925-1954) incl. the batch-axis attention quirk and NaN padding."""
+@pytest.mark.parametrize("precision", ["bf16", "f32"])
+def test_gelu_stack_whose_width_is_not_a_multiple_of_32(dev, precision):
+    """a post-LN gelu stack at the notebook's width 120 (K % 32 != 0: the generic-K GEMM, which has no
+    8-bit GELU' operand) must train - the u8 request is gated by shape (ops.gelu_aux_u8_applies), such widths keep the
+    bf16 pre-activation.  Forward and parameter gradients against the oracle; the f32 arithmetic on the same stack."""
+    import clip_dplm_amd as K
+    from oracle import encoder_ref
+    torch.manual_seed(3)
+    enc = K.TransformerSeqEncoder(120, 2, 8, 200, "gelu", 1e-5, precision=precision)
+    sd = {"e." + k: v.detach().clone().requires_grad_(True) for k, v in enc.state_dict().items()}
+    enc = enc.to(dev).train()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(3, 40, 120, generator=g)
+    valid = torch.arange(40)[None] < torch.tensor([40, 17, 33])[:, None]
+    y = enc(x.to(dev), src_key_padding_mask=(~valid).to(dev))
+    dy = torch.randn(3, 40, 120, generator=g) * valid[..., None]
+    y.backward(dy.to(dev))
+    yo = encoder_ref.post_ln_encoder(x, sd, "e", 2, 8, valid, "gelu", 1e-5, 1e-5)
+    yo.backward(dy)
+    tol = 0.06 if precision == "bf16" else 2e-4
+    assert ((y.detach().cpu() - yo.detach()) * valid[..., None]).abs().max().item() < tol
+    for n, p in enc.named_parameters():
+        r = sd["e." + n].grad
+        if precision == "bf16":
+            assert_grad_close(p.grad, r, n)
+        else:
+            assert (p.grad.cpu() - r).abs().max().item() <= 2e-4 * max(r.abs().max().item(), 1e-3), n
+
+
+def _slice_equivalence(build, run, rel=1e-5):
+    """embeds / loss / EVERY parameter gradient of a position-0-pooled model with the dead positions removed before the
+    encoders (slice_first_position=True, the default) against the full computation the notebook does."""
+    outs = []
+    for sl in (True, False):
+        m = build(sl)
+        o = run(m)
+        o[-1].backward()
+        outs.append(([x.detach().cpu() for x in o], {n: p.grad.detach().cpu() for n, p in m.named_parameters()}))
+    (a, ga), (b, gb) = outs
+    exact = all(torch.equal(x, y) for x, y in zip(a, b)) and all(torch.equal(ga[n], gb[n]) for n in ga)
+    for x, y in zip(a, b):
+        assert (x - y).abs().max().item() <= rel * max(1.0, y.abs().max().item())
+    for n in ga:
+        assert (ga[n] - gb[n]).abs().max().item() <= rel * max(1e-6, gb[n].abs().max().item()), n
+    return exact
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_notebook_model_golden(dev, precision):
+    """RNARBPCLIPModel (rna_clip_codes.ipynb:1925-1954) incl. the batch-axis attention quirk and NaN padding, against the
+    values the REFERENCE class produced (tools/make_golden.py gen_notebook).  Default arithmetic (exact f32, position 0
+    sliced before the encoders): the north-star bar |loss - reference| <= 1e-3 holds with three orders of margin.
+    precision="bf16" (optional bf16-MFMA kernels) is checked for agreement at bf16 level only: this model pools ONE
+    position, so bf16-rounded weights move its loss by ~2e-3 - that is why f32 is its default."""
     import clip_dplm_amd as K
     z, sd = load("notebook_model.npz")
-    m = K.RNARBPCLIPModel(rna_dim=24, rbp_dim=64, projection_dim=32)
+    m = K.RNARBPCLIPModel(rna_dim=24, rbp_dim=64, projection_dim=32, precision=precision)
     m.load_state_dict(sd)
     m = m.to(dev).eval()
     ea, eb, loss = m(t(z, "rna", dev), t(z, "rbp", dev))
-    assert (ea.cpu() - t(z, "rna_embed")).abs().max().item() < 0.03
-    assert (eb.cpu() - t(z, "rbp_embed")).abs().max().item() < 0.03
-    assert abs(loss.item() - float(z["loss"])) < 2e-2       # B = 8 only: a single row moves the mean by 1/8
+    e_emb = max((ea.cpu() - t(z, "rna_embed")).abs().max().item(), (eb.cpu() - t(z, "rbp_embed")).abs().max().item())
+    e_loss = abs(loss.item() - float(z["loss"]))
+    print(f"notebook B=8 [{precision}]: |dloss| {e_loss:.2e}, max |dembed| {e_emb:.2e}")
+    if precision == "f32":
+        assert e_loss < 1e-4 and e_emb < 1e-4, (e_loss, e_emb)       # bar: 1e-3
+    else:
+        assert e_loss < 2e-2 and e_emb < 0.03, (e_loss, e_emb)       # diagnostic: the optional arithmetic runs and agrees
     loss.backward()
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_notebook_model_position0_slice_is_exact(dev, precision):
+    """VERDICT r03 #1a: slicing to position 0 before the encoders (rna_clip_codes.ipynb:1944-1949 reads only `enc[:, 0]`
+    of a stack whose attention mixes the batch axis per position) changes nothing: embeds, loss and every parameter
+    gradient equal the full computation (bit for bit where the summation grouping does not depend on the row count)."""
+    import clip_dplm_amd as K
+    z, sd = load("notebook_model_b32.npz")
+
+    def build(sl):
+        m = K.RNARBPCLIPModel(rna_dim=40, rbp_dim=128, projection_dim=64, precision=precision, slice_first_position=sl)
+        m.load_state_dict(sd)
+        return m.to(dev).eval()
+    exact = _slice_equivalence(build, lambda m: m(t(z, "rna", dev), t(z, "rbp", dev)),
+                               rel=1e-5 if precision == "f32" else 2e-2)
+    print(f"notebook position-0 slice [{precision}]: bitwise equal = {exact}")
 
 
 def _load_esm(K, sd, dev, nl=2, d=96, h=4, f=384):
@@ -530,29 +603,56 @@ def test_load_state_dict_after_forward_refreshes_fused_qkv_copies(dev):
     assert torch.equal(l1, l2), (l1.item(), l2.item())
 
 
-def test_trimodal_contrastive_model_golden(dev):
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_trimodal_contrastive_model_golden(dev, precision):
     """ContrastiveModel (current/tf_clip_codes (1).ipynb:13113-13176) with the reference's state_dict,
-    against the fixture built from the reference's own sub-modules and loss expressions (tools/make_golden.py
-    gen_trimodal; `[:, 0]` on the 2-D encoder outputs is upstream defect A-19).  Embeddings at bf16-GEMM level, the
-    three pairwise losses and their sum at the loss bar; the batched loss kernels' gradients reach every parameter."""
+    against the fixture built from the reference's own sub-modules and loss expressions at B = 32 (tools/make_golden.py
+    gen_trimodal; `[:, 0]` on the 2-D encoder outputs is upstream defect A-19): embeddings, the three pairwise losses,
+    their sum and every parameter gradient.  Default arithmetic (exact f32): north-star bar 1e-3 on every loss, met with
+    orders of margin; the optional bf16 kernels are checked at bf16 level (diagnostic)."""
     import clip_dplm_amd as K
     z, sd = load("trimodal_model.npz")
-    m = K.ContrastiveModel(21, 64, projection_dim=64, esm_dim=40)
+    m = K.ContrastiveModel(21, 64, projection_dim=64, esm_dim=40, precision=precision)
     m.load_state_dict(sd)                                  # reference keys load as they are
     m = m.to(dev).eval()
     out = m(t(z, "cell_state", dev), t(z, "connectivity", dev), t(z, "gene_esm", dev), t(z, "gene_values", dev),
             t(z, "protein_emb", dev))
     assert set(out) == {"cell_embed", "pert_embed", "protein_embed", "loss", "cell_pert_loss", "cell_protein_loss",
                         "pert_protein_loss"}
-    for k in ("cell_embed", "pert_embed", "protein_embed"):
-        err = (out[k].cpu() - t(z, k)).abs().max().item()
-        assert err < 0.03, (k, err)
-    for k in ("cell_pert_loss", "cell_protein_loss", "pert_protein_loss", "loss"):
-        assert abs(out[k].item() - float(z[k])) < 2e-2, (k, out[k].item(), float(z[k]))   # B = 16: one row = 1/16 of the mean
+    e_emb = max((out[k].cpu() - t(z, k)).abs().max().item() for k in ("cell_embed", "pert_embed", "protein_embed"))
+    e_loss = max(abs(out[k].item() - float(z[k])) for k in ("cell_pert_loss", "cell_protein_loss", "pert_protein_loss", "loss"))
+    print(f"tri-modal B={out['cell_embed'].shape[0]} [{precision}]: max |dloss| {e_loss:.2e}, max |dembed| {e_emb:.2e}")
+    if precision == "f32":
+        assert e_loss < 1e-4 and e_emb < 1e-4, (e_loss, e_emb)       # bar: 1e-3
+    else:
+        assert e_loss < 2e-2 and e_emb < 0.03, (e_loss, e_emb)       # diagnostic
     out["loss"].backward()
     missing = [n for n, p in m.named_parameters() if p.grad is None]
     assert not missing, missing
     assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+    if precision == "f32":                                 # the reference's own gradients, parameter by parameter
+        gmax = max(t(z, "g:" + n).abs().max().item() for n, _ in m.named_parameters())
+        for n, p in m.named_parameters():
+            ref = t(z, "g:" + n)
+            assert (p.grad.cpu() - ref).abs().max().item() <= 2e-4 * max(ref.abs().max().item(), 1e-3 * gmax), n
+
+
+def test_trimodal_position0_slice_is_exact(dev):
+    """As test_notebook_model_position0_slice_is_exact for the perturbation encoder's [B, G, E] input
+    (tf_clip_codes (1).ipynb:13140-13142 reads `pert_enc[:, 0]`)."""
+    import clip_dplm_amd as K
+    z, sd = load("trimodal_model.npz")
+
+    def build(sl):
+        m = K.ContrastiveModel(21, 64, projection_dim=64, esm_dim=40, slice_first_position=sl)
+        m.load_state_dict(sd)
+        return m.to(dev).eval()
+
+    def run(m):
+        o = m(t(z, "cell_state", dev), t(z, "connectivity", dev), t(z, "gene_esm", dev), t(z, "gene_values", dev),
+              t(z, "protein_emb", dev))
+        return [o["cell_embed"], o["pert_embed"], o["protein_embed"], o["loss"]]
+    print(f"tri-modal position-0 slice: bitwise equal = {_slice_equivalence(build, run)}")
 
 
 def test_trimodal_loss_pairs_kernels_vs_f64(dev):
@@ -757,38 +857,38 @@ def test_clip_c1_exact_f32_linears_reproduce_the_fp32_reference(dev):
 
 
 def test_notebook_model_b32_golden_loss_and_gradients(dev):
-    """VERDICT r02 #3a: the notebook model (rna_clip_codes.ipynb:1925-1954: batch-axis attention, NaN padding,
-    position-0 pooling) at the notebook's batch size with ragged lengths: embeddings, loss and the direction of EVERY
-    parameter gradient that is not negligible.  Two loss bars: (i) 1e-3 against the oracle evaluated on the bf16-ROUNDED
-    weights - everything the kernels do; (ii) 5e-3 against the reference's own value: at these reduced widths (40 / 128)
-    the rounding of the weights to bf16 alone moves the loss by 2 - 3e-3 (tests/ops_emulator.py with / without weight
-    rounding: 2.0e-3 -> 2.0e-4), a perturbation of the model itself that no batch size averages away; the widths the
-    reference trained (120 / 1280) sit at 1e-4 .. 1e-3 (profiles/r03/notebook_parity_*.txt, tests/test_gpu_configs.py)."""
+    """the notebook model (rna_clip_codes.ipynb:1925-1954: batch-axis attention, NaN padding, position-0
+    pooling) at the notebook's batch size with ragged lengths, against what the REFERENCE produced
+    (tools/make_golden.py gen_notebook_b32): embeddings, loss (north-star bar 1e-3) and EVERY parameter gradient, entry
+    by entry.  Default arithmetic = exact f32 with position 0 sliced before the encoders.  The optional bf16 kernels are
+    run beside it as a printed diagnostic (round 3: 2.8e-3 against this fixture - a bf16-rounded weight perturbs the
+    model identically for every sample and this model pools one row; that is why they are not this model's default)."""
     import clip_dplm_amd as K
     z, sd = load("notebook_model_b32.npz")
     m = K.RNARBPCLIPModel(rna_dim=40, rbp_dim=128, projection_dim=64)
     m.load_state_dict(sd)
     m = m.to(dev).eval()
     ea, eb, loss = m(t(z, "rna", dev), t(z, "rbp", dev))
-    assert (ea.cpu() - t(z, "rna_embed")).abs().max().item() < 0.02
-    assert (eb.cpu() - t(z, "rbp_embed")).abs().max().item() < 0.02
-    from oracle import model_ref
-    with torch.no_grad():
-        _, _, lw = model_ref.rnarbp_clip_forward(bf16_weights(sd), t(z, "rna"), t(z, "rbp"))
-    assert abs(loss.item() - lw.item()) < 1e-3, (loss.item(), lw.item())               # (i) the kernels' arithmetic
-    assert abs(loss.item() - float(z["loss"])) < 5e-3, (loss.item(), float(z["loss"]))  # (ii) incl. bf16 weights
+    e_emb = max((ea.cpu() - t(z, "rna_embed")).abs().max().item(), (eb.cpu() - t(z, "rbp_embed")).abs().max().item())
+    e_loss = abs(loss.item() - float(z["loss"]))
+    assert e_loss < 1e-4, (loss.item(), float(z["loss"]))              # bar: 1e-3
+    assert e_emb < 1e-4, e_emb
     loss.backward()
     gmax = max(t(z, "g:" + n).abs().max().item() for n, _ in m.named_parameters())
-    worst = 1.0
+    worst = 0.0
     for n, p in m.named_parameters():
         ref = t(z, "g:" + n)
-        if ref.numel() < 64 or ref.abs().max().item() < 1e-3 * gmax:
-            continue
-        cos = torch.nn.functional.cosine_similarity(p.grad.detach().cpu().flatten(), ref.flatten(), dim=0).item()
-        worst = min(worst, cos)
-        assert cos > 0.99, (n, cos)
-    print(f"notebook b32: |dloss| vs reference {abs(loss.item() - float(z['loss'])):.2e}, vs oracle on bf16 weights "
-          f"{abs(loss.item() - lw.item()):.2e}, worst gradient cosine {worst:.5f}")
+        e = (p.grad.detach().cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-3 * gmax)
+        worst = max(worst, e)
+        assert e <= 2e-4, (n, e)
+    mb = K.RNARBPCLIPModel(rna_dim=40, rbp_dim=128, projection_dim=64, precision="bf16")
+    mb.load_state_dict(sd)
+    mb = mb.to(dev).eval()
+    with torch.no_grad():
+        _, _, lb = mb(t(z, "rna", dev), t(z, "rbp", dev))
+    print(f"notebook b32: |dloss| vs reference {e_loss:.2e}, max |dembed| {e_emb:.2e}, worst relative gradient error "
+          f"{worst:.2e}; optional bf16 kernels (diagnostic): |dloss| {abs(lb.item() - float(z['loss'])):.2e}")
+    assert abs(lb.item() - float(z["loss"])) < 2e-2
 
 
 def test_esm_integration_get_embeddings_golden(dev):

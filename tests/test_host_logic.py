@@ -644,3 +644,38 @@ def test_bench_self_launch_plumbing_with_two_gloo_ranks():
     # one rank, no launcher: same line
     r = _run_bench(["--config", "stub", "--gpus", "1", "--steps", "2", "--warmup", "0"])
     assert r.returncode == 0 and json.loads(r.stdout.strip())["n_gpus"] == 1
+
+
+def test_weight_cache_never_refreshes_from_a_per_call_copy(monkeypatch):
+    """a padded / concatenated operand is rebuilt per call; after a no_grad forward the cache's
+    `src` was a LEAF copy of the weights at that moment, the batched refresh after the next optimiser step rebuilt the
+    bf16 copies from it and stamped the new key on them: training went on with eval-time weights.  Sequence: train
+    forward, no_grad forward, weight update (fused: epoch bump), batched-refresh selection, train forward."""
+    ops_emulator.install(monkeypatch)
+    import torch.nn.functional as F
+    from clip_dplm_amd import functional as KF
+    w = torch.nn.Parameter(torch.randn(16, 21))
+    pad = lambda: F.pad(w, (0, 11))
+    cache = KF.WeightCache()
+    vf = KF.params_version(w)
+    cache.get(pad(), vf)                                         # training forward: non-leaf copy
+    with torch.no_grad():
+        cache.get(pad(), vf)                                     # evaluation forward: a leaf copy, cache HIT
+    assert cache.derived
+    with torch.no_grad():
+        w.mul_(2.0)                                              # optimiser step ...
+    KF.mark_weights_dirty()                                      # ... by the fused kernels (no version bump of their own)
+    assert all(c is not cache for c, _, _ in KF._stale_caches(require_cuda=False))
+    wb, wtb = cache.get(pad(), vf)                               # next training forward: lazy rebuild from THIS call's copy
+    assert torch.equal(wb.float(), pad().detach().to(torch.bfloat16).float())
+    assert torch.equal(wtb.float(), pad().detach().t().to(torch.bfloat16).float())
+    # a zero-copy view of the parameters' own storage (ESM's fused qkv) stays eligible for the batched refresh
+    q, k = torch.nn.Parameter(torch.randn(8, 32)), torch.nn.Parameter(torch.randn(8, 32))
+    flat = torch.cat([q.data.flatten(), k.data.flatten()])
+    q.data, k.data = flat[:256].view(8, 32), flat[256:].view(8, 32)
+    view = torch.as_strided(q.data, (16, 32), (32, 1))
+    c2 = KF.WeightCache()
+    c2.get(view, KF.params_version(q, k))
+    assert not c2.derived
+    KF.mark_weights_dirty()
+    assert any(c is c2 for c, _, _ in KF._stale_caches(require_cuda=False))

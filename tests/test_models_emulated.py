@@ -13,7 +13,12 @@ CASES = [
     ("clip_opt", T.test_clip_opt_golden_cache_loss, {}),
     ("tlayer_relu", T.test_transformer_layer_golden, {"act": "relu"}),
     ("tlayer_gelu", T.test_transformer_layer_golden, {"act": "gelu"}),
-    ("notebook", T.test_notebook_model_golden, {}),
+    ("notebook_f32", T.test_notebook_model_golden, {"precision": "f32"}),
+    ("notebook_bf16", T.test_notebook_model_golden, {"precision": "bf16"}),
+    ("notebook_slice_f32", T.test_notebook_model_position0_slice_is_exact, {"precision": "f32"}),
+    ("notebook_slice_bf16", T.test_notebook_model_position0_slice_is_exact, {"precision": "bf16"}),
+    ("gelu120_bf16", T.test_gelu_stack_whose_width_is_not_a_multiple_of_32, {"precision": "bf16"}),
+    ("gelu120_f32", T.test_gelu_stack_whose_width_is_not_a_multiple_of_32, {"precision": "f32"}),
     ("esm_tiny", T.test_esm_tiny_golden, {}),
     ("protein_rna", T.test_protein_rna_clip_vs_oracle, {}),
     ("adamw_train", T.test_fused_adamw_training_reduces_loss, {}),
@@ -24,7 +29,9 @@ CASES = [
     ("icnn_noln", T.test_icnn_without_layer_norm_golden, {}),
     ("icnn_train_ragged", T.test_icnn_training_large_ragged_batch_vs_oracle, {}),
     ("esm_proj", T.test_esm_projections_golden, {}),
-    ("trimodal", T.test_trimodal_contrastive_model_golden, {}),
+    ("trimodal_f32", T.test_trimodal_contrastive_model_golden, {"precision": "f32"}),
+    ("trimodal_bf16", T.test_trimodal_contrastive_model_golden, {"precision": "bf16"}),
+    ("trimodal_slice", T.test_trimodal_position0_slice_is_exact, {}),
     ("trimodal_loss", T.test_trimodal_loss_pairs_kernels_vs_f64, {}),
     ("packed_varlen", T.test_packed_varlen_path_equals_padded_path, {}),
     ("dropout_layer", T.test_dropout_layer_vs_masked_oracle, {}),

@@ -167,7 +167,7 @@ def gen_trimodal():
     ns = {}
     exec(src, ns)
     torch.manual_seed(0)
-    gene_dim, protein_dim, P, esm_dim, B, G = 21, 64, 64, 40, 16, 5
+    gene_dim, protein_dim, P, esm_dim, B, G = 21, 64, 64, 40, 32, 5      # B = 32: the notebooks' batch size
     m = ns["ContrastiveModel"](gene_dim, protein_dim, projection_dim=P, esm_dim=esm_dim).eval()
     with torch.no_grad():                                   # move layer_scale off its 1e-4 init so the MLP branch counts
         for h in (m.cell_projection, m.pert_projection, m.protein_projection):
@@ -179,27 +179,35 @@ def gen_trimodal():
     gene_esm = torch.randn(B, G, esm_dim, generator=g)
     gene_values = torch.randn(B, G, generator=g)
     protein_emb = torch.randn(B, protein_dim, generator=g)
-    with torch.no_grad():
-        cell_enc = m.cell_encoder(cell_state, conn)          # [B, P]
-        pert_enc = m.pert_encoder(gene_esm, gene_values)     # [B, G, P]
-        prot_enc = m.protein_encoder(protein_emb)            # [B, protein_dim]
-        ce = F.normalize(m.cell_projection(cell_enc), dim=-1)
-        pe = F.normalize(m.pert_projection(pert_enc[:, 0]), dim=-1)
-        pr = F.normalize(m.protein_projection(prot_enc), dim=-1)
-        ls = m.logit_scale.exp()
-        lab = torch.arange(B)
-        sym = lambda a, b: (F.cross_entropy((a @ b.t()) * ls, lab) + F.cross_entropy(((a @ b.t()) * ls).t(), lab)) / 2
-        cp, cpr, ppr = sym(ce, pe), sym(ce, pr), sym(pe, pr)
+    cell_enc = m.cell_encoder(cell_state, conn)          # [B, P]
+    pert_enc = m.pert_encoder(gene_esm, gene_values)     # [B, G, P]
+    prot_enc = m.protein_encoder(protein_emb)            # [B, protein_dim]
+    ce = F.normalize(m.cell_projection(cell_enc), dim=-1)
+    pe = F.normalize(m.pert_projection(pert_enc[:, 0]), dim=-1)
+    pr = F.normalize(m.protein_projection(prot_enc), dim=-1)
+    ls = m.logit_scale.exp()
+    lab = torch.arange(B)
+    sym = lambda a, b: (F.cross_entropy((a @ b.t()) * ls, lab) + F.cross_entropy(((a @ b.t()) * ls).t(), lab)) / 2
+    cp, cpr, ppr = sym(ce, pe), sym(ce, pr), sym(pe, pr)
+    grads = torch.autograd.grad(cp + cpr + ppr, list(m.parameters()))        # the reference's own gradients
+    ce, pe, pr, cp, cpr, ppr = (v.detach() for v in (ce, pe, pr, cp, cpr, ppr))
     sd = {k: v.detach() for k, v in m.state_dict().items()}
-    o = model_ref.contrastive_model_forward(sd, cell_state, conn, gene_esm, gene_values, protein_emb)
-    check("trimodal cell embed", o["cell_embed"], ce, 3e-5)
-    check("trimodal pert embed", o["pert_embed"], pe, 3e-5)
-    check("trimodal protein embed", o["protein_embed"], pr, 3e-5)
-    check("trimodal loss", o["loss"], cp + cpr + ppr, 3e-5)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    o = model_ref.contrastive_model_forward(sdg, cell_state, conn, gene_esm, gene_values, protein_emb)
+    check("trimodal cell embed", o["cell_embed"].detach(), ce, 3e-5)
+    check("trimodal pert embed", o["pert_embed"].detach(), pe, 3e-5)
+    check("trimodal protein embed", o["protein_embed"].detach(), pr, 3e-5)
+    check("trimodal loss", o["loss"].detach(), cp + cpr + ppr, 3e-5)
+    o["loss"].backward()
+    for (n, _), gr in zip(m.named_parameters(), grads):
+        err = (sdg[n].grad - gr).abs().max().item()
+        assert err <= 1e-4 * max(1.0, gr.abs().max().item()), (n, err)
+    print("  oracle gradients == reference gradients for every parameter")
+    arrays = {"g:" + n: gr.numpy() for (n, _), gr in zip(m.named_parameters(), grads)}
     save("trimodal_model.npz", cell_state=cell_state.numpy(), connectivity=conn.numpy(), gene_esm=gene_esm.numpy(),
          gene_values=gene_values.numpy(), protein_emb=protein_emb.numpy(), cell_embed=ce.numpy(), pert_embed=pe.numpy(),
          protein_embed=pr.numpy(), cell_pert_loss=cp.item(), cell_protein_loss=cpr.item(), pert_protein_loss=ppr.item(),
-         loss=(cp + cpr + ppr).item(), **sd_np(m))
+         loss=(cp + cpr + ppr).item(), **arrays, **sd_np(m))
 
 
 # ------------------------------------------------------------------------------------------------ torch layer
@@ -571,6 +579,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "icnn":
         gen_icnn()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "trimodal":       # round 4: B = 32 + the reference's gradients
+        gen_trimodal()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "r03":            # the round-3 additions only
         sys.path[:0] = [REF + "/run1", REF + "/old"]
