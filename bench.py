@@ -29,6 +29,9 @@ Other BASELINE configurations (bench lines of their own, not the driver's defaul
     --config c3sim             fused similarity + CE at one rank's config-3 shape (512 x 4096 x 512): achieved GB/s
     --config c5                ICNN transport system 512 / [512, 256], B = 4096 (eval transport maps)
     --config c1                old/clip.py tiny dual encoder (2 layers, d = 128) on 256 random pairs
+    --config notebook          the model the reference actually trained (rna_clip_codes.ipynb:1925-1954) at its own
+                               shapes [32, 48, 120] x [32, 600, 1280]; --variant full-bf16 = every position through the
+                               bf16 kernels (round 3), default = position 0 sliced before the encoders, exact f32
 Every line carries `parity` (GPU vs the CPU oracle on the same inputs) and, where BASELINE.md §3 promises one, a
 `cpu_baseline`.
 """
@@ -46,6 +49,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md §Chip-level parameters
 HBM_PEAK_GBS = 8000.0
+MFMA_F32_PEAK_TFLOPS = 157.3         # dense f32 MFMA (= the packed-f32 vector rate): 256 FLOP/clk/CU x 256 CUs x 2.4 GHz
 
 
 def parse_args():
@@ -53,9 +57,12 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3sim", "c4", "c5", "stub"],
+    ap.add_argument("--config", default="c2", choices=["c1", "c2", "c3sim", "c4", "c5", "notebook", "stub"],
                     help="stub: the launch / rendezvous / timing / output plumbing of the multi-rank path on a trivial "
                          "CPU workload over gloo (tests/test_host_logic.py); never a measurement")
+    ap.add_argument("--variant", default="sliced-f32", choices=["sliced-f32", "sliced-bf16", "full-bf16", "full-f32"],
+                    help="notebook only: sliced = position 0 before the encoders (exact), full = every position as the "
+                         "notebook computes them; f32 / bf16 = the arithmetic")
     ap.add_argument("--batch", type=int, default=None, help="pairs per GPU (default: 1024 for c2, 256 for c4, 4096 for c5)")
     ap.add_argument("--seq-len", type=int, default=None)
     ap.add_argument("--esm", default=None)
@@ -92,6 +99,35 @@ def self_launch(args) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def collective_report(device, world):
+    """What the collective library actually saw, for the N > 1 line (VERDICT r03 #6a: the driver must be able to tell
+    that RCCL had N ranks on N devices): backend, world size, an all-reduce of 1 over every rank, and each rank's
+    (rank, device index, PCI bus id) gathered through the same process group the training step uses."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return None
+    one = torch.ones(1, dtype=torch.int64, device=device)
+    dist.all_reduce(one)
+    bus = -1
+    if device.type == "cuda":
+        bus = int(getattr(torch.cuda.get_device_properties(device), "pci_bus_id", -1))
+    mine = torch.tensor([dist.get_rank(), device.index if device.index is not None else -1, bus], dtype=torch.int64,
+                        device=device)
+    everyone = torch.empty(world * 3, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(everyone, mine)
+    rows = everyone.view(world, 3).tolist()
+    rep = {"backend": dist.get_backend(), "world": dist.get_world_size(), "ranks_seen": int(one.item()),
+           "devices": [{"rank": r, "device_index": d, "pci_bus_id": b} for r, d, b in rows],
+           "distinct_devices": len({(d, b) for _, d, b in rows})}
+    if device.type == "cuda" and dist.get_backend() == "nccl":
+        try:
+            rep["library_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:                                    # version probing must never cost the line
+            rep["library_version"] = None
+    return rep
+
+
 def synth_batch(B, L, rna_dim, device, seed):
     """protein ids uniform over the 20 standard amino-acid ids [4, 24) with <cls>=0 first and <eos>=2
     last, no padding; RNA side N(0,1) features [B, L, rna_dim] (the reference feeds precomputed RNABERT vectors)."""
@@ -112,10 +148,17 @@ def host_threads():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(model_sd, cfg, L, sample_b=32, steps=3, budget_s=75.0):
+def cpu_baseline(model_sd, cfg, L, sample_b=32, steps=3, budget_s=75.0, probe=None):
     """Time the CPU oracle (kind 'port') on a bounded sample of the same workload: forward + backward + clip + AdamW
     (B = 32, >= 3 steps).  The first (warm-up) step runs on the initial weights, so its loss is also the
-    oracle side of the `parity` object.  Returns (cpu_baseline dict, step-0 oracle loss)."""
+    oracle side of the `parity` object, and the loss of every later step (taken BEFORE that step's update, i.e. after
+    `it` updates) is the oracle's training trajectory for `parity.trajectory`.
+    probe (optional, from gpu_trajectory): {"grads0": name -> the fused path's step-0 gradient, "weights": [state_dict
+    after 1, 2, ... fused updates]} - filled in here with (i) how many gradient entries differ in SIGN between the two
+    paths at step 0 and what share of sum|g| they carry (AdamW's first update is lr * sign(g) for every entry, however
+    small: such entries move the weights apart by 2 lr each), (ii) the oracle's loss AT the fused path's weights after
+    each update, which splits a trajectory difference into forward arithmetic and weight divergence.
+    Returns (cpu_baseline dict, [oracle loss after 0, 1, ... updates])."""
     import torch
     from oracle import model_ref
     ncores = host_threads()
@@ -128,7 +171,7 @@ def cpu_baseline(model_sd, cfg, L, sample_b=32, steps=3, budget_s=75.0):
     rna, ids = synth_batch(sample_b, L, cfg["rna_dim"], "cpu", 4321)
     if cfg.get("rna_len") and cfg["rna_len"] != L:
         rna = rna[:, : cfg["rna_len"]].contiguous()
-    times, loss0 = [], None
+    times, losses = [], []
     t_start = time.perf_counter()
     for it in range(steps + 1):
         t0 = time.perf_counter()
@@ -136,25 +179,90 @@ def cpu_baseline(model_sd, cfg, L, sample_b=32, steps=3, budget_s=75.0):
         loss, _, _ = model_ref.protein_rna_clip_loss(sd, rna, ids, None, None, esm_layers=cfg["esm_layers"],
                                                      esm_heads=cfg["esm_heads"], rna_layers=cfg["rna_layers"],
                                                      rna_heads=cfg["rna_heads"])
-        if it == 0:
-            loss0 = float(loss.item())
+        losses.append(float(loss.item()))
         loss.backward()
+        if it == 0 and probe is not None and probe.get("grads0"):
+            flips = total = 0
+            carried = mass = 0.0
+            for name, gg in probe["grads0"].items():
+                r = sd[name].grad
+                if r is None:
+                    continue
+                d = torch.sign(gg) != torch.sign(r)
+                flips += int(d.sum()); total += d.numel()
+                carried += float(r.abs()[d].sum()); mass += float(r.abs().sum())
+            probe["sign_flips"] = {"entries": flips, "of": total, "share_of_entries": flips / max(total, 1),
+                                   "share_of_sum_abs_grad": carried / max(mass, 1e-30)}
+            probe["grads0"] = None
         torch.nn.utils.clip_grad_norm_(params, 1.0)
         opt.step()
         times.append(time.perf_counter() - t0)
         print(f"[cpu_baseline] step {it}: {times[-1]:.2f} s on {ncores} threads", file=sys.stderr, flush=True)
         if time.perf_counter() - t_start > budget_s:      # bounded sample: never hold the bench for minutes
             break
+    if probe is not None and probe.get("weights"):
+        probe["loss_oracle_at_gpu_weights"] = []
+        for w in probe["weights"][: len(losses) - 1]:
+            with torch.no_grad():
+                lw, _, _ = model_ref.protein_rna_clip_loss(w, rna, ids, None, None, esm_layers=cfg["esm_layers"],
+                                                           esm_heads=cfg["esm_heads"], rna_layers=cfg["rna_layers"],
+                                                           rna_heads=cfg["rna_heads"])
+            probe["loss_oracle_at_gpu_weights"].append(float(lw.item()))
+        probe["weights"] = None
     steps = len(times) - 1
     timed = sorted(times[1:] if len(times) > 1 else times)   # drop the warm-up step when there is more than one
     dt = timed[len(timed) // 2]                              # median
     return ({"value": round(sample_b / dt, 3), "unit": "seq-pairs/s", "cores": ncores, "kind": "port",
              "sample": f"median of {len(timed)} training step(s) (fwd+bwd+clip+AdamW) of the CPU oracle at B={sample_b}, "
                        f"L={L}, f32, {'after 1 warm-up step' if len(times) > 1 else 'no warm-up (time budget)'}; "
-                       f"{dt:.2f} s/step"}, loss0)
+                       f"{dt:.2f} s/step"}, losses)
 
 
-GEMM_SOURCES = ("gemm_nt.hip", "gemm_nt_v2.hip", "gemm_nt_v3.hip", "gemm_epilogue.h", "common.h")
+def gpu_trajectory(build_model, sd_cpu, device, Lp, rna_dim=768, sample_b=32, updates=3):
+    """The training trajectory of the fused path on the parity sub-batch: the same `updates` optimiser steps the CPU
+    oracle takes in cpu_baseline() (rna_clip_codes.ipynb:2061-2089 / old/ablation.py:9-18: loss -> backward ->
+    clip_grad_norm_(1.0) -> AdamW(lr 1e-4, weight_decay 0.01)) on the same 32 pairs from the same initial weights, on a
+    private copy of the model (the timed model stays at its initial weights).  Returns (the loss after 0 .. updates
+    updates, each taken before the next update as the oracle's; a probe for cpu_baseline(): the step-0 gradients and the
+    weights after each update, on the host)."""
+    import torch
+    import clip_dplm_amd as K
+    m = build_model()
+    m.load_state_dict(sd_cpu)
+    m = m.to(device).train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    opt = K.FusedAdamW(m, lr=1e-4, weight_decay=0.01, max_grad_norm=1.0)
+    rna, ids = synth_batch(sample_b, Lp, rna_dim, device, 4321)
+    losses, probe = [], {"grads0": None, "weights": []}
+    for it in range(updates + 1):
+        opt.zero_grad()
+        loss = m.loss(rna, ids)
+        losses.append(float(loss.item()))
+        loss.backward()
+        if it == 0:
+            probe["grads0"] = {n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters()
+                               if p.grad is not None}
+        if it == updates:
+            break
+        opt.step()
+        probe["weights"].append({k: v.detach().float().cpu().clone() if v.is_floating_point() else v.detach().cpu().clone()
+                                 for k, v in m.state_dict().items()})
+    del opt, m, rna, ids
+    torch.cuda.empty_cache()
+    return losses, probe
+
+
+def _gemm_sources():
+    """Every source clipk_gemm_nt can dispatch to (csrc/gemm_nt*.hip by glob: ADVICE r03 - v4 was missing from a fixed
+    list) + the shared epilogue / common headers."""
+    import glob
+    d = os.path.join(ROOT, "clip_dplm_amd", "csrc")
+    return tuple(sorted(os.path.basename(f) for f in glob.glob(os.path.join(d, "gemm_nt*.hip")))) + ("gemm_epilogue.h", "common.h")
+
+
+GEMM_SOURCES = _gemm_sources()
 
 
 def gemm_source_hash() -> str:
@@ -244,6 +352,9 @@ def bench_clip(args):
         with torch.no_grad():
             parity = {"sub_batch": 32, "loss_gpu": float(model.loss(rna_s, ids_s).item())}
         del rna_s, ids_s
+        # ... and the first optimiser steps of the same sub-batch (the metric is a TRAINING step)
+        parity["_traj_gpu"] = gpu_trajectory(lambda: K.ProteinRNACLIP(esm=esm, freeze_protein_encoder=freeze), sd_cpu,
+                                             device, Lp)
 
     opt = K.FusedAdamW(model, lr=1e-4, weight_decay=0.01, max_grad_norm=1.0, group=group)
     g = torch.Generator().manual_seed(1234 + rank)
@@ -318,6 +429,7 @@ def bench_clip(args):
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
+    coll = collective_report(device, world) if (world > 1 or force_dist) else None      # every rank takes part
     if rank == 0:
         print(f"[bench] {args.steps} timed steps: {dt:.3f} s", file=sys.stderr, flush=True)
     if rank != 0:
@@ -346,6 +458,8 @@ def bench_clip(args):
                    "projection_dim": 512, "hip_streams": 2 if model.dual_stream else 1},
         "loss": round(float(loss.item()), 5),
     }
+    if coll is not None:
+        out["rccl"] = coll
     if ragged:
         out["config"]["lengths"] = (f"{args.lengths}: lengths uniform in [L/4, L]; {real_tokens} real tokens of "
                                     f"{B * (Lp + Lr)} padded positions ({real_tokens / (B * (Lp + Lr)):.3f})")
@@ -381,6 +495,10 @@ def bench_clip(args):
                                "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
                                "traffic": traffic["bytes_per_launch"] if traffic else None,
+                               # the same launches against the OTHER roof: HBM-side bytes (PMC) per average launch
+                               "frac_hbm": round(traffic["bytes_per_launch"] / (gm["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                               if traffic else None,
+                               "frac_hbm_algorithmic": round(gm["bytes"] / (gm["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                "avg_launch_us": round(gm["avg_us"], 2), "launches": gm["launches"],
                                "share_of_step": round(gm["total_ms"] / (1e3 * dt), 4),
                                "algorithmic_bytes_per_launch": round(gm["bytes"] / max(gm["launches"], 1)),
@@ -410,15 +528,36 @@ def bench_clip(args):
     if want_cpu:
         del opt, model, rna, ids
         torch.cuda.empty_cache()
-        cb, loss0 = cpu_baseline(sd_cpu, {"rna_dim": 768, "esm_layers": nl, "esm_heads": h, "rna_layers": 6,
-                                          "rna_heads": 8}, Lp)
+        probe = parity["_traj_gpu"][1] if parity is not None else None
+        cb, traj_or = cpu_baseline(sd_cpu, {"rna_dim": 768, "esm_layers": nl, "esm_heads": h, "rna_layers": 6,
+                                            "rna_heads": 8}, Lp, probe=probe)
+        loss0 = traj_or[0]
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cb
         if parity is not None:
+            traj_gpu, _ = parity.pop("_traj_gpu")
             parity["loss_oracle"] = loss0
             parity["loss_abs_err"] = abs(parity["loss_gpu"] - loss0)
             parity["bar"] = 1e-3
             parity["note"] = "step-0 loss, initial weights, 32 pairs (seed 4321), full depth; oracle = CPU f32 restatement"
+            parity["trajectory"] = [{"step": i, "loss_gpu": lg, "loss_oracle": lo, "abs_err": abs(lg - lo)}
+                                    for i, (lg, lo) in enumerate(zip(traj_gpu, traj_or))]
+            at_w = [loss0] + list(probe.get("loss_oracle_at_gpu_weights") or [])
+            for t_, lw in zip(parity["trajectory"], at_w):
+                # |gpu - oracle| = forward arithmetic at the SAME weights (+) how far the two weight sets have moved apart
+                t_["loss_oracle_at_gpu_weights"] = lw
+                t_["forward_abs_err"] = abs(t_["loss_gpu"] - lw)
+                t_["weight_divergence_abs_err"] = abs(lw - t_["loss_oracle"])
+            parity["trajectory_max_abs_err"] = max(t_["abs_err"] for t_ in parity["trajectory"])
+            parity["trajectory_max_forward_abs_err"] = max(t_.get("forward_abs_err", 0.0) for t_ in parity["trajectory"])
+            parity["trajectory_sign_flips_step0"] = probe.get("sign_flips")
+            parity["trajectory_note"] = (
+                "loss after `step` fused optimiser updates (clip 1.0 + AdamW lr 1e-4, wd 0.01) of the same 32 pairs vs the "
+                "CPU oracle's torch.optim.AdamW trajectory, bar 1e-3; forward_abs_err = GPU loss vs the oracle evaluated at "
+                "the GPU path's own weights (the parity claim at every trained step), weight_divergence_abs_err = the "
+                "oracle at the GPU path's weights vs the oracle's own trajectory: AdamW's first update is lr * sign(g) for "
+                "every entry, so the entries whose bf16 gradient differs in sign (trajectory_sign_flips_step0: a fraction "
+                "of a percent of the entries, carrying ~1e-5 of sum|g|) move by 2 lr each")
             out["parity"] = parity
     if want_c4_cpu:
         sd_full = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
@@ -428,7 +567,7 @@ def bench_clip(args):
             out["parity"] = c4_parity(device, Lp)
         if not args.no_cpu_baseline:
             # config 4 on the host at B = 1, one step (frozen 650M forward at L = 1024 + trained RNA tower)
-            cb, _ = cpu_baseline(sd_full, {"rna_dim": 768, "esm_layers": nl, "esm_heads": h, "rna_layers": 6,
+            cb, _traj = cpu_baseline(sd_full, {"rna_dim": 768, "esm_layers": nl, "esm_heads": h, "rna_layers": 6,
                                            "rna_heads": 8, "rna_len": Lr, "frozen_prefix": "protein_model."},
                                  Lp, sample_b=1, steps=1, budget_s=60.0)
             out["cpu_baseline"] = cb
@@ -476,7 +615,7 @@ def bench_stub(args):
     import torch
     import torch.distributed as dist
     from clip_dplm_amd.distributed import init_distributed
-    rank, world, _ = init_distributed(backend="gloo")
+    rank, world, _ = init_distributed(backend="gloo", cpu_only=True)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     fail = os.environ.get("CLIPK_BENCH_STUB_FAIL_RANK")
@@ -503,8 +642,9 @@ def bench_stub(args):
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = max(tmax.item(), 1e-9)
+    coll = collective_report(torch.device("cpu"), world) if world > 1 else None
     if rank == 0:
-        emit({"metric": "stub", "value": round(1024 * world * args.steps / dt, 1), "unit": "elements/s", "n_gpus": world,
+        emit({"metric": "stub", "rccl": coll, "value": round(1024 * world * args.steps / dt, 1), "unit": "elements/s", "n_gpus": world,
               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
               "config": {"workload": "plumbing stub (CPU, gloo)"}, "checksum": float(y.sum().item())})
@@ -599,6 +739,114 @@ def bench_c1(args):
     emit(out)
 
 
+# ====================================================================================================== notebook
+def bench_notebook(args):
+    """The one variant the reference trained (current/rna_clip_codes.ipynb:1925-1954, 71.6 M parameters): RNA features
+    [32, 48, 120] and RBP features [32, 600, 1280] (the notebook's RBP lengths are 557-2542), ragged NaN padding, one
+    TRAINING step = forward + symmetric InfoNCE + backward + clip + fused AdamW (ipynb:2061-2089), dropout 0.
+    The encoders attend over the BATCH axis per position and only position 0 is read (App. A-8), so all the work that
+    reaches the loss is 32 rows per tower through 3 layers: with the slice the step is bound by reading the f32 weights
+    (fwd + dgrad), writing their gradients and the AdamW pass - ~8 passes over 287 MB."""
+    import torch
+
+    import clip_dplm_amd as K
+    from clip_dplm_amd import ops
+    from oracle import model_ref
+    dev = torch.device("cuda:0")
+    B, Lr, Lp = args.batch or 32, 48, args.seq_len or 600
+    sliced, prec = args.variant.startswith("sliced"), args.variant.split("-")[1]
+    torch.manual_seed(0)
+    model = K.RNARBPCLIPModel(rna_dim=120, rbp_dim=1280, projection_dim=512, dropout=0.0, precision=prec,
+                              slice_first_position=sliced)
+    nparam = sum(p.numel() for p in model.parameters())
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(7)
+    rna = torch.randn(B, Lr, 120, generator=g)
+    rbp = torch.randn(B, Lp, 1280, generator=g)
+    lr_ = torch.randint(10, Lr + 1, (B,), generator=g)
+    lp_ = torch.randint(Lp // 3, Lp + 1, (B,), generator=g)
+    lr_[0], lp_[0] = Lr, Lp
+    for i in range(B):
+        rna[i, lr_[i]:] = float("nan")
+        rbp[i, lp_[i]:] = float("nan")
+    model = model.to(dev).train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    rna_d, rbp_d = rna.to(dev), rbp.to(dev)
+    with torch.no_grad():
+        loss_gpu0 = float(model(rna_d, rbp_d)[2].item())
+    opt = K.FusedAdamW(model, lr=1e-4, weight_decay=0.01, max_grad_norm=1.0)
+
+    def step():
+        opt.zero_grad()
+        loss = model(rna_d, rbp_d)[2]
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timer = ops.KernelTimer()
+    ops.set_kernel_timer(timer)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    ops.set_kernel_timer(None)
+    summ = timer.summary()
+    kernels = {k: {"launches_per_step": v["launches"] // 2, "avg_us": round(v["avg_us"], 2),
+                   "ms_per_step": round(v["total_ms"] / 2, 4)} for k, v in summ.items()}
+    dom = max(summ, key=lambda k: summ[k]["total_ms"])
+    dv = summ[dom]
+    if dv["bytes"] > 0 and prec == "f32":
+        ach = dv["bytes"] / (dv["total_ms"] * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": f"clipk_{dom} (exact-f32 Linear fwd / dgrad / wgrad at M = {B} rows: one pass over "
+                                          "the f32 weight per launch)",
+                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "traffic": None, "avg_launch_us": round(dv["avg_us"], 2), "launches": dv["launches"],
+                "algorithmic_bytes_per_launch": round(dv["bytes"] / max(dv["launches"], 1))}
+    else:
+        ach = dv["work"] / (dv["total_ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": f"clipk_{dom}", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                "avg_launch_us": round(dv["avg_us"], 2), "launches": dv["launches"]}
+    # whole-step floor of the sliced model: weights read by fwd and dgrad, gradients written, AdamW's 16 B per parameter
+    step_bytes = nparam * 4.0 * 3 + nparam * 16.0
+    out = {"metric": "seq-pairs/sec, contrastive training step, RNA-RBP notebook model (rna_clip_codes.ipynb:1925-1954)",
+           "value": round(B * args.steps / dt, 1), "unit": "seq-pairs/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": prec, "data": "synthetic",
+           "config": {"workload": f"RNARBPCLIPModel(120, 1280, 512), {nparam} parameters, rna [{B}, {Lr}, 120] x rbp "
+                                  f"[{B}, {Lp}, 1280] with ragged NaN padding, training step (fwd + symmetric InfoNCE + bwd + "
+                                  f"clip + fused AdamW), variant {args.variant}"},
+           "loss": round(float(loss.item()), 5), "roofline": roof, "kernels": kernels,
+           "step_hbm_floor": {"algorithmic_bytes_per_step": int(step_bytes),
+                              "ms_at_8TBps": round(step_bytes / 8e12 * 1e3, 4),
+                              "frac_of_floor": round(step_bytes / 8e12 / (dt / args.steps), 4),
+                              "note": "sliced model only: weights read by forward and dgrad, weight gradients written, "
+                                      "AdamW 16 B / parameter"}}
+    if not (args.no_parity and args.no_cpu_baseline):
+        ncores = host_threads()
+        torch.set_num_threads(ncores)
+        sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd0.items()}
+        t1 = time.perf_counter()
+        _, _, lo = model_ref.rnarbp_clip_forward(sd, rna, rbp)
+        lo.backward()
+        cdt = time.perf_counter() - t1
+        out["parity"] = {"loss_gpu": loss_gpu0, "loss_oracle": float(lo.item()), "loss_abs_err": abs(loss_gpu0 - float(lo.item())),
+                         "bar": 1e-3, "note": "step-0 loss at the initial weights; oracle = CPU f32 restatement computing "
+                                              "EVERY position, as the notebook does"}
+        out["cpu_baseline"] = {"value": round(B / cdt, 3), "unit": "seq-pairs/s", "cores": ncores, "kind": "port",
+                               "sample": f"ONE forward + backward of the CPU oracle on the same batch (every position, "
+                                         f"f32, no optimiser step, no warm-up); {cdt:.2f} s"}
+    emit(out)
+
+
 # ====================================================================================================== c3sim
 def bench_c3sim(args):
     """Fused similarity + symmetric CE at one rank's share of config 3: B_l = 512 local pairs against B_g = 4096
@@ -653,12 +901,13 @@ def bench_c3sim(args):
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"BASELINE config 3, one rank's loss block: {Bl} local pairs x {Bg} gathered keys, P={P}, "
                                   "simce_lse x2 + simce_grad x2 (host-synchronised per step)"},
-           "roofline": {"bound": "hbm", "kernel": "simce_kernel<LSE> (exact-f32 MFMA similarity + online LSE)",
-                        "achieved": round(bytes_lse / (lse_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(bytes_lse / (lse_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                        "avg_launch_us": round(lse_us, 2), "algorithmic_bytes_per_launch": bytes_lse,
-                        "f32_mfma_tflops": round(flop_lse / (lse_us * 1e-6) / 1e12, 1),
-                        "f32_mfma_frac_of_157": round(flop_lse / (lse_us * 1e-6) / 1e12 / 157.3, 3)},
+           # the fusion removed the logits from HBM: what binds the kernel is its 2 * Bl * Bg * P exact-f32 MFMA FLOP
+           "roofline": {"bound": "mfma", "kernel": "simce_lse_tiled_kernel (exact-f32 MFMA similarity + online LSE)",
+                        "achieved": round(flop_lse / (lse_us * 1e-6) / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(flop_lse / (lse_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                        "traffic": None, "avg_launch_us": round(lse_us, 2), "algorithmic_bytes_per_launch": bytes_lse,
+                        "frac_hbm_algorithmic": round(bytes_lse / (lse_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                        "peak_note": "dense f32 MFMA peak (v_mfma_f32_32x32x2_f32: 256 FLOP/clk/CU x 256 CUs x 2.4 GHz)"},
            "parity": c3sim_parity(al, bl, a, b, sc, Bl, Bg),
            "kernels": {"simce_lse": {"avg_us": round(lse_us, 2), "GBps": round(bytes_lse / (lse_us * 1e-6) / 1e9, 1)},
                        "simce_grad": {"avg_us": round(grad_us, 2), "GBps": round(bytes_grad / (grad_us * 1e-6) / 1e9, 1),
@@ -735,14 +984,14 @@ def bench_c5(args):
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"BASELINE config 5: create_transport_system(512, 512, 512), hidden [512, 256], B={B}, "
                                   "three eval-mode transport maps per step"},
-           "roofline": {"bound": "hbm", "kernel": "ICNN transport map (whole op: all launches of the three maps, hipGraph replay)",
-                        "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+           # exact-f32 matrix work (2.1 MFLOP per sample and map): the f32 matrix pipe is the bound, not HBM
+           "roofline": {"bound": "mfma", "kernel": "ICNN transport map (whole op: all launches of the three maps, hipGraph "
+                                                   "replay; gemm_f32_kernel dominates)",
+                        "achieved": round(flop * args.steps / dt / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(flop * args.steps / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                         "algorithmic_bytes_per_step": int(3 * per_map_bytes),
-                        "f32_mfma_tflops": round(flop * args.steps / dt / 1e12, 1),
-                        "f32_mfma_frac_of_157": round(flop * args.steps / dt / 1e12 / 157.3, 3),
-                        "note": "the op is exact-f32 matrix work (2.1 MFLOP / sample / map at 64 FLOP/clk/SIMD): its own "
-                                "bound is the f32 matrix pipe, not HBM"},
+                        "frac_hbm_algorithmic": round(ach / HBM_PEAK_GBS, 5),
+                        "peak_note": "dense f32 MFMA peak (v_mfma_f32_32x32x2_f32: 256 FLOP/clk/CU x 256 CUs x 2.4 GHz)"},
            "parity": parity,
            "eager_ms_per_step": round(1e3 * dt_eager / args.steps, 4)}
     emit(out)
@@ -780,6 +1029,8 @@ def main():
         bench_c1(args)
     elif args.config == "c3sim":
         bench_c3sim(args)
+    elif args.config == "notebook":
+        bench_notebook(args)
     else:
         bench_c5(args)
 

@@ -16,12 +16,13 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend: str | None = None):
-    """Initialise from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT.  Returns (rank, world, device)."""
+def init_distributed(backend: str | None = None, cpu_only: bool = False):
+    """Initialise from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT.  Returns (rank, world, device).
+    cpu_only: never touch a GPU (no torch.cuda call at all), device = cpu, gloo transport."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    use_gpu = torch.cuda.is_available()
+    use_gpu = (not cpu_only) and torch.cuda.is_available()
     # Rehearsal on a box with fewer GPUs than ranks (CLIPK_REHEARSE_ONE_GPU=1, tests / tools only): every rank on cuda:0
     # and gloo as the transport (RCCL refuses two ranks on one device).  Same kernels, same rank bookkeeping.
     rehearse = (use_gpu and world > 1 and os.environ.get("CLIPK_REHEARSE_ONE_GPU") == "1"

@@ -136,6 +136,14 @@ def _bucket_begin(module):
         cb()
 
 
+def _bucket_backward_begin(module):
+    """Start of a stack's backward: if this stack's bucket has ALREADY been sent in this step (a count that went wrong, a
+    backward nobody announced), take it back before new gradient is written into it - it is reduced again when final."""
+    cb = getattr(module, "_grad_bucket_begin", None)
+    if cb is not None:
+        cb()
+
+
 def _bucket_done(module, grads):
     """End of a stack's backward: with every parameter gradient written straight into the flat .grad buffer (all
     returned grads None) and no other backward of this stack outstanding, the stack's gradient bucket is final, and a
@@ -303,6 +311,7 @@ class EsmStackFn(torch.autograd.Function):
             raise RuntimeError("EsmStackFn: second backward through the same forward: the stack frees each layer's "
                                "activations as its backward consumes them (retain_graph is not supported)")
         module, meta = ctx.module, ctx.meta
+        _bucket_backward_begin(module)
         x, fin_w, fin_b, mf, rf = ctx.fin
         nl = module.num_layers
         grads: List[Optional[torch.Tensor]] = [None] * (3 + 12 * nl)
@@ -643,6 +652,7 @@ class PostLNStackFn(torch.autograd.Function):
             raise RuntimeError("PostLNStackFn: second backward through the same forward: the stack frees each layer's "
                                "activations as its backward consumes them (retain_graph is not supported)")
         module, meta = ctx.module, ctx.meta
+        _bucket_backward_begin(module)
         x, fin_w, fin_b, mf, rf = ctx.fin
         nl = module.num_layers
         grads: List[Optional[torch.Tensor]] = [None] * (2 + 12 * nl)

@@ -374,11 +374,12 @@ def gemm_f32(a, b, trans_a=False, trans_b=False, bias=None, addend=None, addend_
     out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     if addend is not None:
         assert addend.shape == (M, N) and addend.stride(1) == 1
+    nb = 4.0 * (M * K + N * K + M * N * (2 if addend is not None else 1))     # operands once, output (+ addend) once
     check(_timed("gemm_f32", 2.0 * M * N * K,
                  lambda: _lib().clipk_gemm_f32(a.data_ptr(), a.stride(0), int(trans_a), b.data_ptr(), b.stride(0),
                                                int(trans_b), M, N, K, ptr(alpha), ptr(bias), ptr(addend),
                                                addend.stride(0) if addend is not None else 0, ptr(addend_scale),
-                                               out.data_ptr(), out.stride(0), _stream())), "clipk_gemm_f32")
+                                               out.data_ptr(), out.stride(0), _stream()), nb), "clipk_gemm_f32")
     return out
 
 

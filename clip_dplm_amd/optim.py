@@ -157,9 +157,9 @@ class FusedAdamW:
     def zero_grad(self):
         self.flat.zero_grad()
         self._reduced = [False] * len(self.flat.buckets)
-        for (_, _, root) in self.flat.buckets:
-            if root is not None:
-                root._bucket_pending = 0     # forwards that were never differentiated must not block the next step
+        # (the stacks' count of outstanding backwards is NOT reset here: with the common order forward -> zero_grad() ->
+        # backward a stack applied twice would fire its reduce-scatter after the first of its two backwards, ADVICE r03;
+        # step() clears it, so a forward that was never differentiated costs one step's overlap, never a gradient)
 
     def _retract_bucket(self, b: int) -> None:
         """A stack whose bucket was already sent in this step is about to produce more gradient (second backward()
@@ -225,6 +225,9 @@ class FusedAdamW:
             for (s0, s1, _), (lo, hi, _off) in zip(self.flat.buckets, self.pieces):
                 w = self.flat.data[lo:hi]
                 dist.all_gather_into_tensor(self.flat.data[s0:s1], w if self._nccl else w.clone(), group=self.group)
+        for (_, _, root) in self.flat.buckets:
+            if root is not None:
+                root._bucket_pending = 0     # forwards that were never differentiated must not block the next step
         KF.mark_weights_dirty()              # bf16 W / W^T copies of the Linear weights are stale now ...
         if self.flat.data.is_cuda and os.environ.get("CLIPK_BATCH_REFRESH", "1") != "0":
             KF.refresh_weight_caches()       # ... rebuild them in one launch (what is left is refreshed lazily)

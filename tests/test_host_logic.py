@@ -408,7 +408,8 @@ def _one_rank_gloo(tmp_path):
     return dist
 
 
-@pytest.mark.parametrize("mode", ["micro_batches", "two_backwards", "micro_batches+two_backwards"])
+@pytest.mark.parametrize("mode", ["micro_batches", "two_backwards", "micro_batches+two_backwards",
+                                  "micro_batches+zero_grad_after_forward"])
 def test_overlapped_bucket_reduce_waits_for_every_backward(monkeypatch, tmp_path, mode):
     """with `overlap=True` the encoder stacks start their bucket's reduce-scatter from inside the
     backward.  When a stack runs backward more than once per optimiser step (micro-batches; gradient accumulation over
@@ -438,8 +439,14 @@ def test_overlapped_bucket_reduce_waits_for_every_backward(monkeypatch, tmp_path
                 for b, (_, _, root) in enumerate(opt.flat.buckets):
                     if root is not None:
                         root._grad_bucket_done = (lambda b=b: opt._reduce_bucket(b))
-            opt.zero_grad()
-            m.loss(rna, ids).backward()
+            if "zero_grad_after_forward" in mode:         # forward -> zero_grad() -> backward (a common order)
+                opt.zero_grad()
+                loss = m.loss(rna, ids)
+                opt.zero_grad()                           # must not forget that two backwards of each stack are outstanding
+                loss.backward()
+            else:
+                opt.zero_grad()
+                m.loss(rna, ids).backward()
             if "two_backwards" in mode:
                 m.loss(rna.flip(0), ids).backward()
             gfull = opt.flat.grad.clone()
@@ -630,6 +637,9 @@ def test_bench_self_launch_plumbing_with_two_gloo_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["checksum"] == 1024 * 2.0 * (1 + 2)                     # the all-reduce saw both ranks
+    # the line says what the collective library saw (VERDICT r03 #6a; "rccl" on the GPU path, gloo in this rehearsal)
+    assert out["rccl"]["world"] == 2 and out["rccl"]["ranks_seen"] == 2 and out["rccl"]["backend"] == "gloo"
+    assert sorted(d["rank"] for d in out["rccl"]["devices"]) == [0, 1]
     assert "library chatter" in r.stderr and "library chatter" not in r.stdout
     # a rank that dies after the rendezvous: the launcher's return code is the bench's
     r = _run_bench(["--config", "stub", "--gpus", "2", "--steps", "1", "--warmup", "0"],

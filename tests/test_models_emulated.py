@@ -22,6 +22,7 @@ CASES = [
     ("esm_tiny", T.test_esm_tiny_golden, {}),
     ("protein_rna", T.test_protein_rna_clip_vs_oracle, {}),
     ("adamw_train", T.test_fused_adamw_training_reduces_loss, {}),
+    ("trajectory", T.test_training_trajectory_matches_the_oracle, {}),
     ("icnn", T.test_icnn_transport_golden, {}),
     ("icnn_train_A", T.test_icnn_training_through_transport_map_golden, {"case": "A"}),
     ("icnn_train_B", T.test_icnn_training_through_transport_map_golden, {"case": "B"}),
