@@ -80,36 +80,9 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {     // Phi(x) + x phi(
   const float cdf = fmaf(copysignf(0.5f, x), erf_abs, 0.5f);
   return fmaf(x * 0.39894228040143267794f, e, cdf);
 }
-// Two elements at a time on the packed-f32 pipe (v_pk_fma_f32 / v_pk_mul_f32: 2 results per issue slot): 9 VALU + 2
-// transcendentals per element instead of 15 + 2.  Same arithmetic as gelu_parts, element for element.
+// packed-f32 pipe (v_pk_fma_f32 / v_pk_mul_f32: 2 results per issue slot): see gelu_erf8 below
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 splat2(float c) { return f32x2{c, c}; }
-__device__ __forceinline__ void gelu_parts2(f32x2 x, f32x2 ax, f32x2& erf_abs, f32x2& e) {
-  const f32x2 d = __builtin_elementwise_fma(splat2(0.3275911f * 0.70710678118654752440f), ax, splat2(1.0f));
-  const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-  const f32x2 xx = (x * splat2(-0.72134752044448170368f)) * x;
-  e = f32x2{__builtin_amdgcn_exp2f(xx[0]), __builtin_amdgcn_exp2f(xx[1])};
-  f32x2 poly = __builtin_elementwise_fma(splat2(1.061405429f), t, splat2(-1.453152027f));
-  poly = __builtin_elementwise_fma(poly, t, splat2(1.421413741f));
-  poly = __builtin_elementwise_fma(poly, t, splat2(-0.284496736f));
-  poly = __builtin_elementwise_fma(poly, t, splat2(0.254829592f));
-  erf_abs = __builtin_elementwise_fma(-(poly * t), e, splat2(1.0f));
-}
-__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
-  const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
-  f32x2 erf_abs, e;
-  gelu_parts2(x, ax, erf_abs, e);
-  return __builtin_elementwise_fma(ax * splat2(0.5f), erf_abs, x * splat2(0.5f));
-}
-__device__ __forceinline__ f32x2 gelu_erf_grad2(f32x2 x) {
-  const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
-  f32x2 erf_abs, e;
-  gelu_parts2(x, ax, erf_abs, e);
-  const f32x2 half_sgn = {copysignf(0.5f, x[0]), copysignf(0.5f, x[1])};
-  const f32x2 cdf = __builtin_elementwise_fma(half_sgn, erf_abs, splat2(0.5f));
-  return __builtin_elementwise_fma(x * splat2(0.39894228040143267794f), e, cdf);
-}
-
 __device__ __forceinline__ float act_apply(float x, int act) {
   if (act == CLIPK_ACT_RELU) return x > 0.f ? x : 0.f;
   if (act == CLIPK_ACT_GELU) return gelu_erf(x);
@@ -126,12 +99,15 @@ __device__ __forceinline__ float act_grad(float x, int act) {
 }
 
 // ---- GELU'(u) as an 8-bit code: what the FFN keeps for its backward instead of the bf16 pre-activation u.
-// GELU' takes values in [-0.1290, 1.1290]; the code is the nearest of 256 levels over [-0.13, 1.13] (step 0.00494, error
-// <= 0.0025 absolute - the size of a bf16 rounding of a value near 1): half the bytes of u in the two store-bound FFN
-// epilogues, no erf in the backward one.  The forward value GELU(u) is untouched.
-constexpr float CLIPK_GD8_MIN = -0.13f, CLIPK_GD8_STEP = 1.26f / 255.0f, CLIPK_GD8_INV = 255.0f / 1.26f;
+// GELU' takes values in [-0.1290, 1.1290]; the code is the nearest of 256 levels of step 0.005 starting at -0.13
+// (levels -0.13 ... 1.145; error <= 0.0025 absolute - the size of a bf16 rounding of a value near 1): half the bytes of u
+// in the two store-bound FFN epilogues, no erf in the backward one.  The forward value GELU(u) is untouched.
+// The grid is chosen so that the two values most hidden units take ARE code points (on the round-3 grid
+// [-0.13, 1.13] / 255 a dead unit decoded to -0.0015 and a saturated one to 1.0015, a bias of one sign per class of unit
+// in every layer): GELU' = 0 -> code 26 -> fma(26, 0.005f, -0.13f) = 1.9e-9, GELU' = 1 -> code 226 -> exactly 1.0f.
+constexpr float CLIPK_GD8_MIN = -0.13f, CLIPK_GD8_STEP = 0.005f, CLIPK_GD8_INV = 200.0f, CLIPK_GD8_OFF = 26.0f;
 __device__ __forceinline__ unsigned gelu_grad_code(float d) {                 // d = GELU'(u) -> 0 .. 255
-  float t = fmaf(d, CLIPK_GD8_INV, -CLIPK_GD8_MIN * CLIPK_GD8_INV + 0.5f);    // + 0.5: v_cvt_u32_f32 truncates
+  float t = fmaf(d, CLIPK_GD8_INV, CLIPK_GD8_OFF + 0.5f);                     // + 0.5: v_cvt_u32_f32 truncates
   t = t < 0.f ? 0.f : (t > 255.f ? 255.f : t);
   return (unsigned)t;
 }
@@ -143,21 +119,84 @@ __device__ __forceinline__ u32x2 gelu_grad_pack8(const float (&d)[8]) {
   w[1] = gelu_grad_code(d[4]) | (gelu_grad_code(d[5]) << 8) | (gelu_grad_code(d[6]) << 16) | (gelu_grad_code(d[7]) << 24);
   return w;
 }
-// GELU(x) and the code of GELU'(x) for two elements from ONE evaluation of erf / exp, the code's scale and offset folded
-// into the derivative's own two fmas: t = (Phi + x phi) * INV - MIN * INV, written into byte `b`, `b + 1` of `w` by
-// v_cvt_pk_u8_f32, which ROUNDS to nearest and saturates to 0 .. 255 (measured: with the + 0.5 of the truncating
-// v_cvt_u32_f32 path every code came out half a level high; the GPU test bounds the mean code error)
-__device__ __forceinline__ f32x2 gelu_erf2_code(f32x2 x, unsigned& w, int b) {
-  const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
-  f32x2 erf_abs, e;
-  gelu_parts2(x, ax, erf_abs, e);
-  constexpr float C0 = 0.5f * CLIPK_GD8_INV - CLIPK_GD8_MIN * CLIPK_GD8_INV;
-  const f32x2 hs = {copysignf(0.5f * CLIPK_GD8_INV, x[0]), copysignf(0.5f * CLIPK_GD8_INV, x[1])};
-  const f32x2 cdf = __builtin_elementwise_fma(hs, erf_abs, splat2(C0));
-  const f32x2 t = __builtin_elementwise_fma(x * splat2(0.39894228040143267794f * CLIPK_GD8_INV), e, cdf);
-  w = __builtin_amdgcn_cvt_pk_u8_f32(t[0], b, w);
-  w = __builtin_amdgcn_cvt_pk_u8_f32(t[1], b + 1, w);
-  return __builtin_elementwise_fma(ax * splat2(0.5f), erf_abs, x * splat2(0.5f));
+// GELU(x) as packed bf16 and (CODE) the code of GELU'(x) for EIGHT elements from one evaluation of erf / exp each - the
+// FFN epilogue of the Linear kernels, whose instruction time is purely additive to the main loop (MFMA and VALU of one
+// SIMD do not overlap on gfx950).  Round 4 rewrite, counted in the ISA of gemm_nt_v3_kernel<GELU_D8>
+// per output pair: 17 packed + 7 plain VALU + 4 transcendentals + 3.3 hazard s_nop  ->  13 + 7 + 4 + 0:
+//   * written STAGE BY STAGE over the four pairs: a v_pk_*_f32 whose operand is the previous packed result needs a wait
+//     state, and with one pair's dependent chain after the other hipcc filled those with s_nop (214 per tile and wave);
+//   * |x| as the source modifier of a plain v_fma_f32 (VOP3P has none): no v_and, no separate packed fma for 1 + p|x|;
+//   * Phi(x) = 1/2 + copysign(1/2, x) erf(|x| / sqrt 2) once, GELU = x Phi and GELU' = Phi + x phi(x) both from it (the
+//     round-3 form evaluated 0.5 |x| erf + 0.5 x and a separately scaled cdf: one packed multiply more);
+//   * erf still by Abramowitz-Stegun 7.1.26 (five coefficients, |err| <= 1.5e-7): with the three-coefficient 7.1.25
+//     the error reaches 3.2 half-ulps of the bf16 result at x = -3.4 (measured over the f32 grid), 7.1.26 stays at 0.11.
+template <bool CODE>
+__device__ __forceinline__ void gelu_erf8(const float (&v)[8], u32x4& o, unsigned (&q)[2]) {
+  constexpr float P = 0.3275911f * 0.70710678118654752440f;
+  // (sched_barrier: hipcc's scheduler otherwise re-serialises the stages into one dependent chain per pair to save
+  // registers, and pays for it with a wait state between every two packed instructions)
+#define GELU8_FENCE() __builtin_amdgcn_sched_barrier(0)
+  f32x2 x[4], t[4], e[4], pl[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) x[c] = f32x2{v[2 * c], v[2 * c + 1]};
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    t[c] = f32x2{__builtin_amdgcn_rcpf(fmaf(fabsf(v[2 * c]), P, 1.0f)), __builtin_amdgcn_rcpf(fmaf(fabsf(v[2 * c + 1]), P, 1.0f))};
+  GELU8_FENCE();
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const f32x2 xx = (x[c] * splat2(-0.72134752044448170368f)) * x[c];
+    e[c] = f32x2{__builtin_amdgcn_exp2f(xx[0]), __builtin_amdgcn_exp2f(xx[1])};
+  }
+  GELU8_FENCE();
+#pragma unroll
+  for (int c = 0; c < 4; ++c) pl[c] = __builtin_elementwise_fma(splat2(1.061405429f), t[c], splat2(-1.453152027f));
+  GELU8_FENCE();
+#pragma unroll
+  for (int c = 0; c < 4; ++c) pl[c] = __builtin_elementwise_fma(pl[c], t[c], splat2(1.421413741f));
+  GELU8_FENCE();
+#pragma unroll
+  for (int c = 0; c < 4; ++c) pl[c] = __builtin_elementwise_fma(pl[c], t[c], splat2(-0.284496736f));
+  GELU8_FENCE();
+#pragma unroll
+  for (int c = 0; c < 4; ++c) pl[c] = __builtin_elementwise_fma(pl[c], t[c], splat2(0.254829592f));
+  GELU8_FENCE();
+#pragma unroll
+  for (int c = 0; c < 4; ++c) pl[c] = pl[c] * t[c];
+  GELU8_FENCE();
+#pragma unroll
+  for (int c = 0; c < 4; ++c) pl[c] = __builtin_elementwise_fma(-pl[c], e[c], splat2(1.0f));        // erf(|x| / sqrt 2)
+  GELU8_FENCE();
+#pragma unroll
+  for (int c = 0; c < 4; ++c)                                                                        // Phi(x)
+    pl[c] = __builtin_elementwise_fma(f32x2{copysignf(0.5f, v[2 * c]), copysignf(0.5f, v[2 * c + 1])}, pl[c], splat2(0.5f));
+  GELU8_FENCE();
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const f32x2 y = x[c] * pl[c];
+    o[c] = pack_bf16x2(y[0], y[1]);
+  }
+  GELU8_FENCE();
+  if constexpr (CODE) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) t[c] = x[c] * splat2(0.39894228040143267794f);
+  GELU8_FENCE();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) t[c] = __builtin_elementwise_fma(t[c], e[c], pl[c]);                    // GELU' = Phi + x phi
+  GELU8_FENCE();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) t[c] = __builtin_elementwise_fma(t[c], splat2(CLIPK_GD8_INV), splat2(CLIPK_GD8_OFF));
+  GELU8_FENCE();
+    // v_cvt_pk_u8_f32 ROUNDS to nearest and saturates to 0 .. 255 (a + 0.5 as for the truncating v_cvt_u32_f32 left every
+    // code half a level high: the GPU test bounds the mean code error)
+    unsigned w0 = 0u, w1 = 0u;
+    w0 = __builtin_amdgcn_cvt_pk_u8_f32(t[0][0], 0, w0); w0 = __builtin_amdgcn_cvt_pk_u8_f32(t[0][1], 1, w0);
+    w0 = __builtin_amdgcn_cvt_pk_u8_f32(t[1][0], 2, w0); w0 = __builtin_amdgcn_cvt_pk_u8_f32(t[1][1], 3, w0);
+    w1 = __builtin_amdgcn_cvt_pk_u8_f32(t[2][0], 0, w1); w1 = __builtin_amdgcn_cvt_pk_u8_f32(t[2][1], 1, w1);
+    w1 = __builtin_amdgcn_cvt_pk_u8_f32(t[3][0], 2, w1); w1 = __builtin_amdgcn_cvt_pk_u8_f32(t[3][1], 3, w1);
+    q[0] = w0; q[1] = w1;
+  }
+#undef GELU8_FENCE
 }
 
 // second derivative of the activations the ICNN potential uses (2_icnn_core.py:121-127: CELU default, softplus): the

@@ -41,13 +41,20 @@ enum {
   EPI_ROPE = 6,       // bf16 out = rotate-half RoPE of (acc + bias) on the first rope_cols columns, plain on the rest
   EPI_GELU_D8 = 7,    // u8 GELU'(pre-activation) code out and bf16 GELU out (+bias)
   EPI_DGELU8 = 8,     // bf16 out = acc * decode(u8 aux)
+  EPI_PLAIN_NB = 9,   // bf16 out, no bias (the plain input gradients)
 };
+// Every specialised mode requires alpha == 1 (no caller scales the product: one packed multiply per output pair gone from
+// every epilogue), and the modes that only input-gradient GEMMs use - DGELU, DGELU8, PRES16, PLAIN_NB - take no bias
+// (another packed add per pair): round 4, counted in the ISA (plain epilogue: 2 packed ops + 1 convert per pair -> 0 + 1).
+constexpr bool epi_no_bias(int mode) {
+  return mode == EPI_DGELU || mode == EPI_DGELU8 || mode == EPI_PRES16 || mode == EPI_PLAIN_NB;
+}
 constexpr int EPI_UNSUPPORTED = -2;   // epi_mode_for: the request cannot be honoured by any epilogue
 
 // VMEM stores one wave issues in gemm_epilogue<MODE, NJ> (its loads are consumed inside): callers that keep LDS-DMA
 // in flight across the epilogue count them in their s_waitcnt vmcnt(N)
 constexpr int epi_stores(int mode, int nj) {
-  return (mode == EPI_PLAIN || mode == EPI_DGELU || mode == EPI_PRES16 || mode == EPI_ROPE || mode == EPI_DGELU8) ? 2 * nj
+  return (mode == EPI_PLAIN || mode == EPI_PLAIN_NB || mode == EPI_DGELU || mode == EPI_PRES16 || mode == EPI_ROPE || mode == EPI_DGELU8) ? 2 * nj
          : (mode == EPI_RES32 || mode == EPI_GELU_PRE || mode == EPI_RES16 || mode == EPI_GELU_D8) ? 4 * nj : -1;
 }
 
@@ -56,6 +63,7 @@ static inline int epi_mode_for(const clipk_gemm_args* a) {
   const bool c_f32 = a->c_dtype == CLIPK_F32, has_res = a->residual != nullptr, has_aux = a->dact_aux != nullptr;
   const bool has_pre = a->out_preact != nullptr;
   const bool aux8 = a->aux_dtype == CLIPK_U8;
+  const bool has_bias = a->bias != nullptr;
   if (aux8) {                                            // 8-bit GELU' codes: the FFN pair only
     if (has_pre && (a->act != CLIPK_ACT_GELU || (a->ldp & 7))) return EPI_UNSUPPORTED;
     if (has_aux && (a->dact != CLIPK_ACT_GELU || (a->ldd & 7))) return EPI_UNSUPPORTED;
@@ -65,21 +73,24 @@ static inline int epi_mode_for(const clipk_gemm_args* a) {
     const int hd = a->rope_hd;
     const bool ok = a->rope_sin && (hd == 16 || hd == 32 || hd == 64) && a->rope_L > 0 && a->rope_cols > 0 &&
                     a->rope_cols % hd == 0 && a->rope_cols <= a->N && a->rope_row0 >= 0 && !c_f32 && !has_res &&
-                    !has_aux && !has_pre && a->act == CLIPK_ACT_NONE && a->drop_p <= 0.f &&
+                    !has_aux && !has_pre && a->act == CLIPK_ACT_NONE && a->drop_p <= 0.f && a->alpha == 1.0f &&
                     ((long)(a->M - 1) * a->ldc + a->N) * 2 <= lim;
     return ok ? EPI_ROPE : EPI_UNSUPPORTED;
   }
   if (a->drop_p > 0.f) return EPI_GENERIC;               // dropout lives in the run-time epilogue
+  if (a->alpha != 1.0f) return EPI_GENERIC;              // the straight-line modes do not scale the product
   if (((long)(a->M - 1) * a->ldc + a->N) * (c_f32 ? 4 : 2) > lim) return EPI_GENERIC;
   if (has_pre && ((long)(a->M - 1) * a->ldp + a->N) * (aux8 ? 1 : 2) > lim) return EPI_GENERIC;
-  if (a->act == CLIPK_ACT_NONE && !has_aux && !has_res && !has_pre && !c_f32) return EPI_PLAIN;
+  if (a->act == CLIPK_ACT_NONE && !has_aux && !has_res && !has_pre && !c_f32) return has_bias ? EPI_PLAIN : EPI_PLAIN_NB;
   if (a->act == CLIPK_ACT_NONE && !has_aux && has_res && a->r_dtype == CLIPK_F32 && !has_pre && c_f32) return EPI_RES32;
-  if (a->act == CLIPK_ACT_NONE && !has_aux && has_res && a->r_dtype == CLIPK_BF16 && !has_pre)
-    return c_f32 ? EPI_RES16 : EPI_PRES16;
+  if (a->act == CLIPK_ACT_NONE && !has_aux && has_res && a->r_dtype == CLIPK_BF16 && !has_pre) {
+    if (c_f32) return EPI_RES16;
+    return has_bias ? EPI_GENERIC : EPI_PRES16;          // bf16 out + bf16 residual: the post-LN input gradients (no bias)
+  }
   // (without a pre-activation output — frozen encoders keep nothing for a backward — the same mode runs with a
   // zero-length descriptor for u: the hardware drops those stores)
   if (a->act == CLIPK_ACT_GELU && !has_aux && !has_res && !c_f32) return (aux8 && has_pre) ? EPI_GELU_D8 : EPI_GELU_PRE;
-  if (a->act == CLIPK_ACT_NONE && has_aux && a->dact == CLIPK_ACT_GELU && !has_res && !has_pre && !c_f32)
+  if (a->act == CLIPK_ACT_NONE && has_aux && a->dact == CLIPK_ACT_GELU && !has_res && !has_pre && !c_f32 && !has_bias)
     return aux8 ? EPI_DGELU8 : EPI_DGELU;
   return EPI_GENERIC;
 }
@@ -214,9 +225,9 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       const int j = s >> 1;
-      if ((s & 1) == 0) {
+      if ((s & 1) == 0) {                                  // (alpha == 1 in every specialised mode: epi_mode_for)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(eb + slab_off<SWZ>(li, i * 4 + g)) = acc[i][j] * alpha;
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(eb + slab_off<SWZ>(li, i * 4 + g)) = acc[i][j];
       }
 #pragma unroll
       for (int t = (s == 0 ? 0 : hi(s - 1) + 1); t <= hi(s); ++t)
@@ -229,7 +240,10 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(eb + slab_off<SWZ>(row, ecol >> 2));
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(eb + slab_off<SWZ>(row, (ecol >> 2) + 1));
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { v[c] = v0[c] + bv[c]; v[4 + c] = v1[c] + bv[4 + c]; }
+        for (int c = 0; c < 4; ++c) {
+          v[c] = epi_no_bias(MODE) ? v0[c] : v0[c] + bv[c];
+          v[4 + c] = epi_no_bias(MODE) ? v1[c] : v1[c] + bv[4 + c];
+        }
       }
       const bool ok = col_ok && gm < M;
       if constexpr (MODE == EPI_ROPE) {
@@ -252,7 +266,7 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
         }
         const unsigned off = ok ? (unsigned)(((long)gm * p.ldc + gn) * 2) : OOB;
         epi_store(o, c_rsrc, off, p.nt);
-      } else if constexpr (MODE == EPI_PLAIN) {
+      } else if constexpr (MODE == EPI_PLAIN || MODE == EPI_PLAIN_NB) {
         u32x4 o;
 #pragma unroll
         for (int c = 0; c < 4; ++c) o[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
@@ -287,26 +301,19 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
         }
       } else if constexpr (MODE == EPI_GELU_PRE) {
         u32x4 u, o;
+        unsigned qq[2];
 #pragma unroll
         for (int c = 0; c < 4; ++c) u[c] = pack_bf16x2(v[2 * c], v[2 * c + 1]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const f32x2 y = gelu_erf2(f32x2{v[2 * c], v[2 * c + 1]});           // packed-f32 pipe
-          o[c] = pack_bf16x2(y[0], y[1]);
-        }
+        gelu_erf8<false>(v, o, qq);                                            // packed-f32 pipe, stage by stage
         const unsigned offu = (ok && p.out_preact) ? (unsigned)(((long)gm * p.ldp + gn) * 2) : OOB;
         const unsigned off = ok ? (unsigned)(((long)gm * p.ldc + gn) * 2) : OOB;
         epi_store(u, u_rsrc, offu, p.nt);
         epi_store(o, c_rsrc, off, p.nt);
       } else if constexpr (MODE == EPI_GELU_D8) {
         u32x4 o;
-        unsigned q0 = 0u, q1 = 0u;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const f32x2 y = gelu_erf2_code(f32x2{v[2 * c], v[2 * c + 1]}, c < 2 ? q0 : q1, 2 * (c & 1));   // packed-f32 pipe
-          o[c] = pack_bf16x2(y[0], y[1]);
-        }
-        const u32x2 q = {q0, q1};
+        unsigned qq[2];
+        gelu_erf8<true>(v, o, qq);
+        const u32x2 q = {qq[0], qq[1]};
         const unsigned offu = (ok && p.out_preact) ? (unsigned)((long)gm * p.ldp + gn) : OOB;
         const unsigned off = ok ? (unsigned)(((long)gm * p.ldc + gn) * 2) : OOB;
         if (p.nt) __builtin_amdgcn_raw_buffer_store_b64(q, u_rsrc, offu, 0, 2);

@@ -201,6 +201,7 @@ extern "C" int clipk_gemm_nt_v2_launch(const clipk_gemm_args* a, void* stream) {
     else if (mode == EPI_ROPE) hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, EPI_ROPE>), grid, blk, lds, st, p);
     else if (mode == EPI_GELU_D8) hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, EPI_GELU_D8>), grid, blk, lds, st, p);
     else if (mode == EPI_DGELU8) hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, EPI_DGELU8>), grid, blk, lds, st, p);
+    else if (mode == EPI_PLAIN_NB) hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, EPI_PLAIN_NB>), grid, blk, lds, st, p);
     else hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1>), grid, blk, lds, st, p);
   }
   return clipk_check_launch();

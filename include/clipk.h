@@ -90,8 +90,9 @@ typedef struct clipk_gemm_args {
   const float* rope_cos; const float* rope_sin; int rope_L, rope_hd, rope_cols, rope_row0;
   /* aux_dtype = CLIPK_U8 (act / dact must be GELU): the auxiliary tensor of the FFN pair is the DERIVATIVE GELU'(v) as an
    * 8-bit code instead of the bf16 pre-activation v - out_preact receives u8 [M, N] codes (ldp in bytes, % 8 == 0),
-   * dact_aux is read as such codes and the product is multiplied by the decoded value: code = round((GELU'(v) + 0.13) *
-   * 255 / 1.26), 256 levels over [-0.13, 1.13] (GELU' lies in [-0.129, 1.129]), error <= 0.0025 - half the bytes of the
+   * dact_aux is read as such codes and the product is multiplied by the decoded value: code = round(GELU'(v) * 200 + 26),
+   * decoded as -0.13 + 0.005 code: 256 levels from -0.13 to 1.145 (GELU' lies in [-0.129, 1.129]) with GELU' = 0 and
+   * GELU' = 1 - what dead and saturated units take - code points themselves, error <= 0.0025 - half the bytes of the
    * pre-activation in the two store-bound FFN epilogues of EsmLayer / nn.TransformerEncoderLayer(activation = gelu)
    * (modeling_esm.py:517-521; run1/configuration_hybrid_clip.py:75 hidden_act), nothing but the backward's GELU' factor
    * is affected.  CLIPK_BF16 (0): the pre-activation itself, as before. */

@@ -58,12 +58,12 @@ def drop_mult(p, seed, idx):
     return (drop_hash32(seed, idx) >= thr).float() / (1.0 - p)
 
 
-GD8_MIN, GD8_STEP = -0.13, 1.26 / 255.0
+GD8_MIN, GD8_STEP = -0.13, 0.005          # code 26 <-> GELU' = 0, code 226 <-> GELU' = 1 (csrc/common.h)
 
 
 def gelu_grad_code(x):
-    """clipk.h aux_dtype = U8: GELU'(x) -> nearest of 256 levels over [-0.13, 1.13]."""
-    return torch.clamp(torch.floor((_act_grad(x, "gelu") - GD8_MIN) / GD8_STEP + 0.5), 0, 255).to(torch.uint8)
+    """clipk.h aux_dtype = U8: GELU'(x) -> nearest of 256 levels -0.13 + 0.005 k."""
+    return torch.clamp(torch.floor(_act_grad(x, "gelu") * 200.0 + 26.0 + 0.5), 0, 255).to(torch.uint8)
 
 
 def gemm_nt(a, b, bias=None, act=None, out_dtype=BF, residual=None, out_preact=False, dact_aux=None, dact=None,

@@ -135,7 +135,7 @@ def test_gemm_nt_specialised_epilogues(dev, kopt, kernel, M, N, K):
     assert torch.equal(g8, g)                                   # the forward value does not depend on the aux format
     pre = (ref + bias).requires_grad_(True)
     dref, = torch.autograd.grad(F.gelu(pre), pre, torch.ones_like(pre))
-    step, lo = 1.26 / 255.0, -0.13
+    step, lo = 0.005, -0.13                                     # code 26 <-> 0, code 226 <-> 1 (csrc/common.h)
     dec = q.float() * step + lo
     # the kernel's pre-activation differs from torch's f32 product by summation order only: codes within one level
     assert (dec - dref).abs().max().item() <= 1.5 * step, (dec - dref).abs().max().item()
@@ -1130,3 +1130,25 @@ def test_dropout_f32_kernel_matches_the_epilogue_mask(dev):
     yg = ops.gemm_nt(xb, eye, out_dtype=torch.float32, dropout=(0.1, 99))
     yd = ops.dropout_f32(xb.float(), (0.1, 99))
     assert torch.equal(yg == 0, yd == 0)
+
+
+@pytest.mark.parametrize("kernel", ["v2", "v3"])
+def test_gelu_grad_code_grid_has_zero_and_one_as_code_points(dev, kopt, kernel):
+    """the 8-bit GELU' levels are -0.13 + 0.005 k, so a dead unit (GELU' = 0) is code 26 and decodes
+    to 0 (1.9e-9 in f32) and a saturated one (GELU' = 1) is code 226 and decodes to exactly 1 - no bias of one sign per class
+    of unit (the round-3 grid decoded them to -0.0015 / 1.0015)."""
+    ops = _ops()
+    kopt("gemm_kernel", _GEMM_KERNEL[kernel])
+    M, N, K = 2304, 256, 64
+    a = torch.zeros(M, K, dtype=torch.bfloat16, device=dev)
+    b = _rand((N, K), dev, 3, 0.05, dtype=torch.bfloat16)
+    bias = torch.full((N,), -30.0, device=dev)
+    bias[N // 2:] = 30.0
+    g, q = ops.gemm_nt(a, b, bias=bias, act="gelu", out_preact=True, aux_u8=True)
+    assert (q[:, : N // 2] == 26).all() and (q[:, N // 2:] == 226).all()
+    assert (g[:, : N // 2] == 0).all() and (g[:, N // 2:].float() == 30.0).all()
+    x = _rand((M, K), dev, 4, dtype=torch.bfloat16)
+    ref = ops.gemm_nt(x, b).float()                             # the same product through the plain epilogue
+    d = ops.gemm_nt(x, b, dact_aux=q, dact="gelu").float()
+    assert torch.equal(d[:, N // 2:], ref[:, N // 2:])                                      # x 1.0 exactly
+    assert d[:, : N // 2].abs().max().item() <= 4e-9 * ref.abs().max().item()              # x 1.9e-9
