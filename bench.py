@@ -63,6 +63,9 @@ def parse_args():
     ap.add_argument("--variant", default="sliced-f32", choices=["sliced-f32", "sliced-bf16", "full-bf16", "full-f32"],
                     help="notebook only: sliced = position 0 before the encoders (exact), full = every position as the "
                          "notebook computes them; f32 / bf16 = the arithmetic")
+    ap.add_argument("--eager", action="store_true",
+                    help="notebook only: issue the step's launches eagerly instead of replaying them from one hipGraph "
+                         "(training.GraphedTrainStep, the default)")
     ap.add_argument("--batch", type=int, default=None, help="pairs per GPU (default: 1024 for c2, 256 for c4, 4096 for c5)")
     ap.add_argument("--seq-len", type=int, default=None)
     ap.add_argument("--esm", default=None)
@@ -784,12 +787,19 @@ def bench_notebook(args):
         loss.backward()
         opt.step()
         return loss
+    run = step
+    if not args.eager:
+        # the sliced step is ~350 launches of microsecond kernels: replayed from ONE hipGraph (inputs, learning rate and
+        # AdamW's bias corrections live in device memory)
+        from clip_dplm_amd.training import GraphedTrainStep
+        gstep = GraphedTrainStep(model, opt, lambda a, b: model(a, b)[2], (rna_d, rbp_d))
+        run = lambda: gstep(rna_d, rbp_d)
     for _ in range(args.warmup):
-        step()
+        run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = run()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     timer = ops.KernelTimer()
@@ -823,7 +833,8 @@ def bench_notebook(args):
            "scaling": "weak", "vs_baseline": None, "dtype": prec, "data": "synthetic",
            "config": {"workload": f"RNARBPCLIPModel(120, 1280, 512), {nparam} parameters, rna [{B}, {Lr}, 120] x rbp "
                                   f"[{B}, {Lp}, 1280] with ragged NaN padding, training step (fwd + symmetric InfoNCE + bwd + "
-                                  f"clip + fused AdamW), variant {args.variant}"},
+                                  f"clip + fused AdamW), variant {args.variant}, "
+                                  + ("launches issued eagerly" if args.eager else "step replayed from one hipGraph")},
            "loss": round(float(loss.item()), 5), "roofline": roof, "kernels": kernels,
            "step_hbm_floor": {"algorithmic_bytes_per_step": int(step_bytes),
                               "ms_at_8TBps": round(step_bytes / 8e12 * 1e3, 4),

@@ -65,7 +65,8 @@ SIGNATURES = {
     "clipk_ce_logits_lse": (_i, [_vp, _i64, _i, _i, _vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
     "clipk_ce_logits_bwd": (_i, [_vp, _i64, _i, _i, _vp, _i64, _i, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _i64, _vp, _i64, _vp]),
     "clipk_transpose_scale_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
-    "clipk_gemm_f32": (_i, [_vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp]),
+    "clipk_gemm_f32_workspace": (_sz, [_i, _i, _i, _i, _i]),
+    "clipk_gemm_f32": (_i, [_vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _sz, _vp]),
     "clipk_gemm_f32_nt": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "clipk_layernorm_fwd": (_i, [_vp, _i, _i64, _vp, _vp, _f, _i, _vp, _vp, _i64, _vp, _vp, _i, _i, _vp]),
     "clipk_layernorm_bwd_workspace": (_sz, [_i, _i]),
@@ -95,6 +96,7 @@ SIGNATURES = {
     "clipk_attn_f32_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, C.c_uint32, _vp]),
     "clipk_attn_f32_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, C.c_uint32, _vp]),
     "clipk_dropout_f32": (_i, [_vp, _vp, _vp, _i64, _f, C.c_uint32, _vp]),
+    "clipk_colsum_f32": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "clipk_embed_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "clipk_embed_bwd_workspace": (_sz, [_i, _i, _i, _i]),
     "clipk_embed_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
@@ -105,7 +107,7 @@ SIGNATURES = {
     "clipk_pool_varlen_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "clipk_sumsq_workspace": (_sz, [_i64]),
     "clipk_sumsq": (_i, [_vp, _i64, _vp, _vp, _sz, _vp]),
-    "clipk_adamw_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp]),
+    "clipk_adamw_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp, _vp]),
 }
 
 _lib = None

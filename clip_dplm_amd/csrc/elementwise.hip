@@ -428,7 +428,10 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const float* part, int
 
 __global__ void adamw_kernel(float* w, const float* g, float* m, float* v, unsigned short* wb, long n, float lr,
                              float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt,
-                             const float* gnsq, float max_norm, float grad_scale) {
+                             const float* gnsq, float max_norm, float grad_scale, const float* hyper) {
+  if (hyper) {                    // {lr, 1 - beta1^t, sqrt(1 - beta2^t)} from device memory: a step replayed from a hipGraph
+    lr = hyper[0]; bc1 = hyper[1]; bc2_sqrt = hyper[2];
+  }
   float clip = grad_scale;
   if (gnsq) {
     // torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
@@ -603,14 +606,16 @@ extern "C" int clipk_sumsq(const float* g, int64_t n, float* out, void* workspac
 }
 extern "C" int clipk_adamw_step(float* w, const float* g, float* m, float* v, void* w_bf16, int64_t n, float lr,
                                 float beta1, float beta2, float eps, float weight_decay, int step,
-                                const float* grad_norm_sq, float max_norm, float grad_scale, void* stream) {
-  if (!w || !g || !m || !v || n <= 0 || step < 1) return CLIPK_ERR_BAD_ARG;
+                                const float* grad_norm_sq, float max_norm, float grad_scale, const float* hyper_dev,
+                                void* stream) {
+  if (!w || !g || !m || !v || n <= 0 || (step < 1 && !hyper_dev)) return CLIPK_ERR_BAD_ARG;
+  if (hyper_dev && step < 1) step = 1;
   // bias corrections in double on the host, as torch.optim.AdamW computes them (f32 powf is ~6e-5 off in 1 - beta2^t
   // at small t)
   const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   hipLaunchKernelGGL(adamw_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, w, g, m, v,
                      (unsigned short*)w_bf16, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s,
-                     grad_norm_sq, max_norm, grad_scale);
+                     grad_norm_sq, max_norm, grad_scale, hyper_dev);
   return clipk_check_launch();
 }

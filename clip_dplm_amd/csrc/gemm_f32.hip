@@ -27,6 +27,9 @@ struct GP {
   float* out; long ldo;
   const float* bias; const float* addend; long ldadd; const float* addend_scale; const float* alpha;
   int M, N, K, transA, transB;
+  // skinny form only: S-way split of the contraction ACROSS workgroups (grid.y = S); the partial tiles
+  // [S][N / 32][MB][32][32] live in the caller's workspace
+  int S; float* parts;
 };
 
 // stage one BK-deep slice of an operand tile [ROWS][BK] into registers (RPT float4 per thread)
@@ -167,17 +170,224 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Skinny form: M <= 64 rows against a large weight - every Linear (forward and input gradient) of the models that pool
+// ONE position and are sliced to it before their encoders (RNARBPCLIPModel / ContrastiveModel: M = batch = 32 rows
+// through 71.6 M f32 parameters, rna_clip_codes.ipynb:1925-1954).  Such a launch is a single pass over the weight: HBM-bound
+// at 2 M FLOP per weight byte / 4, and the tiled kernel above walked its whole contraction in ONE workgroup per 64
+// output columns (40 - 80 workgroups, 50 - 220 us for 6 - 26 MB).  Here:
+//   * one workgroup of SIXTEEN waves per 32 output columns; the waves split the contraction 16 ways (runs of 32-index
+//     units), so a CU has 16 independent load streams in flight, and N / 32 workgroups x 16 waves cover the chip's load
+//     issue capacity;
+//   * each lane feeds the f32 MFMA straight from its loads: A (the M rows) as consecutive float4 along the contraction
+//     (whole 128-byte lines per lane and trip), B either the same way (weight stored [N][K]: forward) or as dwords of
+//     consecutive weight rows (weight stored [K][N]: input gradient, 128-byte row segments per half wave) - no LDS
+//     staging, no barrier in the main loop;
+//   * the 16 partial tiles meet in LDS and are summed in wave order (deterministic; no atomics, no workspace), then the
+//     same alpha / bias / addend epilogue as above, 128-byte rows per store.
+// v_mfma_f32_32x32x2_f32 operands: lane (i = lane & 31, h = lane >> 5) supplies A[i][k = h] and B[k = h][j = i].  The
+// pairing of contraction indices into k = 0 / 1 is free as long as A and B agree: lane half h takes c0 + 4 h + t.
+template <int MB, bool TB>
+__global__ __launch_bounds__(1024) void gemm_f32_skinny_kernel(const GP p) {
+  extern __shared__ float red[];                             // [16 waves][MB][32 x 32]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int j0 = blockIdx.x * 32, gj = j0 + li;
+  const bool jok = gj < p.N;
+  // the contraction in UNITS of 4 U indices = what one lane reads contiguously per trip (U float4: a whole 128-byte line
+  // of its row at U = 8); each wave owns a contiguous run of units, a trip feeds two of them (one per lane half)
+  constexpr int U = MB == 1 ? 8 : 4;
+  constexpr int UNIT = 4 * U;
+  const int nunit = (p.K + UNIT - 1) / UNIT;
+  const int S = p.S, sid = blockIdx.y;
+  const int per_wg = (nunit + S - 1) / S;                      // this workgroup's run of units ...
+  const int g0 = sid * per_wg, g1 = (g0 + per_wg < nunit) ? g0 + per_wg : nunit;
+  const int per = (g1 - g0 + 15) >> 4;                         // ... split over its 16 waves
+  const int u0 = g0 + wid * per, u1 = (u0 + per < g1) ? u0 + per : g1;
+  f32x16 acc[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+  const float* arow[MB];
+  bool mok[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = mb * 32 + li;
+    mok[mb] = m < p.M;
+    arow[mb] = p.A + (long)(mok[mb] ? m : 0) * p.lda;
+  }
+  const float* bcol = TB ? p.B + (jok ? gj : 0) : p.B + (long)(jok ? gj : 0) * p.ldb;
+  // Every load of a trip is issued (unconditionally, from clamped addresses) before the first MFMA consumes one; what lies
+  // outside the matrix is zeroed by a bit mask (a select would come back as a branch around the load, and the loop as one
+  // load pair per wait).  A lane's U float4 are CONSECUTIVE: with one float4 per row and trip (first version) every
+  // 128-byte line of the weight crossed L2 -> L1 four times (16 waves x 8 trips in flight do not fit the 32 KiB L1).
+  const unsigned jmask = jok ? 0xffffffffu : 0u;
+  for (int ub = u0; ub < u1; ub += 2) {
+    const int unit = ub + h;
+    const bool uok = unit < u1;
+    const int cb = UNIT * unit;
+    f32x4 a[U][MB], b[U];
+    unsigned cm[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = cb + 4 * u;                              // this lane's contraction indices c .. c + 3
+      const bool cok = uok && c < p.K;                       // (K % 4 == 0: checked by the host)
+      const int cc = cok ? c : 0;
+      cm[u] = cok ? 0xffffffffu : 0u;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) a[u][mb] = *reinterpret_cast<const f32x4*>(arow[mb] + cc);
+      if constexpr (TB) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[u][t] = bcol[(long)(cc + t) * p.ldb];
+      } else {
+        b[u] = *reinterpret_cast<const f32x4*>(bcol + cc);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float bv = __uint_as_float(__float_as_uint(b[u][t]) & (cm[u] & jmask));
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const float av = __uint_as_float(__float_as_uint(a[u][mb][t]) & (mok[mb] ? cm[u] : 0u));
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mb], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // C / D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      red[((wid * MB + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + li] = acc[mb][r];
+  __syncthreads();
+  const float asc = (p.addend && p.addend_scale) ? p.addend_scale[0] : 1.0f;
+  const float alpha = p.alpha ? p.alpha[0] : 1.0f;
+  float vsum[MB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i) {
+    const int e = tid + i * 1024;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) v += red[w * MB * 1024 + e];
+    vsum[i] = v;
+  }
+  if (S > 1) {
+    // cross-workgroup split: park this workgroup's partial tile; gemm_f32_skinny_reduce_kernel adds the S of them in split
+    // order and runs the epilogue.  (One kernel with a "last workgroup to arrive reduces" counter was built first: its
+    // agent-scope release fence is an L2 write-back on this multi-XCD part - 320 workgroups x one write-back each took
+    // a 22 us launch to 142 us.  The kernel boundary is the cheap fence.)
+    const long tile = (long)MB * 1024;
+    float* mine = p.parts + ((long)sid * gridDim.x + blockIdx.x) * tile;
+#pragma unroll
+    for (int i = 0; i < MB; ++i) mine[tid + i * 1024] = vsum[i];
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < MB; ++i) {
+    const int e = tid + i * 1024;
+    const int m = e >> 5, j = j0 + (e & 31);
+    if (m < p.M && j < p.N) {
+      float v = alpha * vsum[i] + (p.bias ? p.bias[j] : 0.f);
+      if (p.addend) v += asc * p.addend[(long)m * p.ldadd + j];
+      p.out[(long)m * p.ldo + j] = v;
+    }
+  }
+}
+
+// second pass of a split launch: out = epilogue(sum over the S partial tiles, in split order)
+template <int MB>
+__global__ __launch_bounds__(1024) void gemm_f32_skinny_reduce_kernel(const GP p, int njb) {
+  const int tid = threadIdx.x, j0 = blockIdx.x * 32;
+  const long tile = (long)MB * 1024;
+  const float asc = (p.addend && p.addend_scale) ? p.addend_scale[0] : 1.0f;
+  const float alpha = p.alpha ? p.alpha[0] : 1.0f;
+#pragma unroll
+  for (int i = 0; i < MB; ++i) {
+    const int e = tid + i * 1024;
+    float v = 0.f;
+    for (int s2 = 0; s2 < p.S; ++s2) v += p.parts[((long)s2 * njb + blockIdx.x) * tile + e];
+    const int m = e >> 5, j = j0 + (e & 31);
+    if (m < p.M && j < p.N) {
+      v = alpha * v + (p.bias ? p.bias[j] : 0.f);
+      if (p.addend) v += asc * p.addend[(long)m * p.ldadd + j];
+      p.out[(long)m * p.ldo + j] = v;
+    }
+  }
+}
+
+// split of the contraction across workgroups: enough workgroups to put every CU to work (an f32-MFMA-fed CU takes in
+// 16 B / clk of weight at M = 32: the chip's 8 TB/s need ~all 256 of them), never less than one 32-index unit per wave
+static int skinny_splits(int N, int K, int MB) {
+  // one 1024-thread workgroup fits a CU (101 VGPRs x 16 waves), so S * njb workgroups run in ceil(S njb / 256) rounds
+  // of 1 / S of the contraction each: take the S <= 8 with the least rounds / S (ties: the smaller S - fewer partial
+  // tiles), never less than one 32-index unit per wave
+  const int njb = (N + 31) / 32, nunit = (K + (MB == 1 ? 32 : 16) - 1) / (MB == 1 ? 32 : 16);
+  int best = 1;
+  double cost = (double)((njb + 255) / 256);
+  for (int S = 2; S <= 8; ++S) {
+    if (nunit / S < 16) break;
+    const double c = (double)((S * njb + 255) / 256) / S;
+    if (c < cost - 1e-9) { cost = c; best = S; }
+  }
+  return best;
+}
+static size_t skinny_ws_bytes(int M, int N, int K) {
+  const int MB = M <= 32 ? 1 : 2, njb = (N + 31) / 32, S = skinny_splits(N, K, MB);
+  if (S <= 1) return 0;
+  return (size_t)S * njb * MB * 1024 * sizeof(float);
+}
+static bool skinny_applies(int transA, int transB, int M, int K, int64_t ldb) {
+  return !transA && M <= 64 && K >= 256 && (K & 3) == 0 && (transB || (ldb & 3) == 0);
+}
+
+template <int MB, bool TB>
+int launch_skinny(const GP& p, hipStream_t st) {
+  static std::atomic<uint64_t> once{0};
+  const size_t lds = (size_t)16 * MB * 1024 * sizeof(float);
+  clipk_once_per_device(once, [&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_skinny_kernel<MB, TB>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  });
+  const int njb = (p.N + 31) / 32;
+  hipLaunchKernelGGL((gemm_f32_skinny_kernel<MB, TB>), dim3((unsigned)njb, (unsigned)p.S), dim3(1024), lds, st, p);
+  if (p.S > 1) hipLaunchKernelGGL((gemm_f32_skinny_reduce_kernel<MB>), dim3((unsigned)njb), dim3(1024), 0, st, p, njb);
+  return clipk_check_launch();
+}
+
 }  // namespace
+
+extern "C" size_t clipk_gemm_f32_workspace(int M, int N, int K, int transA, int transB) {
+  if (M <= 0 || N <= 0 || K <= 0 || !skinny_applies(transA, transB, M, K, 4)) return 0;
+  return skinny_ws_bytes(M, N, K);
+}
 
 extern "C" int clipk_gemm_f32(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB,
                               int M, int N, int K, const float* alpha, const float* bias, const float* addend,
-                              int64_t ldadd, const float* addend_scale, float* out, int64_t ldo, void* stream) {
+                              int64_t ldadd, const float* addend_scale, float* out, int64_t ldo,
+                              void* workspace, size_t workspace_bytes, void* stream) {
   if (!A || !B || !out || M <= 0 || N <= 0 || K <= 0) return CLIPK_ERR_BAD_ARG;
   if ((lda & 3) || (ldb & 3) || !aligned16(A) || !aligned16(B)) return CLIPK_ERR_UNSUPPORTED;   // float4 staging
   GP p;
   p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.out = out; p.ldo = ldo;
   p.bias = bias; p.addend = addend; p.ldadd = ldadd; p.addend_scale = addend_scale; p.alpha = alpha;
   p.M = M; p.N = N; p.K = K; p.transA = transA; p.transB = transB;
+  p.S = 1; p.parts = nullptr;
+  // a few rows against a large weight: one bandwidth-bound pass over B (see gemm_f32_skinny_kernel)
+  if (skinny_applies(transA, transB, M, K, ldb)) {
+    hipStream_t st = (hipStream_t)stream;
+    const size_t need = skinny_ws_bytes(M, N, K);
+    if (need && workspace && workspace_bytes >= need && aligned16(workspace)) {   // else: one workgroup per column block
+      p.S = skinny_splits(N, K, M <= 32 ? 1 : 2);
+      p.parts = reinterpret_cast<float*>(workspace);
+    }
+    if (M <= 32) return transB ? launch_skinny<1, true>(p, st) : launch_skinny<1, false>(p, st);
+    return transB ? launch_skinny<2, true>(p, st) : launch_skinny<2, false>(p, st);
+  }
   const long ntn = (N + BN - 1) / BN;
   const long t128 = (long)((M + 127) / 128) * ntn, t64 = (long)((M + 63) / 64) * ntn;
   if (t64 > 0x7fffffffL) return CLIPK_ERR_UNSUPPORTED;

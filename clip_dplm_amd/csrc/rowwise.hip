@@ -629,6 +629,14 @@ extern "C" int clipk_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, c
   return rc;
 }
 
+// out[c] (+)= sum over rows of x[r][c]: the bias gradient of an exact-f32 Linear (db = dY.sum(0)), fixed summation order
+extern "C" int clipk_colsum_f32(const float* x, int rows, int cols, float* out, int accumulate, void* stream) {
+  if (!x || !out || rows <= 0 || cols <= 0) return CLIPK_ERR_BAD_ARG;
+  hipLaunchKernelGGL(colreduce_kernel, dim3((cols + 15) / 16), dim3(256), 0, (hipStream_t)stream, x, rows, cols, out,
+                     (float*)nullptr, cols, accumulate);
+  return clipk_check_launch();
+}
+
 // Second-order LayerNorm(+activation) backward (see ln_bwd2_kernel): f32 only, [rows, cols] row-major with one leading
 // dimension.  workspace: clipk_layernorm_bwd_workspace(rows, cols) bytes.  d_gamma / d_beta are overwritten
 // (accumulate = 0) or added to (accumulate = 1); either both or neither.

@@ -22,6 +22,21 @@ def mark_weights_dirty() -> None:
     _WEIGHT_EPOCH += 1
 
 
+# hipGraph capture of a training step (training.GraphedTrainStep): whether a bf16 copy is stale is a HOST decision, which a
+# replay never repeats - so while a step is being captured every copy is rebuilt at its point of use (into the same
+# buffers: the launches become part of the graph and every replay refreshes every copy from the current master weights).
+_CAPTURE_FORCE = False
+
+
+def set_capture_force(on: bool) -> None:
+    global _CAPTURE_FORCE
+    _CAPTURE_FORCE = bool(on)
+
+
+def capture_force() -> bool:
+    return _CAPTURE_FORCE
+
+
 def weight_epoch() -> int:
     """Counter of out-of-band parameter updates (mark_weights_dirty): part of every derived-operand cache key."""
     return _WEIGHT_EPOCH
@@ -59,7 +74,7 @@ class WeightCache:
         self.derived = ver is not None and w.data_ptr() not in {v[0] for v in ver if isinstance(v, tuple)}
         key = _cache_key(w, ver)
         self.src = w                         # always the operand of THIS call, hit or miss
-        if key != self.key:
+        if key != self.key or _CAPTURE_FORCE:
             src = w.detach()
             if not src.is_contiguous():
                 src = src.contiguous()
@@ -95,6 +110,8 @@ def refresh_weight_caches() -> int:
     """Rebuild every stale bf16 copy in ONE kernel launch on the current stream.  Called by FusedAdamW.step() right
     after the update: the lazy path costs one launch per weight (76 in the config-2 model) at the next forward.
     Covers caches that already have their buffers and a contiguous leaf master weight; the rest stay lazy."""
+    if _CAPTURE_FORCE:                       # every copy is rebuilt where it is used (see set_capture_force)
+        return 0
     todo = _stale_caches()
     if not todo:
         return 0
@@ -165,19 +182,34 @@ class LinearF32Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, addend=None):
         ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
+        ctx.bias = bias
         return ops.gemm_f32(x, weight, bias=bias, addend=None if addend is None else addend.contiguous())
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
+        bias = ctx.bias
         dy = dy.contiguous()
         dx = ops.gemm_f32(dy, weight, trans_b=True) if ctx.needs_input_grad[0] else None
-        dw = ops.gemm_f32(dy, x, trans_a=True, trans_b=True) if ctx.needs_input_grad[1] else None
-        db = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = ops.pool_fwd(dy, 1, dy.shape[0], None, 1).reshape(-1) * float(dy.shape[0])   # column sum
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            if _grad_in_place(weight):       # dW added straight into the parameter's .grad (a view of FusedAdamW's flat
+                ops.gemm_f32(dy, x, trans_a=True, trans_b=True, addend=weight.grad, out=weight.grad)     # buffer): no
+            else:                            # temporary, no AccumulateGrad add launch per parameter
+                dw = ops.gemm_f32(dy, x, trans_a=True, trans_b=True)
+        if bias is not None and ctx.needs_input_grad[2]:
+            if _grad_in_place(bias):
+                ops.colsum_f32(dy, out=bias.grad, accumulate=True)
+            else:
+                db = ops.colsum_f32(dy)
         return dx, dw, db, (dy if len(ctx.needs_input_grad) > 3 and ctx.needs_input_grad[3] else None)
+
+
+def _grad_in_place(p) -> bool:
+    """A leaf parameter whose .grad buffer already exists (FusedAdamW.zero_grad keeps them as views of its flat buffer):
+    kernels accumulate into it and autograd gets None - same semantics as AccumulateGrad (grad += dW)."""
+    g = p.grad if (p is not None and p.is_leaf) else None
+    return g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.device == p.device and g.shape == p.shape
 
 
 def linear_f32(x, weight, bias=None, addend=None):

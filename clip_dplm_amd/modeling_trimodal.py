@@ -47,7 +47,7 @@ class _CatPadColsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, holder, pad_to, *ws):
         key = KF.params_version(*ws)() + (KF.weight_epoch(),)
-        if holder.get("key") != key:
+        if holder.get("key") != key or KF.capture_force():
             w = torch.cat([t.detach() for t in ws], 1)
             pad = (-w.shape[1]) % pad_to
             holder["w"] = F.pad(w, (0, pad)) if pad else w

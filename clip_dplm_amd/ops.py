@@ -352,10 +352,23 @@ def transpose_scale_f32(x, scale=None):
     return out
 
 
-def gemm_f32(a, b, trans_a=False, trans_b=False, bias=None, addend=None, addend_scale=None, alpha=None):
+def colsum_f32(x, out=None, accumulate=False):
+    """out[c] (+)= sum_r x[r, c] (f32): bias gradients, written straight into `out` (e.g. a parameter's .grad)."""
+    _need_cuda(x, out)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
+    if out is None:
+        out, accumulate = torch.empty(x.shape[1], dtype=torch.float32, device=x.device), False
+    check(_lib().clipk_colsum_f32(x.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), int(accumulate), _stream()),
+          "clipk_colsum_f32")
+    return out
+
+
+def gemm_f32(a, b, trans_a=False, trans_b=False, bias=None, addend=None, addend_scale=None, alpha=None, out=None):
     """Exact-f32 out[M, N] = alpha * opA(a) @ opB(b) (+ bias) (+ addend_scale * addend) on the tiled f32-MFMA kernel
     (alpha / addend_scale: 1-element device tensors).
-    trans_a: a is stored [K, M];  trans_b: b is stored [K, N] (else [N, K], the nn.Linear layout)."""
+    trans_a: a is stored [K, M];  trans_b: b is stored [K, N] (else [N, K], the nn.Linear layout).
+    out: write into this [M, N] f32 tensor (row stride = its stride(0)); out may BE the addend (in-place accumulation:
+    every element is read and written by the same thread)."""
     _need_cuda(a, b, bias, addend, addend_scale, alpha)
     assert a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 2 and b.dim() == 2
     if a.stride(1) != 1 or a.stride(0) % 4:
@@ -371,15 +384,22 @@ def gemm_f32(a, b, trans_a=False, trans_b=False, bias=None, addend=None, addend_
         a = torch.nn.functional.pad(a, (0, (-a.shape[1]) % 4))
     if b.stride(0) % 4:
         b = torch.nn.functional.pad(b, (0, (-b.shape[1]) % 4))
-    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    else:
+        assert out.shape == (M, N) and out.dtype == torch.float32 and out.stride(1) == 1 and out.device == a.device
     if addend is not None:
         assert addend.shape == (M, N) and addend.stride(1) == 1
     nb = 4.0 * (M * K + N * K + M * N * (2 if addend is not None else 1))     # operands once, output (+ addend) once
+    lib = _lib()
+    wsb = lib.clipk_gemm_f32_workspace(M, N, K, int(trans_a), int(trans_b))
+    ws = workspace(wsb, a.device, "gemm_f32") if wsb else None
     check(_timed("gemm_f32", 2.0 * M * N * K,
-                 lambda: _lib().clipk_gemm_f32(a.data_ptr(), a.stride(0), int(trans_a), b.data_ptr(), b.stride(0),
-                                               int(trans_b), M, N, K, ptr(alpha), ptr(bias), ptr(addend),
-                                               addend.stride(0) if addend is not None else 0, ptr(addend_scale),
-                                               out.data_ptr(), out.stride(0), _stream()), nb), "clipk_gemm_f32")
+                 lambda: lib.clipk_gemm_f32(a.data_ptr(), a.stride(0), int(trans_a), b.data_ptr(), b.stride(0),
+                                            int(trans_b), M, N, K, ptr(alpha), ptr(bias), ptr(addend),
+                                            addend.stride(0) if addend is not None else 0, ptr(addend_scale),
+                                            out.data_ptr(), out.stride(0), ptr(ws), ws.numel() if ws is not None else 0,
+                                            _stream()), nb), "clipk_gemm_f32")
     return out
 
 
@@ -803,8 +823,10 @@ def sumsq(g: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
 
 
 def adamw_step(w, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq=None, max_norm=0.0,
-               grad_scale=1.0, w_bf16=None):
-    _need_cuda(w, g, m, v)
+               grad_scale=1.0, w_bf16=None, hyper=None):
+    """hyper: device f32 [3] = {lr, 1 - beta1^t, sqrt(1 - beta2^t)} read by the kernel instead of lr / step (graph replay)."""
+    _need_cuda(w, g, m, v, hyper)
     check(_lib().clipk_adamw_step(w.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), ptr(w_bf16), w.numel(),
                                   float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
-                                  ptr(grad_norm_sq), float(max_norm), float(grad_scale), _stream()), "clipk_adamw_step")
+                                  ptr(grad_norm_sq), float(max_norm), float(grad_scale), ptr(hyper), _stream()),
+          "clipk_adamw_step")

@@ -18,6 +18,7 @@ import math
 from typing import Iterable, List, Optional
 
 import os
+import struct
 
 import torch
 import torch.distributed as dist
@@ -148,6 +149,11 @@ class FusedAdamW:
         self.overlap = (self._nccl if overlap is None else bool(overlap)) and group is not None
         self._comm = torch.cuda.Stream(device=dev) if (self._nccl and dev.type == "cuda") else None
         self._reduced = [False] * len(self.flat.buckets)
+        # hipGraph replay (training.GraphedTrainStep): what changes from step to step - lr and the two bias corrections -
+        # is read by the kernel from this device array instead of from launch arguments
+        self.hyper = None
+        self._hyper_host = None
+        self._graph_body = False
         if self.overlap:
             for b, (_, _, root) in enumerate(self.flat.buckets):
                 if root is not None:
@@ -198,10 +204,32 @@ class FusedAdamW:
                     dst.copy_(out)
         self._reduced[b] = True
 
+    def enable_device_hyper(self) -> None:
+        """Keep {lr, 1 - beta1^t, sqrt(1 - beta2^t)} in device memory (see prepare_step)."""
+        if self.hyper is None:
+            self.hyper = torch.zeros(3, dtype=torch.float32, device=self.flat.data.device)
+            self._hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory() if self.flat.data.is_cuda else torch.zeros(3)
+
+    def prepare_step(self, lr: Optional[float] = None) -> None:
+        """Host side of one optimiser step when the step itself is a hipGraph replay: count the step and upload its
+        hyper-parameters (bias corrections in double, as torch.optim.AdamW computes them)."""
+        self.enable_device_hyper()
+        self.step_count += 1
+        lr = self.lr if lr is None else lr
+        t = self.step_count
+        # exactly what clipk_adamw_step computes from its (float) arguments: betas rounded to f32 first, pow / sqrt in double
+        b1 = struct.unpack("f", struct.pack("f", self.betas[0]))[0]
+        b2 = struct.unpack("f", struct.pack("f", self.betas[1]))[0]
+        self._hyper_host[0] = lr
+        self._hyper_host[1] = 1.0 - math.pow(b1, float(t))
+        self._hyper_host[2] = math.sqrt(1.0 - math.pow(b2, float(t)))
+        self.hyper.copy_(self._hyper_host, non_blocking=True)
+
     @torch.no_grad()
     def step(self, lr: Optional[float] = None) -> torch.Tensor:
         """Returns the (device) squared global gradient norm before clipping."""
-        self.step_count += 1
+        if not self._graph_body:                 # (inside a captured step the host bookkeeping is prepare_step()'s)
+            self.step_count += 1
         lr = self.lr if lr is None else lr
         if self.group is not None:
             for b in range(len(self.flat.buckets)):
@@ -218,9 +246,10 @@ class FusedAdamW:
         for (lo, hi, off) in self.pieces:
             n = hi - lo
             _kernels.adamw_step(self.flat.data[lo:hi], g[off:off + n], self.m[off:off + n], self.v[off:off + n], lr,
-                                self.betas[0], self.betas[1], self.eps, self.wd, self.step_count,
+                                self.betas[0], self.betas[1], self.eps, self.wd, max(self.step_count, 1),
                                 grad_norm_sq=self.norm_sq if clip else None,
-                                max_norm=self.max_grad_norm if clip else 0.0)
+                                max_norm=self.max_grad_norm if clip else 0.0,
+                                **({"hyper": self.hyper} if self._graph_body else {}))
         if self.group is not None:
             for (s0, s1, _), (lo, hi, _off) in zip(self.flat.buckets, self.pieces):
                 w = self.flat.data[lo:hi]

@@ -19,6 +19,8 @@ from typing import Any, Callable, Dict, Iterable, Optional
 
 import torch
 
+from . import functional as KF
+
 
 class CosineAnnealingLR:
     """eta_t = eta_min + (base_lr - eta_min) (1 + cos(pi t / T_max)) / 2 (the closed form torch documents; equal to its
@@ -145,3 +147,78 @@ def load_checkpoint(path, model, optimizer=None, scheduler=None, map_location="c
     if scheduler is not None and ckpt.get("scheduler_state") is not None:
         scheduler.load_state_dict(ckpt["scheduler_state"])
     return ckpt
+
+
+class GraphedTrainStep:
+    """One whole training step - zero_grad -> loss_fn(*inputs) -> backward -> clip + AdamW (the loop body of
+    rna_clip_codes.ipynb:2061-2089) - captured ONCE in a hipGraph and replayed.
+
+    For the models that pool one position (RNARBPCLIPModel, ContrastiveModel) the sliced step is ~350 launches of
+    microsecond kernels over 32 rows: eager, the host cannot issue them as fast as the GPU retires them (7 ms per step
+    on MI355X of which ~3 ms are kernel time).  Replayed from a graph the step costs its kernels.  What changes between
+    steps lives in device memory: the inputs (static buffers, copied in before the replay) and AdamW's learning rate and
+    bias corrections (`FusedAdamW.prepare_step`).
+
+        step = GraphedTrainStep(model, opt, lambda rna, rbp: model(rna, rbp)[2], (rna, rbp))
+        for rna, rbp in loader: loss = step(rna, rbp)           # same shapes as the example inputs
+
+    Restrictions: fixed input shapes; no active dropout (the masks' seeds are drawn on the host per forward: they would
+    repeat with every replay) - use dropout = 0 or hand-written eager steps for that; single process (no collectives).
+    The returned loss is a static device tensor overwritten by the next call (`.item()` / `.clone()` it to keep it)."""
+
+    def __init__(self, model, optimizer, loss_fn, example_inputs, warmup: int = 3):
+        for m in model.modules():
+            p = getattr(m, "dropout", None) if not isinstance(m, torch.nn.Dropout) else m.p
+            if model.training and isinstance(p, float) and p > 0.0:
+                raise ValueError("GraphedTrainStep: dropout is active (its seeds are host-side): build the model with "
+                                 "dropout = 0.0 or call .eval()-style p = 0 before capturing")
+        if getattr(optimizer, "group", None) is not None:
+            raise ValueError("GraphedTrainStep captures single-process steps only")
+        self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
+        self.static_in = [t.detach().clone().contiguous() for t in example_inputs]
+        optimizer.enable_device_hyper()
+        # the warm-up steps are real optimiser steps on the example inputs: put weights and optimiser state back afterwards
+        saved = (optimizer.flat.data.clone(), optimizer.m.clone(), optimizer.v.clone(), optimizer.step_count)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # eager warm-up steps: workspaces, kernel attributes, .grad views
+            for _ in range(warmup):
+                self._eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        optimizer._graph_body = True
+        KF.set_capture_force(True)                         # bf16 weight copies: rebuilt at their point of use, in the graph
+        try:
+            optimizer.prepare_step()                       # the captured step is a real one, too
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.static_loss = self._body()
+        finally:
+            optimizer._graph_body = False
+            KF.set_capture_force(False)
+        optimizer.flat.data.copy_(saved[0])
+        optimizer.m.copy_(saved[1])
+        optimizer.v.copy_(saved[2])
+        optimizer.step_count = saved[3]
+        KF.mark_weights_dirty()                            # bf16 copies of the restored weights are rebuilt on demand
+
+    def _body(self):
+        self.opt.zero_grad()
+        loss = self.loss_fn(*self.static_in)
+        loss.backward()
+        self.opt.step()
+        return loss.detach()
+
+    def _eager(self):
+        self.opt.zero_grad()
+        loss = self.loss_fn(*self.static_in)
+        loss.backward()
+        self.opt.step()
+        return loss.detach()
+
+    def __call__(self, *inputs, lr=None):
+        for dst, src in zip(self.static_in, inputs):
+            dst.copy_(src, non_blocking=True)
+        self.opt.prepare_step(lr)
+        self.graph.replay()
+        return self.static_loss

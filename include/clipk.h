@@ -201,11 +201,21 @@ int clipk_gemm_f32_nt(const float* X, int M, const float* W, int N, int K, const
  *   transB == 0: B is [N,K] (nn.Linear weight, out = A·B^T);  transB == 1: B is stored [K,N] (dA = dZ · W)
  * Every product of the ICNN potential, of its input gradient T(x) = dPsi/dx and of the training path's double backward
  * (triple_flow/2_icnn_core.py:102-119,181-211 under autocast(enabled=False)), and the gradients of the materialised
- * logits (old/clip.py:67): no transposed copies, any K.  lda / ldb % 4 == 0, A / B 16-byte aligned. */
+ * logits (old/clip.py:67): no transposed copies, any K.  lda / ldb % 4 == 0, A / B 16-byte aligned.
+ * M <= 64 rows against a large weight (K >= 256, A not transposed: forward and input gradient of every Linear of the
+ * position-0-sliced notebook models, M = batch) take the skinny form: one bandwidth-bound pass over B, the contraction
+ * split 16 ways inside a workgroup and - given a workspace - across workgroups so that every CU streams its share.
+ * workspace: clipk_gemm_f32_workspace(...) bytes (0 = none needed; scratch for the partial tiles of a split launch, summed
+ * in split order by a second kernel); NULL or too small: no cross-workgroup split. */
+size_t clipk_gemm_f32_workspace(int M, int N, int K, int transA, int transB);
 int clipk_gemm_f32(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB,
                    int M, int N, int K, const float* alpha /* device scalar or NULL */, const float* bias,
                    const float* addend, int64_t ldadd, const float* addend_scale /* device scalar or NULL (=1) */,
-                   float* out, int64_t ldo, void* stream);
+                   float* out, int64_t ldo, void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[c] (+)= sum_r x[r][c] (x f32 [rows, cols] contiguous): the bias gradient dY.sum(0) of the exact-f32 Linear layers
+ * (old/clip.py:11,27,31 under autograd), accumulated straight into the parameter's .grad; fixed summation order. */
+int clipk_colsum_f32(const float* x, int rows, int cols, float* out, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Row-wise normalisation kernels (one wave per row, f32 statistics).
@@ -389,10 +399,13 @@ int clipk_attn_varlen_bwd(const void* qkv, const int* cu_seqlens, const float* r
 size_t clipk_sumsq_workspace(int64_t n);
 int clipk_sumsq(const float* g, int64_t n, float* out /* device scalar, overwritten */,
                 void* workspace, size_t workspace_bytes, void* stream);
+/* hyper_dev (optional): DEVICE array {lr, 1 - beta1^t, sqrt(1 - beta2^t)} read by the kernel instead of `lr` / `step` -
+ * what changes from step to step lives in memory, so that a whole training step (rna_clip_codes.ipynb:2061-2089) can be
+ * captured once in a hipGraph and replayed (clip_dplm_amd.training.GraphedTrainStep); NULL: the scalars. */
 int clipk_adamw_step(float* w, const float* g, float* m, float* v, void* w_bf16 /* or NULL */,
                      int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                      int step, const float* grad_norm_sq /* device scalar or NULL */, float max_norm,
-                     float grad_scale, void* stream);
+                     float grad_scale, const float* hyper_dev /* or NULL */, void* stream);
 
 #ifdef __cplusplus
 }

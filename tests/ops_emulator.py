@@ -177,15 +177,26 @@ def matmul_f32_nt(a, b):
     return a @ b.t()
 
 
-def gemm_f32(a, b, trans_a=False, trans_b=False, bias=None, addend=None, addend_scale=None, alpha=None):
-    out = (a.t() if trans_a else a) @ (b if trans_b else b.t())
-    if alpha is not None:
-        out = out * alpha
-    if bias is not None:
-        out = out + bias
-    if addend is not None:
-        out = out + (addend_scale if addend_scale is not None else 1.0) * addend
+def colsum_f32(x, out=None, accumulate=False):
+    s_ = x.sum(0)
+    if out is None:
+        return s_
+    out.copy_(out + s_ if accumulate else s_)
     return out
+
+
+def gemm_f32(a, b, trans_a=False, trans_b=False, bias=None, addend=None, addend_scale=None, alpha=None, out=None):
+    r = (a.t() if trans_a else a) @ (b if trans_b else b.t())
+    if alpha is not None:
+        r = r * alpha
+    if bias is not None:
+        r = r + bias
+    if addend is not None:
+        r = r + (addend_scale if addend_scale is not None else 1.0) * addend
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
 
 
 def transpose_scale_f32(x, scale=None):
@@ -528,7 +539,7 @@ def sumsq(g, out=None):
 
 
 def adamw_step(w, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_norm_sq=None, max_norm=0.0, grad_scale=1.0,
-               w_bf16=None):
+               w_bf16=None, hyper=None):
     clip = grad_scale
     if grad_norm_sq is not None:
         norm = grad_norm_sq.sqrt().item() * grad_scale
@@ -538,6 +549,8 @@ def adamw_step(w, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_norm_
     m.mul_(beta1).add_(gi, alpha=1 - beta1)
     v.mul_(beta2).addcmul_(gi, gi, value=1 - beta2)
     bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+    if hyper is not None:
+        lr, bc1, bc2 = float(hyper[0]), float(hyper[1]), float(hyper[2]) ** 2
     w.addcdiv_(m, v.sqrt() / math.sqrt(bc2) + eps, value=-lr / bc1)
 
 

@@ -819,11 +819,16 @@ def test_pool_varlen(dev):
 
 # ------------------------------------------------------------------------------------------------ tiled f32 GEMM
 @pytest.mark.parametrize("M,N,K", [(4096, 512, 512), (64, 256, 512), (1030, 130, 66), (300, 64, 1030), (17, 8, 4),
-                                   (2048, 768, 2050)])
+                                   (2048, 768, 2050),
+                                   # M <= 64 rows against a large weight: the skinny kernel (16-way split of the contraction
+                                   # inside the workgroup) for the untransposed-A layouts - the sliced notebook model's shapes
+                                   (32, 3840, 1280), (32, 1280, 5120), (1, 40, 256), (33, 1000, 1284), (64, 520, 2560),
+                                   (17, 31, 260), (32, 480, 120)])
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
 def test_gemm_f32_all_layouts(dev, M, N, K, ta, tb):
-    """clipk_gemm_f32 (tiled v_mfma_f32_32x32x2_f32): all four operand layouts, ragged M / N / K (K % 16, % 4 != 0,
-    odd leading dimensions), bias and scaled addend, against f64; exact-f32 products: error ~1e-7 * sum |a b|."""
+    """clipk_gemm_f32 (tiled v_mfma_f32_32x32x2_f32; skinny form for M <= 64, K >= 256): all four operand layouts, ragged
+    M / N / K (K % 16, % 4 != 0, odd leading dimensions), bias and scaled addend, against f64; exact-f32 products: error
+    ~1e-7 * sum |a b|."""
     ops = _ops()
     a = _rand((K, M) if ta else (M, K), dev, 51)
     b = _rand((K, N) if tb else (N, K), dev, 52, 0.1)

@@ -479,6 +479,51 @@ def test_training_trajectory_matches_the_oracle(dev):
         assert d.max().item() <= 6.5e-4 and d.mean().item() <= 1e-5, (n, d.max().item(), d.mean().item())
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_graphed_train_step_equals_eager_steps(dev, precision):
+    """training.GraphedTrainStep: the whole training step (zero_grad -> forward -> symmetric InfoNCE -> backward -> clip ->
+    AdamW, rna_clip_codes.ipynb:2061-2089) replayed from ONE hipGraph, inputs and AdamW's per-step scalars in device memory.
+    Five steps on five different batches: losses and every weight bit-identical to the same steps issued eagerly, the
+    model untouched by the capture's warm-up, and the optimiser's step count advanced by the replays."""
+    import clip_dplm_amd as K
+    from clip_dplm_amd.training import GraphedTrainStep
+
+    def build():
+        torch.manual_seed(1)
+        m = K.RNARBPCLIPModel(rna_dim=40, rbp_dim=128, projection_dim=64, dropout=0.0, precision=precision)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        return m.to(dev).train()
+    g = torch.Generator().manual_seed(3)
+    batches = []
+    for _ in range(5):
+        rna, rbp = torch.randn(32, 6, 40, generator=g), torch.randn(32, 9, 128, generator=g)
+        rna[5, 4:] = float("nan")
+        rbp[7, 3:] = float("nan")
+        batches.append((rna.to(dev), rbp.to(dev)))
+    me = build()
+    oe = K.FusedAdamW(me, lr=1e-3, weight_decay=0.01, max_grad_norm=1.0)
+    eager = []
+    for i, (rna, rbp) in enumerate(batches):
+        oe.zero_grad()
+        loss = me(rna, rbp)[2]
+        loss.backward()
+        oe.step(lr=1e-3 * (1 + i))                          # a schedule: the learning rate changes every step
+        eager.append(loss.item())
+    mg = build()
+    og = K.FusedAdamW(mg, lr=1e-3, weight_decay=0.01, max_grad_norm=1.0)
+    w0 = og.flat.data.clone()
+    step = GraphedTrainStep(mg, og, lambda a, b: mg(a, b)[2], batches[0])
+    assert torch.equal(og.flat.data, w0) and og.step_count == 0 and float(og.m.abs().max()) == 0.0
+    graphed = [step(rna, rbp, lr=1e-3 * (1 + i)).item() for i, (rna, rbp) in enumerate(batches)]
+    assert og.step_count == 5
+    assert graphed == eager, (graphed, eager)
+    for (n, p), (_, q) in zip(me.named_parameters(), mg.named_parameters()):
+        assert torch.equal(p, q), n
+    assert eager[-1] < eager[0]
+
+
 def test_icnn_transport_golden(dev):
     """BASELINE config 5 (eval): T(x) = dPsi/dx from the hand-derived gradient on exact-f32 MFMA kernels vs the
     reference's autograd-of-autograd output (golden); f32 path, tolerance 2e-4."""
