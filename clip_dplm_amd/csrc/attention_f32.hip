@@ -37,8 +37,9 @@ struct AF {
 };
 
 constexpr int KB = 64;        // keys (dQ / forward) or queries (dK/dV) per LDS block = one per lane
-constexpr int RB = 16;        // rows owned by a workgroup: 4 waves x 4 rows
-constexpr int NW = 4, RW = 4;
+constexpr int NW = 4;         // waves per workgroup; each owns RW rows (template parameter: 4, or 1 for short sequences -
+                              // the sliced notebook models attend over L = batch = 32 samples: with 4 rows per wave that
+                              // is 2 workgroups per head, 16 on the whole chip, and the launch is pure latency)
 
 __host__ __device__ inline int row_stride(int D) { return 4 * ((((D + 3) >> 2)) | 1); }   // floats; S / 4 odd
 
@@ -61,6 +62,7 @@ __device__ __forceinline__ void stage_rows(float* dst, const float* src, long ld
 }
 
 // acc[r] += <rowsA[r] (wave-uniform rows, broadcast reads), rowB (this lane's row)> over the padded head dim, d ascending
+template <int RW>
 __device__ __forceinline__ void dot4(const float* rowsA, const float* rowB, int S, int D4, float (&acc)[RW]) {
   for (int d = 0; d < D4; d += 4) {
     const f32x4 b = *reinterpret_cast<const f32x4*>(rowB + d);
@@ -77,8 +79,9 @@ __device__ __forceinline__ void dot4(const float* rowsA, const float* rowB, int 
 
 // ---------------------------------------------------------------------------------------------------------------------
 // forward: workgroup = 16 queries of one (batch, head); wave w owns queries q0 + 4w .. + 3
-template <int DT>
+template <int DT, int RW>
 __global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const AF p) {
+  constexpr int RB = NW * RW;
   extern __shared__ float smem[];
   const int L = p.L, H = p.H, D = p.D, S = row_stride(D), D4 = (D + 3) & ~3;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * RB;
@@ -103,9 +106,11 @@ __global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const AF p) {
     __syncthreads();
     const int key = k0 + lane;
     const bool valid = key < L && (!p.key_mask || p.key_mask[row0 + key]);
-    float s[RW] = {0.f, 0.f, 0.f, 0.f};
-    dot4(Qs + w * RW * S, Ks + lane * S, S, D4, s);
-    f32x4 pt;
+    float s[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) s[r] = 0.f;
+    dot4<RW>(Qs + w * RW * S, Ks + lane * S, S, D4, s);
+    float pt[RW];
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
       const float sv = valid ? s[r] : -INFINITY;
@@ -122,11 +127,14 @@ __global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const AF p) {
       if (p.drop_thr) pv *= drop_at(p, row0 + q0 + w * RW + r, h, key);
       pt[r] = pv;
     }
-    *reinterpret_cast<f32x4*>(Ps + (w * KB + lane) * RW) = pt;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) Ps[(w * KB + lane) * RW + r] = pt[r];
     __syncthreads();
     const int nk = L - k0 < KB ? L - k0 : KB;
     for (int j = 0; j < nk; ++j) {
-      const f32x4 pj = *reinterpret_cast<const f32x4*>(Ps + (w * KB + j) * RW);
+      float pj[RW];
+#pragma unroll
+      for (int r = 0; r < RW; ++r) pj[r] = Ps[(w * KB + j) * RW + r];
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
         const int d = lane + 64 * t;
@@ -152,8 +160,9 @@ __global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const AF p) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // backward, dQ (+ delta): same ownership as the forward
-template <int DT>
+template <int DT, int RW>
 __global__ __launch_bounds__(256) void attn_f32_bwd_dq_kernel(const AF p) {
+  constexpr int RB = NW * RW;
   extern __shared__ float smem[];
   const int L = p.L, H = p.H, D = p.D, S = row_stride(D), D4 = (D + 3) & ~3;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * RB;
@@ -194,21 +203,26 @@ __global__ __launch_bounds__(256) void attn_f32_bwd_dq_kernel(const AF p) {
     __syncthreads();
     const int key = k0 + lane;
     const bool valid = key < L && (!p.key_mask || p.key_mask[row0 + key]);
-    float s[RW] = {0.f, 0.f, 0.f, 0.f}, dp[RW] = {0.f, 0.f, 0.f, 0.f};
-    dot4(Qs + w * RW * S, Ks + lane * S, S, D4, s);
-    dot4(Gs + w * RW * S, Vs + lane * S, S, D4, dp);
-    f32x4 dst;
+    float s[RW], dp[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    dot4<RW>(Qs + w * RW * S, Ks + lane * S, S, D4, s);
+    dot4<RW>(Gs + w * RW * S, Vs + lane * S, S, D4, dp);
+    float dst[RW];
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
       const float pv = (valid && lse[r] != -INFINITY) ? expf(s[r] - lse[r]) : 0.f;
       const float dm = p.drop_thr ? drop_at(p, row0 + q0 + w * RW + r, h, key) : 1.f;
       dst[r] = pv * fmaf(dp[r], dm, -delta[r]);              // dS = P o (dP~ - delta)
     }
-    *reinterpret_cast<f32x4*>(Ds + (w * KB + lane) * RW) = dst;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) Ds[(w * KB + lane) * RW + r] = dst[r];
     __syncthreads();
     const int nk = L - k0 < KB ? L - k0 : KB;
     for (int j = 0; j < nk; ++j) {
-      const f32x4 dj = *reinterpret_cast<const f32x4*>(Ds + (w * KB + j) * RW);
+      float dj[RW];
+#pragma unroll
+      for (int r = 0; r < RW; ++r) dj[r] = Ds[(w * KB + j) * RW + r];
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
         const int d = lane + 64 * t;
@@ -232,8 +246,9 @@ __global__ __launch_bounds__(256) void attn_f32_bwd_dq_kernel(const AF p) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // backward, dK / dV: workgroup = 16 keys of one (batch, head), sweeping 64-query blocks (lane = query); needs delta
-template <int DT>
+template <int DT, int RW>
 __global__ __launch_bounds__(256) void attn_f32_bwd_dkv_kernel(const AF p) {
+  constexpr int RB = NW * RW;
   extern __shared__ float smem[];
   const int L = p.L, H = p.H, D = p.D, S = row_stride(D), D4 = (D + 3) & ~3;
   const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * RB;
@@ -264,10 +279,12 @@ __global__ __launch_bounds__(256) void attn_f32_bwd_dkv_kernel(const AF p) {
     const int q = q0 + lane;
     const float lse = q < L ? p.lse[((long)b * H + h) * L + q] : -INFINITY;
     const float delta = q < L ? p.delta[((long)b * H + h) * L + q] : 0.f;
-    float s[RW] = {0.f, 0.f, 0.f, 0.f}, dp[RW] = {0.f, 0.f, 0.f, 0.f};
-    dot4(Kr + w * RW * S, Qs + lane * S, S, D4, s);
-    dot4(Vr + w * RW * S, Gs + lane * S, S, D4, dp);
-    f32x4 pt, dst;
+    float s[RW], dp[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    dot4<RW>(Kr + w * RW * S, Qs + lane * S, S, D4, s);
+    dot4<RW>(Vr + w * RW * S, Gs + lane * S, S, D4, dp);
+    float pt[RW], dst[RW];
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
       const float pv = (kvalid[r] && lse != -INFINITY) ? expf(s[r] - lse) : 0.f;
@@ -275,13 +292,17 @@ __global__ __launch_bounds__(256) void attn_f32_bwd_dkv_kernel(const AF p) {
       pt[r] = pv * dm;
       dst[r] = pv * fmaf(dp[r], dm, -delta);
     }
-    *reinterpret_cast<f32x4*>(Ps + (w * KB + lane) * RW) = pt;
-    *reinterpret_cast<f32x4*>(Ds + (w * KB + lane) * RW) = dst;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+      Ps[(w * KB + lane) * RW + r] = pt[r];
+      Ds[(w * KB + lane) * RW + r] = dst[r];
+    }
     __syncthreads();
     const int nq = L - q0 < KB ? L - q0 : KB;
     for (int i = 0; i < nq; ++i) {
-      const f32x4 pi = *reinterpret_cast<const f32x4*>(Ps + (w * KB + i) * RW);
-      const f32x4 di = *reinterpret_cast<const f32x4*>(Ds + (w * KB + i) * RW);
+      float pi[RW], di[RW];
+#pragma unroll
+      for (int r = 0; r < RW; ++r) { pi[r] = Ps[(w * KB + i) * RW + r]; di[r] = Ds[(w * KB + i) * RW + r]; }
 #pragma unroll
       for (int t = 0; t < DT; ++t) {
         const int d = lane + 64 * t;
@@ -310,18 +331,38 @@ __global__ __launch_bounds__(256) void attn_f32_bwd_dkv_kernel(const AF p) {
   }
 }
 
-size_t lds_fwd(int D) { return (size_t)(2 * KB * row_stride(D) + RB * row_stride(D) + NW * KB * RW) * 4; }
-size_t lds_dq(int D) { return (size_t)(2 * KB * row_stride(D) + 2 * RB * row_stride(D) + NW * KB * RW) * 4; }
-size_t lds_dkv(int D) { return (size_t)(2 * KB * row_stride(D) + 2 * RB * row_stride(D) + 2 * NW * KB * RW) * 4; }
+size_t lds_fwd(int D, int RW) { return (size_t)(2 * KB * row_stride(D) + NW * RW * row_stride(D) + NW * KB * RW) * 4; }
+size_t lds_dq(int D, int RW) { return (size_t)(2 * KB * row_stride(D) + 2 * NW * RW * row_stride(D) + NW * KB * RW) * 4; }
+size_t lds_dkv(int D, int RW) { return (size_t)(2 * KB * row_stride(D) + 2 * NW * RW * row_stride(D) + 2 * NW * KB * RW) * 4; }
 
 template <typename K>
-int launch(K kern, std::atomic<uint64_t>& once, const AF& p, size_t lds, hipStream_t st) {
+int launch(K kern, std::atomic<uint64_t>& once, const AF& p, int rb, size_t lds, hipStream_t st) {
   clipk_once_per_device(once, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
-  const dim3 grid((unsigned)((p.L + RB - 1) / RB), (unsigned)p.H, (unsigned)p.B);
+  const dim3 grid((unsigned)((p.L + rb - 1) / rb), (unsigned)p.H, (unsigned)p.B);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   return clipk_check_launch();
+}
+
+// rows per wave: 4 (each K / V read from LDS serves four query rows), or 1 when that would leave the chip empty
+int rows_per_wave(const AF& p) { return ((long)((p.L + 15) / 16) * p.H * p.B < 128) ? 1 : 4; }
+
+template <int DT>
+int launch_fwd(const AF& p, hipStream_t st) {
+  static std::atomic<uint64_t> o1{0}, o4{0};
+  if (rows_per_wave(p) == 1) return launch(attn_f32_fwd_kernel<DT, 1>, o1, p, NW, lds_fwd(p.D, 1), st);
+  return launch(attn_f32_fwd_kernel<DT, 4>, o4, p, NW * 4, lds_fwd(p.D, 4), st);
+}
+template <int DT>
+int launch_bwd(const AF& p, hipStream_t st) {
+  static std::atomic<uint64_t> a1{0}, a4{0}, b1{0}, b4{0};
+  if (rows_per_wave(p) == 1) {
+    const int rc = launch(attn_f32_bwd_dq_kernel<DT, 1>, a1, p, NW, lds_dq(p.D, 1), st);
+    return rc ? rc : launch(attn_f32_bwd_dkv_kernel<DT, 1>, b1, p, NW, lds_dkv(p.D, 1), st);
+  }
+  const int rc = launch(attn_f32_bwd_dq_kernel<DT, 4>, a4, p, NW * 4, lds_dq(p.D, 4), st);
+  return rc ? rc : launch(attn_f32_bwd_dkv_kernel<DT, 4>, b4, p, NW * 4, lds_dkv(p.D, 4), st);
 }
 
 int set_dropout(AF& p, float dropout_p, unsigned seed) {
@@ -353,11 +394,10 @@ extern "C" int clipk_attn_f32_fwd(const float* qkv, const uint8_t* key_mask, flo
   p.qkv = qkv; p.key_mask = key_mask; p.out = out; p.lse = lse; p.B = B; p.L = L; p.H = H; p.D = D; p.scale = q_scale;
   rc = set_dropout(p, dropout_p, dropout_seed);
   if (rc) return rc;
-  static std::atomic<uint64_t> o1{0}, o2{0}, o3{0};
   hipStream_t st = (hipStream_t)stream;
-  if (D <= 64) return launch(attn_f32_fwd_kernel<1>, o1, p, lds_fwd(D), st);
-  if (D <= 128) return launch(attn_f32_fwd_kernel<2>, o2, p, lds_fwd(D), st);
-  return launch(attn_f32_fwd_kernel<3>, o3, p, lds_fwd(D), st);
+  if (D <= 64) return launch_fwd<1>(p, st);
+  if (D <= 128) return launch_fwd<2>(p, st);
+  return launch_fwd<3>(p, st);
 }
 
 extern "C" int clipk_attn_f32_bwd(const float* qkv, const uint8_t* key_mask, const float* out, const float* dout,
@@ -371,16 +411,8 @@ extern "C" int clipk_attn_f32_bwd(const float* qkv, const uint8_t* key_mask, con
   p.dout = dout; p.delta = delta; p.dqkv = dqkv; p.B = B; p.L = L; p.H = H; p.D = D; p.scale = q_scale;
   rc = set_dropout(p, dropout_p, dropout_seed);
   if (rc) return rc;
-  static std::atomic<uint64_t> a1{0}, a2{0}, a3{0}, b1{0}, b2{0}, b3{0};
   hipStream_t st = (hipStream_t)stream;
-  if (D <= 64) {
-    rc = launch(attn_f32_bwd_dq_kernel<1>, a1, p, lds_dq(D), st);
-    return rc ? rc : launch(attn_f32_bwd_dkv_kernel<1>, b1, p, lds_dkv(D), st);
-  }
-  if (D <= 128) {
-    rc = launch(attn_f32_bwd_dq_kernel<2>, a2, p, lds_dq(D), st);
-    return rc ? rc : launch(attn_f32_bwd_dkv_kernel<2>, b2, p, lds_dkv(D), st);
-  }
-  rc = launch(attn_f32_bwd_dq_kernel<3>, a3, p, lds_dq(D), st);
-  return rc ? rc : launch(attn_f32_bwd_dkv_kernel<3>, b3, p, lds_dkv(D), st);
+  if (D <= 64) return launch_bwd<1>(p, st);
+  if (D <= 128) return launch_bwd<2>(p, st);
+  return launch_bwd<3>(p, st);
 }

@@ -1064,6 +1064,9 @@ def test_layernorm_second_order_backward_vs_autograd(dev, rows, cols, act):
     (2, 300, 2, 24, True),
     (5, 1, 3, 8, False),        # a single key
     (2, 77, 2, 192, False),     # the largest head dim
+    (4, 200, 8, 64, True),      # enough (batch, head, query-block) workgroups for four query rows per wave
+    (2, 300, 8, 160, True),
+    (16, 40, 8, 15, False),
 ])
 def test_attention_f32_fwd_bwd_vs_f64(dev, B, L, H, D, use_mask):
     """clipk_attn_f32_fwd / _bwd against f64 torch on the same inputs: output, lse and dqkv at f32 rounding level."""
