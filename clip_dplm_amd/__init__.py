@@ -17,7 +17,9 @@ from .modeling_seqclip import (ProteinRNACLIP, RNARBPCLIPEncoder, RNARBPCLIPMode
                                create_padding_mask)
 from .modeling_trimodal import CellStateEncoder, ContrastiveModel, PerturbationEncoder, TransformerEncoder
 from .optim import FlatParams, FusedAdamW, cosine_annealing_lr
-from .training import CosineAnnealingLR, EarlyStopping, evaluate_model, load_checkpoint, save_checkpoint, train_epoch
+from .training import (CosineAnnealingLR, EarlyStopping, GraphedTrainStep, evaluate_model, load_checkpoint, save_checkpoint,
+                       train_epoch)
+from . import training
 
 __all__ = [
     "HybridCLIPConfig", "ModelArchitectureConfig", "TrainingConfig", "SubConfig",
@@ -26,7 +28,7 @@ __all__ = [
     "RNARBPCLIPProjectionHead", "RNARBPCLIPEncoder", "RNARBPCLIPModel", "create_padding_mask", "ProteinRNACLIP",
     "ContrastiveModel", "CellStateEncoder", "PerturbationEncoder", "TransformerEncoder",
     "ESM2Encoder", "ESM2_SHAPES", "TransformerSeqEncoder", "pool", "clip_loss", "FlatParams", "FusedAdamW",
-    "cosine_annealing_lr", "CosineAnnealingLR", "EarlyStopping", "train_epoch", "evaluate_model", "save_checkpoint",
+    "cosine_annealing_lr", "CosineAnnealingLR", "GraphedTrainStep", "EarlyStopping", "train_epoch", "evaluate_model", "save_checkpoint",
     "load_checkpoint", "ESMConfig", "ESMIntegration", "ESMOutput", "BiologicalDataType", "ProteinProjection",
     "GeneProjection", "create_esm_integration", "get_embeddings_batch", "MemoryQueue", "contrastive_loss", "set_linear_precision",
 ]
