@@ -35,7 +35,8 @@ CASES = [
     ("trimodal_slice", T.test_trimodal_position0_slice_is_exact, {}),
     ("trimodal_loss", T.test_trimodal_loss_pairs_kernels_vs_f64, {}),
     ("packed_varlen", T.test_packed_varlen_path_equals_padded_path, {}),
-    ("dropout_layer", T.test_dropout_layer_vs_masked_oracle, {}),
+    ("dropout_layer_bf16", T.test_dropout_layer_vs_masked_oracle, {"precision": "bf16"}),
+    ("dropout_layer_f32", T.test_dropout_layer_vs_masked_oracle, {"precision": "f32"}),
     ("clip_opt_b128", T.test_clip_opt_b128_golden_loss_at_the_north_star_bar, {}),
     ("c1_f32", T.test_clip_c1_exact_f32_linears_reproduce_the_fp32_reference, {}),
     ("notebook_b32", T.test_notebook_model_b32_golden_loss_and_gradients, {}),
