@@ -81,6 +81,8 @@ def parse_args():
     ap.add_argument("--wgrad-stream", action="store_true", help="weight-gradient GEMMs on a side stream per tower")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="libclipk kernel-selection option for this run (experiments; results never depend on options)")
+    ap.add_argument("--graph", action="store_true",
+                    help="c2 / c4, one GPU: replay the training step from one hipGraph (training.GraphedTrainStep)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
@@ -392,6 +394,11 @@ def bench_clip(args):
         opt.step()
         return loss
 
+    eager_step = step
+    if args.graph and world == 1 and not force_dist and not ragged and not model.dual_stream:
+        from clip_dplm_amd.training import GraphedTrainStep
+        gstep = GraphedTrainStep(model, opt, lambda a, b: model.loss(a, b), (rna, ids), warmup=2)
+        step = lambda: gstep(rna, ids)
     tw = time.perf_counter()
     for i in range(args.warmup):
         step()
@@ -420,11 +427,11 @@ def bench_clip(args):
     was_dual = model.dual_stream
     if timer is not None and rank == 0 and world == 1 and (was_dual or not args.all_kernel_timers):
         model.dual_stream = False
-        step(); torch.cuda.synchronize()
+        eager_step(); torch.cuda.synchronize()
         timer_alone = ops.KernelTimer()
         ops.set_kernel_timer(timer_alone)
         for _ in range(2):
-            step()
+            eager_step()
         torch.cuda.synchronize()
         ops.set_kernel_timer(None)
         model.dual_stream = was_dual
@@ -458,7 +465,8 @@ def bench_clip(args):
         "ms_per_step": round(1e3 * dt / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": workload, "global_batch": B * world, "seq_len": Lp, "parallelism": f"dp{world}",
-                   "projection_dim": 512, "hip_streams": 2 if model.dual_stream else 1},
+                   "projection_dim": 512, "hip_streams": 2 if model.dual_stream else 1,
+                   "launch": "hipGraph replay" if step is not eager_step else "eager"},
         "loss": round(float(loss.item()), 5),
     }
     if coll is not None:

@@ -23,8 +23,10 @@ def mark_weights_dirty() -> None:
 
 
 # hipGraph capture of a training step (training.GraphedTrainStep): whether a bf16 copy is stale is a HOST decision, which a
-# replay never repeats - so while a step is being captured every copy is rebuilt at its point of use (into the same
-# buffers: the launches become part of the graph and every replay refreshes every copy from the current master weights).
+# replay never repeats.  While a step is being captured, (i) the copies the batched refresh covers (buffers in place, master
+# weight = the parameters' own storage) are left to it - FusedAdamW.step() launches it right after the update, the launch
+# becomes part of the graph and every replay leaves every such copy current for the next one; (ii) every other copy (per-call
+# operands: padded / concatenated weights, first use) is rebuilt at its point of use, into the same buffers.
 _CAPTURE_FORCE = False
 
 
@@ -51,6 +53,15 @@ def _cache_key(w: torch.Tensor, version=None):
     return (w.data_ptr(), w._version, _WEIGHT_EPOCH, tuple(w.shape))
 
 
+def _batched_refresh_covers(c, w, require_cuda: bool = True) -> bool:
+    """refresh_weight_caches() can rebuild this cache: buffers in place, a contiguous leaf master weight that IS the
+    parameters' storage (never a per-call copy: `derived`)."""
+    if w is None or c.derived or c.wb is None or c.wtb is None or (require_cuda and not w.is_cuda) \
+            or not w.is_leaf or not w.is_contiguous():
+        return False
+    return w.dim() == 2 and c.wb.shape == w.shape
+
+
 class WeightCache:
     """bf16 W [N,K] and W^T [K,N] of an f32 master weight, refreshed lazily (or all at once, refresh_weight_caches)."""
 
@@ -74,7 +85,7 @@ class WeightCache:
         self.derived = ver is not None and w.data_ptr() not in {v[0] for v in ver if isinstance(v, tuple)}
         key = _cache_key(w, ver)
         self.src = w                         # always the operand of THIS call, hit or miss
-        if key != self.key or _CAPTURE_FORCE:
+        if key != self.key or (_CAPTURE_FORCE and not _batched_refresh_covers(self, w)):
             src = w.detach()
             if not src.is_contiguous():
                 src = src.contiguous()
@@ -95,10 +106,7 @@ def _stale_caches(require_cuda: bool = True):
     todo = []
     for c in list(_CACHES):
         w = c.src
-        if w is None or c.derived or c.wb is None or c.wtb is None or (require_cuda and not w.is_cuda) \
-                or not w.is_leaf or not w.is_contiguous():
-            continue
-        if w.dim() != 2 or c.wb.shape != w.shape:
+        if not _batched_refresh_covers(c, w, require_cuda):
             continue
         key = _cache_key(w, None if c.src_version is None else c.src_version())
         if key != c.key:
@@ -110,8 +118,6 @@ def refresh_weight_caches() -> int:
     """Rebuild every stale bf16 copy in ONE kernel launch on the current stream.  Called by FusedAdamW.step() right
     after the update: the lazy path costs one launch per weight (76 in the config-2 model) at the next forward.
     Covers caches that already have their buffers and a contiguous leaf master weight; the rest stay lazy."""
-    if _CAPTURE_FORCE:                       # every copy is rebuilt where it is used (see set_capture_force)
-        return 0
     todo = _stale_caches()
     if not todo:
         return 0

@@ -200,7 +200,9 @@ class GraphedTrainStep:
         optimizer.m.copy_(saved[1])
         optimizer.v.copy_(saved[2])
         optimizer.step_count = saved[3]
-        KF.mark_weights_dirty()                            # bf16 copies of the restored weights are rebuilt on demand
+        KF.mark_weights_dirty()                            # the bf16 copies the first replay reads must be those of the
+        if optimizer.flat.data.is_cuda:                    # RESTORED weights (later replays refresh them in the graph)
+            KF.refresh_weight_caches()
 
     def _body(self):
         self.opt.zero_grad()

@@ -99,13 +99,19 @@ def test_clip_diffmap_golden(dev):
     assert (out["logits_per_diffmap_protein"].cpu() - t(z, "logits")).abs().max().item() < 0.15
 
 
-def test_clip_opt_golden_cache_loss(dev):
-    """OptimizedCLIPModule (old/clip_opt.py): cache columns + clamp; module loss and fused loss."""
+@pytest.mark.parametrize("precision", ["bf16", "f32"])
+def test_clip_opt_golden_cache_loss(dev, precision):
+    """OptimizedCLIPModule (old/clip_opt.py): cache columns + clamp; module loss and fused loss against the reference's
+    values at B = 32.  bf16 operands (the default arithmetic of the MLP towers): 32 rows do not average the rounding of a
+    bf16 GEMM away - the 1e-3 bar is asserted at the reference's own batch size in
+    test_clip_opt_b128_golden_loss_at_the_north_star_bar; here 5e-3 and the measured value is printed.  Exact-f32 Linears
+    (`set_linear_precision(m, "f32")`, the arithmetic of the reference's fp32 caller): 1e-4."""
     import clip_dplm_amd as K
     z, sd = load("clip_opt.npz")
     cfg = NS(diffmap_config=sub(48), protein_config=sub(96), projection_dim=32, cache_size=256)
     m = K.OptimizedCLIPModule(cfg)
     m.load_state_dict(sd)
+    K.set_linear_precision(m, precision)
     m = m.to(dev).eval()
     # put the cache in the state the reference had before this batch (first 32 rows = earlier batch)
     cache = t(z, "cache", dev)
@@ -113,10 +119,13 @@ def test_clip_opt_golden_cache_loss(dev):
     m.cache_ptr = 32
     out = m(t(z, "diffmap", dev), t(z, "protein", dev), gather_distributed=False)
     assert m.cache_ptr == int(z["cache_ptr"])
-    assert (out["logits_per_diffmap_protein"].cpu() - t(z, "logits")).abs().max().item() < 0.3
+    e_logit = (out["logits_per_diffmap_protein"].cpu() - t(z, "logits")).abs().max().item()
+    assert e_logit < (0.3 if precision == "bf16" else 2e-3), e_logit
     assert out["logits_per_diffmap_cache"].shape == tuple(z["logits_cache"].shape)
     loss = K.optimized_clip_loss(out)
-    assert abs(loss.item() - float(z["loss"])) < 5e-3       # B = 32 rows only; the 1e-3 bar is stated for B = 512
+    e_loss = abs(loss.item() - float(z["loss"]))
+    print(f"clip_opt B=32 [{precision}]: |dloss| {e_loss:.2e}, max |dlogit| {e_logit:.2e}")
+    assert e_loss < (5e-3 if precision == "bf16" else 1e-4), e_loss
     m.cache_ptr = 32
     lf = m.loss(t(z, "diffmap", dev), t(z, "protein", dev))
     assert abs(lf.item() - loss.item()) < 1e-4               # fused == materialised on the same embeddings

@@ -97,9 +97,10 @@ def test_notebook_model_wiring(monkeypatch):
     m.load_state_dict(sd)
     m.eval()
     ea, eb, loss = m(torch.from_numpy(z["rna"]), torch.from_numpy(z["rbp"]))
-    assert (ea - torch.from_numpy(z["rna_embed"])).abs().max().item() < 0.03
-    assert (eb - torch.from_numpy(z["rbp_embed"])).abs().max().item() < 0.03
-    assert abs(loss.item() - float(z["loss"])) < 2e-2
+    # default arithmetic of this model: exact f32, position 0 sliced before the encoders (wiring check on the emulator)
+    assert (ea - torch.from_numpy(z["rna_embed"])).abs().max().item() < 1e-4
+    assert (eb - torch.from_numpy(z["rbp_embed"])).abs().max().item() < 1e-4
+    assert abs(loss.item() - float(z["loss"])) < 1e-4
 
 
 def test_fused_adamw_matches_torch(monkeypatch):

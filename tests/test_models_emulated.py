@@ -10,7 +10,8 @@ import test_gpu_models as T
 CASES = [
     ("c1", T.test_clip_c1_golden_forward_loss_and_grads, {}),
     ("diffmap", T.test_clip_diffmap_golden, {}),
-    ("clip_opt", T.test_clip_opt_golden_cache_loss, {}),
+    ("clip_opt_bf16", T.test_clip_opt_golden_cache_loss, {"precision": "bf16"}),
+    ("clip_opt_f32", T.test_clip_opt_golden_cache_loss, {"precision": "f32"}),
     ("tlayer_relu", T.test_transformer_layer_golden, {"act": "relu"}),
     ("tlayer_gelu", T.test_transformer_layer_golden, {"act": "gelu"}),
     ("notebook_f32", T.test_notebook_model_golden, {"precision": "f32"}),
