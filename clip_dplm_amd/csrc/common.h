@@ -27,6 +27,7 @@ enum clipk_opt {
   OPT_SIMCE_KERNEL,        // -1 auto (tiled LSE pass for >= 64 queries), 1 first-generation kernel, 2 tiled
   OPT_GEMM_ABL,            // CLIPK_EXPERIMENTS builds only: timing ablations that change results
   OPT_ATTN_ROW_STORES,     // whole-head forward: 2 = rotated q / k rows written back four lanes to a row from LDS (measured slower; default off)
+  OPT_GEMM_F32_SPLITS,     // skinny exact-f32 Linear: cross-workgroup splits of the contraction (0 = auto, 1 .. 8)
   OPT_COUNT
 };
 int clipk_opt_get(int which);      // core.hip

@@ -23,7 +23,7 @@ const OptDef kOpts[OPT_COUNT] = {
     {"gemm_kernel", -1}, {"gemm_epi_generic", 0}, {"gemm_bm", 0}, {"gemm_stages", 1}, {"gemm_nwg", 0},
     {"gemm_stagger", 0}, {"epi_nt", 0}, {"wgrad_kernel", -1}, {"attn_whole_fwd", -1}, {"attn_fused_bwd", -1},
     {"attn_fused_waves", 0}, {"wgrad_splits", 0}, {"simce_kernel", -1}, {"gemm_abl", 0},
-    {"attn_row_stores", 0},
+    {"attn_row_stores", 0}, {"gemm_f32_splits", 0},
 };
 std::atomic<int> g_opts[OPT_COUNT];
 std::atomic<bool> g_opts_init{false};

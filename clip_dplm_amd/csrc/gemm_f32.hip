@@ -327,6 +327,8 @@ static int skinny_splits(int N, int K, int MB) {
   // of 1 / S of the contraction each: take the S <= 8 with the least rounds / S (ties: the smaller S - fewer partial
   // tiles), never less than one 32-index unit per wave
   const int njb = (N + 31) / 32, nunit = (K + (MB == 1 ? 32 : 16) - 1) / (MB == 1 ? 32 : 16);
+  const int forced = clipk_opt_get(OPT_GEMM_F32_SPLITS);
+  if (forced >= 1 && forced <= 8) return (nunit / forced >= 1) ? forced : 1;
   int best = 1;
   double cost = (double)((njb + 255) / 256);
   for (int S = 2; S <= 8; ++S) {

@@ -45,7 +45,7 @@ const char* clipk_status_string(int status);
  * of every option computes the same results: they pick between kernels / schedules that tests and tools/ compare.
  * Names: gemm_kernel (-1 auto, 1 generic, 2 128x128, 3 persistent 256x256, 4 persistent 128x256 with two workgroups per CU), gemm_epi_generic, gemm_bm, gemm_stages,
  * gemm_nwg, gemm_stagger, epi_nt, wgrad_kernel (-1 auto, 2, 3), attn_whole_fwd, attn_fused_bwd (-1 auto, 0, 1),
- * attn_fused_waves (0 auto: 4 waves for head dims <= 32, 8 for 96; 4; 8), attn_row_stores (0, 2: forward write-back of rotated rows from LDS), simce_kernel (-1 auto, 1 first-generation, 2 tiled LSE pass).  Unknown name -> CLIPK_ERR_BAD_ARG.  (The reference has no counterpart: its kernels are
+ * attn_fused_waves (0 auto: 4 waves for head dims <= 32, 8 for 96; 4; 8), attn_row_stores (0, 2: forward write-back of rotated rows from LDS), gemm_f32_splits (0 auto, 1 .. 8: cross-workgroup splits of the skinny f32 Linear), simce_kernel (-1 auto, 1 first-generation, 2 tiled LSE pass).  Unknown name -> CLIPK_ERR_BAD_ARG.  (The reference has no counterpart: its kernels are
  * ATen's.) */
 int clipk_set_option(const char* name, int value);
 int clipk_get_option(const char* name, int* value);
