@@ -38,6 +38,7 @@ class GemmArgs(C.Structure):
         ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p),
         ("rope_L", C.c_int), ("rope_hd", C.c_int), ("rope_cols", C.c_int), ("rope_row0", C.c_int),
         ("aux_dtype", C.c_int),
+        ("rope_interleaved", C.c_int),
     ]
 
 
@@ -53,7 +54,7 @@ SIGNATURES = {
     "clipk_reset_options": (_i, []),
     "clipk_gemm_nt": (_i, [C.POINTER(GemmArgs), _vp]),
     "clipk_gemm_wgrad_workspace": (_sz, [_i, _i, _i]),
-    "clipk_gemm_wgrad": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "clipk_gemm_wgrad": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "clipk_simce_workspace": (_sz, [_i, _i, _i]),
     "clipk_simce_lse": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "clipk_simce_grad": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _sz, _vp]),
@@ -79,7 +80,7 @@ SIGNATURES = {
     "clipk_l2norm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "clipk_cast_f32_to_bf16": (_i, [_vp, _vp, _i64, _vp]),
     "clipk_cast_bf16_to_f32": (_i, [_vp, _vp, _i64, _vp]),
-    "clipk_cast_transpose": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "clipk_cast_transpose": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "clipk_cast_transpose_batched": (_i, [_vp, _i, _vp]),
     "clipk_act_fwd": (_i, [_vp, _vp, _i, _i64, _vp]),
     "clipk_act_bwd": (_i, [_vp, _vp, _vp, _i, _i64, _vp]),

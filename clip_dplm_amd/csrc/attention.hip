@@ -478,10 +478,12 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_FWD) void attn_fwd_kernel(const AP
 
 // write an f32 [rows][DP+4] LDS image (gradient w.r.t. rotated q/k) as bf16 rows of dqkv, applying the
 // RoPE transpose on the way when ROPE
+// il: the head dim is in pair-interleaved order (common.h il_src; the rows were rotated by clipk_gemm_nt's interleaved
+// epilogue): the partner of column d is d ^ 1 and its angle index d >> 1
 template <bool ROPE>
 __device__ __forceinline__ void store_grad_rows(const float* img, int ILD, unsigned short* base, long tokstride,
                                                 int pos0, int nrows, int L, int D, const float* cosT,
-                                                const float* sinT, int tid) {
+                                                const float* sinT, int tid, bool il = false) {
   const int cpr = D >> 3, half = D >> 1;
   for (int c = tid; c < nrows * cpr; c += 256) {
     const int r = c / cpr, ch = c - r * cpr;
@@ -494,10 +496,10 @@ __device__ __forceinline__ void store_grad_rows(const float* img, int ILD, unsig
       const int d = ch * 8 + e;
       float x = row[d];
       if (ROPE) {
-        const bool lo = d < half;
-        const int j = lo ? d : d - half;
+        const bool lo = il ? !(d & 1) : d < half;
+        const int j = il ? (d >> 1) : (lo ? d : d - half);
         const float cs = cosT[(long)pos * half + j], sn = sinT[(long)pos * half + j];
-        const float other = row[lo ? d + half : d - half];
+        const float other = row[il ? (d ^ 1) : (lo ? d + half : d - half)];
         x = lo ? (x * cs + other * sn) : (x * cs - other * sn);
       }
       v[e] = x;
@@ -524,12 +526,42 @@ __device__ __forceinline__ void load_rope_row(RopeRow<D>& T, const float* cosT, 
 }
 // f32 image row (gradient w.r.t. the rotated q / k) -> RoPE^T -> bf16 row of dqkv
 template <bool ROPE, int D>
-__device__ __forceinline__ void store_grad_row(const float* row, unsigned short* dst, const RopeRow<D>& T, float scale) {
+__device__ __forceinline__ void store_grad_row(const float* row, unsigned short* dst, const RopeRow<D>& T, float scale,
+                                               bool il = false) {
   constexpr int NG = D / 4;
   f32x4 x[NG];
 #pragma unroll
   for (int i = 0; i < NG; ++i) x[i] = *reinterpret_cast<const f32x4*>(row + 4 * i) * scale;
-  if (ROPE) {
+  // `dst` may BE `row` (the whole-head backward converts in place): every read of the row before any write of it.  The
+  // compiler sees a float row and an integer destination and assumes they cannot alias; in the rotate-half form the data
+  // dependences (both halves feed every chunk) happen to enforce the order, in the interleaved form chunk c depends on
+  // x[2 c], x[2 c + 1] only and nothing did.
+  asm volatile("" ::: "memory");
+  if (ROPE && il) {                                        // pair-interleaved head order: partners are neighbours
+    // Four plain VALU instructions per pair, spelled out: left to hipcc this loop became v_pk_mul / v_pk_fma_f32 with
+    // op_sel swizzles on half-overwritten register pairs, and the gradients of lanes 48 - 63 of every wave came out
+    // different from run to run (a few hundred of 23.6 M elements, up to 0.03 absolute; tools/dbg_repro.py) - the
+    // rotate-half form next to it, same kernel, same registers, is bit-reproducible.  The leading s_nop covers the wait
+    // state a packed-f32 result needs before an instruction the hazard recogniser cannot see into.
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq)
+#pragma unroll
+      for (int q = 0; q < 4; q += 2) {
+        const int j = 2 * gq + (q >> 1);                   // the pair's angle
+        const float cs = T.cs[j >> 2][j & 3], sn = T.sn[j >> 2][j & 3];
+        const float a = x[gq][q], b = x[gq][q + 1];
+        float o0, o1, t0, t1;
+        asm volatile("s_nop 1\n\t"
+                     "v_mul_f32 %2, %5, %7\n\t"            // t0 = b sn
+                     "v_mul_f32 %3, %4, %7\n\t"            // t1 = a sn
+                     "v_fma_f32 %0, %4, %6, %2\n\t"        // a cs + b sn
+                     "v_fma_f32 %1, %5, %6, -%3"            // b cs - a sn
+                     : "=&v"(o0), "=&v"(o1), "=&v"(t0), "=&v"(t1)
+                     : "v"(a), "v"(b), "v"(cs), "v"(sn));
+        x[gq][q] = o0;
+        x[gq][q + 1] = o1;
+      }
+  } else if (ROPE) {
 #pragma unroll
     for (int i = 0; i < NG / 2; ++i) {
       const f32x4 lo = x[i], hi = x[i + NG / 2];
@@ -753,7 +785,7 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dq_kernel(const
         img[(wid * 32 + qt * 16 + li) * ILD + dt * 16 + 4 * g + r] = dq[dt][qt][r] * p.scale;
   __syncthreads();
   store_grad_rows<(DR > 0)>(img, ILD, p.dqkv + row0 * tokstride + (long)h * D, tokstride, q0, 128, L, D,
-                            p.cosT, p.sinT, tid);
+                            p.cosT, p.sinT, tid, p.pre_rot == 2);
 }
 
 // =================================================================================================
@@ -915,7 +947,7 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dkv_kernel(cons
       for (int r = 0; r < 4; ++r)
         img[(wid * KPW + kt * 16 + li) * ILD + dt * 16 + 4 * g + r] = dk[dt][kt][r] * p.scale;
   __syncthreads();
-  store_grad_rows<(DR > 0)>(img, ILD, dkbase, tokstride, k0, KPB, L, D, p.cosT, p.sinT, tid);
+  store_grad_rows<(DR > 0)>(img, ILD, dkbase, tokstride, k0, KPB, L, D, p.cosT, p.sinT, tid, p.pre_rot == 2);
   __syncthreads();
 #pragma unroll
   for (int kt = 0; kt < KTW; ++kt)
@@ -1282,8 +1314,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
     // RoPE^T, scale and rounding by the row's owner, IN PLACE (the bf16 row over the start of its own f32 row; the
     // row is read whole before it is written) ...
     if (tq < L) {
-      store_grad_row<ROPE, D>(img + tq * ILD, reinterpret_cast<unsigned short*>(img + tq * ILD), T, p.scale);   // q_scale: once, here
-      store_grad_row<ROPE, D>(img2 + tq * ILD, reinterpret_cast<unsigned short*>(img2 + tq * ILD), T, p.scale);
+      store_grad_row<ROPE, D>(img + tq * ILD, reinterpret_cast<unsigned short*>(img + tq * ILD), T, p.scale, p.pre_rot == 2);   // q_scale: once, here
+      store_grad_row<ROPE, D>(img2 + tq * ILD, reinterpret_cast<unsigned short*>(img2 + tq * ILD), T, p.scale, p.pre_rot == 2);
     }
     __syncthreads();
     // ... and the rows leave four lanes to a row, as they came: a wave instruction covers 16 rows x 2 D bytes.  (One
@@ -2516,7 +2548,7 @@ extern "C" int clipk_attn_bwd(const void* qkv, const uint8_t* key_mask, const fl
   p.out = (unsigned short*)out; p.lse = const_cast<float*>(lse);
   p.dout = (const unsigned short*)dout; p.delta = delta; p.dqkv = (unsigned short*)dqkv;
   p.B = B; p.L = L; p.H = H; p.D = D; p.scale = q_scale;
-  p.pre_rot = (rope && prerotated) ? 1 : 0;
+  p.pre_rot = (rope && prerotated) ? (prerotated == 2 ? 2 : 1) : 0;
   rc = set_dropout(p, dropout_p, dropout_seed);
   if (rc) return rc;
   ATTN_DISPATCH(launch_bwd, D, rope, p, (hipStream_t)stream);
@@ -2585,7 +2617,7 @@ extern "C" int clipk_attn_varlen_bwd(const void* qkv, const int* cu_seqlens, con
   p.dout = (const unsigned short*)dout; p.delta = delta; p.dqkv = (unsigned short*)dqkv;
   p.B = B; p.L = max_len; p.H = H; p.D = D; p.scale = q_scale;
   p.cu = cu_seqlens; p.T = T;
-  p.pre_rot = (rope && prerotated) ? 1 : 0;
+  p.pre_rot = (rope && prerotated) ? (prerotated == 2 ? 2 : 1) : 0;
   rc = set_dropout(p, dropout_p, dropout_seed);
   if (rc) return rc;
   ATTN_DISPATCH(launch_bwd, D, rope, p, (hipStream_t)stream);

@@ -227,6 +227,19 @@ __device__ __forceinline__ float drop_mul(unsigned seed, unsigned long long idx,
   return drop_keep(seed, idx, thr) ? scale : 0.f;
 }
 
+// ---- pair-interleaved head order (round 4: RoPE of the hd-24 ESM heads in the qkv GEMM's epilogue).  The first il_rows
+// output columns of a fused [q | k | v] projection (the q and k sections) are computed in an order in which the two
+// partners of a rotate-half pair (d, d + hd/2) are NEIGHBOURS (2 j, 2 j + 1), so that a lane's 8 consecutive columns
+// hold four complete pairs whatever the head dim (hd = 24 does not tile the epilogue's 64-column wave slices).  q . k is
+// invariant under a common permutation of the head dim, so the attention kernels run unchanged on such q / k; only RoPE
+// (forward: GEMM epilogue; backward: RoPE^T where the gradient rows are written) and the weight copies / weight-gradient
+// rows know about the order.  il_src(r): the ORIGINAL row (output column) that permuted row r holds.
+__host__ __device__ inline int il_src(int r, int hd, int il_rows) {
+  if (r >= il_rows) return r;
+  const int d = r % hd;
+  return (r - d) + (d >> 1) + (d & 1) * (hd >> 1);
+}
+
 // wave-wide reductions over 64 lanes
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

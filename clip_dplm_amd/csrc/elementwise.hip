@@ -43,8 +43,9 @@ __global__ void cast_bf16_f32_kernel(const unsigned short* x, float* y, long n) 
 }
 
 // 64x64 tile through LDS: coalesced f32 reads along cols, coalesced bf16 writes along rows of W^T
+// (il_hd, il_rows): rows [0, il_rows) of BOTH copies in pair-interleaved head order (common.h il_src): copy row r = w row il_src(r)
 __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* w, unsigned short* wb, unsigned short* wt,
-                                                             int rows, int cols) {
+                                                             int rows, int cols, int il_hd, int il_rows) {
   __shared__ float tile[64][65];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* w, uns
     const int r = r0 + i, c = c0 + tx;
     float v = 0.f;
     if (r < rows && c < cols) {
-      v = w[(long)r * cols + c];
+      v = w[(long)il_src(r, il_hd, il_rows) * cols + c];
       if (wb) wb[(long)r * cols + c] = f32_to_bf16(v);
     }
     tile[i][tx] = v;
@@ -67,15 +68,15 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* w, uns
 }
 
 // every weight of a model in ONE launch (the optimiser step refreshes all bf16 copies at once: 76 launches of
-// ~12 us each otherwise).  desc[t] = {w, w_bf16, wt_bf16, rows, cols} as int64; blockIdx.y = tensor, blocks stride
-// over its 64x64 tiles.
+// ~12 us each otherwise).  desc[t] = {w, w_bf16, wt_bf16, rows, cols, il_hd, il_rows} as int64; blockIdx.y = tensor, blocks
+// stride over its 64x64 tiles.
 __global__ __launch_bounds__(256) void cast_transpose_batched_kernel(const long long* desc) {
   __shared__ float tile[64][65];
-  const long long* d = desc + 5 * (long)blockIdx.y;
+  const long long* d = desc + 7 * (long)blockIdx.y;
   const float* w = reinterpret_cast<const float*>(d[0]);
   unsigned short* wb = reinterpret_cast<unsigned short*>(d[1]);
   unsigned short* wt = reinterpret_cast<unsigned short*>(d[2]);
-  const int rows = (int)d[3], cols = (int)d[4];
+  const int rows = (int)d[3], cols = (int)d[4], il_hd = (int)d[5], il_rows = (int)d[6];
   const int tx_n = (cols + 63) / 64, ntiles = tx_n * ((rows + 63) / 64);
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void cast_transpose_batched_kernel(const long 
       const int r = r0 + i, c = c0 + tx;
       float v = 0.f;
       if (r < rows && c < cols) {
-        v = w[(long)r * cols + c];
+        v = w[(long)il_src(r, il_hd, il_rows) * cols + c];
         if (wb) wb[(long)r * cols + c] = f32_to_bf16(v);
       }
       tile[i][tx] = v;
@@ -468,10 +469,12 @@ extern "C" int clipk_cast_bf16_to_f32(const void* x, float* y, int64_t n, void* 
                      (const unsigned short*)x, y, (long)n);
   return clipk_check_launch();
 }
-extern "C" int clipk_cast_transpose(const float* w, void* w_bf16, void* wt_bf16, int rows, int cols, void* stream) {
+extern "C" int clipk_cast_transpose(const float* w, void* w_bf16, void* wt_bf16, int rows, int cols, int il_hd, int il_rows,
+                                    void* stream) {
   if (!w || rows <= 0 || cols <= 0 || (!w_bf16 && !wt_bf16)) return CLIPK_ERR_BAD_ARG;
+  if (il_rows < 0 || il_rows > rows || (il_rows > 0 && (il_hd < 2 || (il_hd & 1) || il_rows % il_hd))) return CLIPK_ERR_BAD_ARG;
   hipLaunchKernelGGL(cast_transpose_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream,
-                     w, (unsigned short*)w_bf16, (unsigned short*)wt_bf16, rows, cols);
+                     w, (unsigned short*)w_bf16, (unsigned short*)wt_bf16, rows, cols, il_rows ? il_hd : 2, il_rows);
   return clipk_check_launch();
 }
 extern "C" int clipk_cast_transpose_batched(const void* desc_dev, int n, void* stream) {

@@ -42,6 +42,8 @@ enum {
   EPI_GELU_D8 = 7,    // u8 GELU'(pre-activation) code out and bf16 GELU out (+bias)
   EPI_DGELU8 = 8,     // bf16 out = acc * decode(u8 aux)
   EPI_PLAIN_NB = 9,   // bf16 out, no bias (the plain input gradients)
+  EPI_ROPE_IL = 10,   // bf16 out = RoPE of (acc + bias) on the first rope_cols columns, whose heads are PAIR-INTERLEAVED
+                      // (common.h il_src): a pair is two neighbouring columns of one lane - any head dim % 8 == 0
 };
 // Every specialised mode requires alpha == 1 (no caller scales the product: one packed multiply per output pair gone from
 // every epilogue), and the modes that only input-gradient GEMMs use - DGELU, DGELU8, PRES16, PLAIN_NB - take no bias
@@ -54,7 +56,8 @@ constexpr int EPI_UNSUPPORTED = -2;   // epi_mode_for: the request cannot be hon
 // VMEM stores one wave issues in gemm_epilogue<MODE, NJ> (its loads are consumed inside): callers that keep LDS-DMA
 // in flight across the epilogue count them in their s_waitcnt vmcnt(N)
 constexpr int epi_stores(int mode, int nj) {
-  return (mode == EPI_PLAIN || mode == EPI_PLAIN_NB || mode == EPI_DGELU || mode == EPI_PRES16 || mode == EPI_ROPE || mode == EPI_DGELU8) ? 2 * nj
+  return (mode == EPI_PLAIN || mode == EPI_PLAIN_NB || mode == EPI_DGELU || mode == EPI_PRES16 || mode == EPI_ROPE || mode == EPI_DGELU8 ||
+          mode == EPI_ROPE_IL) ? 2 * nj
          : (mode == EPI_RES32 || mode == EPI_GELU_PRE || mode == EPI_RES16 || mode == EPI_GELU_D8) ? 4 * nj : -1;
 }
 
@@ -69,6 +72,14 @@ static inline int epi_mode_for(const clipk_gemm_args* a) {
     if (has_aux && (a->dact != CLIPK_ACT_GELU || (a->ldd & 7))) return EPI_UNSUPPORTED;
   }
   const long lim = 0x7fffffffL;                          // buffer-descriptor stores: byte extents must stay < 2 GiB
+  if (a->rope_cos && a->rope_interleaved) {              // pairs are neighbours: no tiling rule beyond 8-column chunks
+    const int hd = a->rope_hd;
+    const bool ok = a->rope_sin && hd >= 8 && (hd & 7) == 0 && a->rope_L > 0 && a->rope_cols > 0 &&
+                    a->rope_cols % hd == 0 && a->rope_cols <= a->N && a->rope_row0 >= 0 && !c_f32 && !has_res &&
+                    !has_aux && !has_pre && a->act == CLIPK_ACT_NONE && a->drop_p <= 0.f && a->alpha == 1.0f &&
+                    ((long)(a->M - 1) * a->ldc + a->N) * 2 <= lim;
+    return ok ? EPI_ROPE_IL : EPI_UNSUPPORTED;
+  }
   if (a->rope_cos) {                                     // rotation exists in its straight-line mode only
     const int hd = a->rope_hd;
     const bool ok = a->rope_sin && (hd == 16 || hd == 32 || hd == 64) && a->rope_L > 0 && a->rope_cols > 0 &&
@@ -166,6 +177,10 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
     int rp_chunk = 0, rp_tcol = 0;
     bool rp_on = false, rp_lo = false;
     float bvp[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (MODE == EPI_ROPE_IL) {
+      rp_tcol = (gn % p.rope_hd) >> 1;                                   // first of this lane's four pairs
+      rp_on = col_ok && gn < p.rope_cols;
+    }
     if constexpr (MODE == EPI_ROPE) {
       const int half = p.rope_hd >> 1, d0 = ecol & (p.rope_hd - 1);
       rp_lo = d0 < half;
@@ -190,6 +205,12 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
         a1 = *reinterpret_cast<const f32x4*>(p.rope_cos + t + 4);
         a2 = *reinterpret_cast<const f32x4*>(p.rope_sin + t);
         a3 = *reinterpret_cast<const f32x4*>(p.rope_sin + t + 4);
+      }
+      if constexpr (MODE == EPI_ROPE_IL) {
+        const int pos = (gm + p.rope_row0) % p.rope_L;
+        const long t = (long)pos * (p.rope_hd >> 1) + rp_tcol;
+        a0 = *reinterpret_cast<const f32x4*>(p.rope_cos + t);
+        a2 = *reinterpret_cast<const f32x4*>(p.rope_sin + t);
       }
       if constexpr (MODE == EPI_RES32) {
         const float* r = reinterpret_cast<const float*>(p.residual) + (long)gm * p.ldr + gnc;
@@ -263,6 +284,19 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
             y[e] = fmaf(v[k], cs, rp_lo ? -(vp * sn) : vp * sn);
           }
           o[c >> 1] = pack_bf16x2(y[0], y[1]);
+        }
+        const unsigned off = ok ? (unsigned)(((long)gm * p.ldc + gn) * 2) : OOB;
+        epi_store(o, c_rsrc, off, p.nt);
+      } else if constexpr (MODE == EPI_ROPE_IL) {
+        u32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float cs = rp_on ? r0[c] : 1.0f, sn = rp_on ? r2[c] : 0.0f;
+          // x1' = fma(x1, c, -(x2 s)), x2' = fma(x2, c, x1 s): the arithmetic of rope_regs (attention.hip), on the f32
+          // value before its one bf16 rounding
+          const float y1 = fmaf(v[2 * c], cs, -(v[2 * c + 1] * sn));
+          const float y2 = fmaf(v[2 * c + 1], cs, v[2 * c] * sn);
+          o[c] = pack_bf16x2(y1, y2);
         }
         const unsigned off = ok ? (unsigned)(((long)gm * p.ldc + gn) * 2) : OOB;
         epi_store(o, c_rsrc, off, p.nt);

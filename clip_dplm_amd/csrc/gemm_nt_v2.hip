@@ -175,7 +175,7 @@ extern "C" int clipk_gemm_nt_v2_launch(const clipk_gemm_args* a, void* stream) {
   const int stages = clipk_opt_get(OPT_GEMM_STAGES);
   const int mode = clipk_opt_get(OPT_GEMM_EPI_GENERIC) == 1 ? EPI_GENERIC : epi_mode_for(a);
   if (mode == EPI_UNSUPPORTED) return CLIPK_ERR_UNSUPPORTED;
-  if (a->rope_cos && (mode != EPI_ROPE || big || stages == 2)) return CLIPK_ERR_UNSUPPORTED;   // never unrotated
+  if (a->rope_cos && ((mode != EPI_ROPE && mode != EPI_ROPE_IL) || big || stages == 2)) return CLIPK_ERR_UNSUPPORTED;   // never unrotated
   static std::atomic<uint64_t> attr_set{0};
   clipk_once_per_device(attr_set, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_v2_kernel<256, 2>),
@@ -202,6 +202,7 @@ extern "C" int clipk_gemm_nt_v2_launch(const clipk_gemm_args* a, void* stream) {
     else if (mode == EPI_GELU_D8) hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, EPI_GELU_D8>), grid, blk, lds, st, p);
     else if (mode == EPI_DGELU8) hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, EPI_DGELU8>), grid, blk, lds, st, p);
     else if (mode == EPI_PLAIN_NB) hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, EPI_PLAIN_NB>), grid, blk, lds, st, p);
+    else if (mode == EPI_ROPE_IL) hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1, EPI_ROPE_IL>), grid, blk, lds, st, p);
     else hipLaunchKernelGGL((gemm_nt_v2_kernel<128, 1>), grid, blk, lds, st, p);
   }
   return clipk_check_launch();

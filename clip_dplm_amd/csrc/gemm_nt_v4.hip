@@ -334,6 +334,7 @@ extern "C" int clipk_gemm_nt_v4_launch(const clipk_gemm_args* a, void* stream) {
   else if (mode == EPI_GELU_D8) launch_v4<EPI_GELU_D8>(p, grid, st);
   else if (mode == EPI_DGELU8) launch_v4<EPI_DGELU8>(p, grid, st);
   else if (mode == EPI_PLAIN_NB) launch_v4<EPI_PLAIN_NB>(p, grid, st);
+  else if (mode == EPI_ROPE_IL) launch_v4<EPI_ROPE_IL>(p, grid, st);
   else if (mode == EPI_UNSUPPORTED || a->rope_cos) return CLIPK_ERR_UNSUPPORTED;   // rotation: its own mode only
   else launch_v4<EPI_GENERIC>(p, grid, st);
   return clipk_check_launch();

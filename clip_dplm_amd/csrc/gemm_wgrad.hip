@@ -190,8 +190,10 @@ __global__ __launch_bounds__(NTHREADS, 3) void wgrad_kernel(const WP p) {
   }
 }
 
+// (il_hd, il_rows): dY's first il_rows columns are in pair-interleaved head order (common.h il_src): gradient row n of the
+// slabs belongs to row il_src(n) of dW / dbias (identity when il_rows == 0)
 __global__ void wgrad_reduce_kernel(const float* slab, const float* bslab, int splits, int bsplits, int N, int K,
-                                    float* dW, long lddw, float* dbias, int accumulate) {
+                                    float* dW, long lddw, float* dbias, int accumulate, int il_hd, int il_rows) {
   const long total4 = (long)N * K / 4;
   const int k4 = K >> 2;
   const long stride = (long)gridDim.x * blockDim.x;
@@ -207,7 +209,7 @@ __global__ void wgrad_reduce_kernel(const float* slab, const float* bslab, int s
     }
     for (; s < splits; ++s) a += src[(long)s * sstride];
     const long n = i / k4; const int c = (int)(i - n * k4);
-    f32x4* o = reinterpret_cast<f32x4*>(dW + n * lddw + 4 * c);
+    f32x4* o = reinterpret_cast<f32x4*>(dW + (long)il_src((int)n, il_hd, il_rows) * lddw + 4 * c);
     *o = accumulate ? (*o + a) : a;
   }
   if (dbias) {
@@ -221,7 +223,8 @@ __global__ void wgrad_reduce_kernel(const float* slab, const float* bslab, int s
         a += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
       }
       for (; s < bsplits; ++s) a += bslab[(long)s * N + i];
-      dbias[i] = accumulate ? dbias[i] + a : a;
+      const int o = il_src((int)i, il_hd, il_rows);
+      dbias[o] = accumulate ? dbias[o] + a : a;
     }
   }
 }
@@ -264,8 +267,10 @@ extern "C" size_t clipk_gemm_wgrad_workspace(int M, int N, int K) {
 
 extern "C" int clipk_gemm_wgrad(const void* dY, int64_t lddy, const void* X, int64_t ldx,
                                 float* dW, int64_t lddw, float* dbias, int M, int N, int K, int accumulate,
-                                void* workspace, size_t workspace_bytes, void* stream) {
+                                int il_hd, int il_rows, void* workspace, size_t workspace_bytes, void* stream) {
   if (!dY || !X || !dW || !workspace || M <= 0 || N <= 0 || K <= 0) return CLIPK_ERR_BAD_ARG;
+  if (il_rows < 0 || il_rows > N || (il_rows > 0 && (il_hd < 2 || (il_hd & 1) || il_rows % il_hd))) return CLIPK_ERR_BAD_ARG;
+  if (il_rows == 0) il_hd = 2;
   if ((N & 7) || (K & 7) || (lddy & 7) || (ldx & 7) || (lddw & 3)) return CLIPK_ERR_UNSUPPORTED;
   if (!aligned16(dY) || !aligned16(X) || !aligned16(dW) || !aligned16(workspace)) return CLIPK_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -283,7 +288,7 @@ extern "C" int clipk_gemm_wgrad(const void* dY, int64_t lddy, const void* X, int
     long total4 = (long)N * K / 4;
     int blocks = (int)((total4 + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)a.slab, (const float*)a.bslab,
-                       a.splits, a.splits * a.ntk, N, K, dW, (long)lddw, dbias, accumulate);
+                       a.splits, a.splits * a.ntk, N, K, dW, (long)lddw, dbias, accumulate, il_hd, il_rows);
     return clipk_check_launch();
   }
   const Plan pl = make_plan(M, N, K);
@@ -302,6 +307,6 @@ extern "C" int clipk_gemm_wgrad(const void* dY, int64_t lddy, const void* X, int
   long total4 = (long)N * K / 4;
   int blocks = (int)((total4 + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)p.slab, (const float*)p.bslab,
-                     pl.splits, pl.splits, N, K, dW, (long)lddw, dbias, accumulate);
+                     pl.splits, pl.splits, N, K, dW, (long)lddw, dbias, accumulate, il_hd, il_rows);
   return clipk_check_launch();
 }

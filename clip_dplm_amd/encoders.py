@@ -40,6 +40,13 @@ _SIDE = {}
 PREROTATE_QK = os.environ.get("CLIPK_PREROTATE", "1") != "0"   # ESM: RoPE on q / k once after the qkv GEMM, not at every staging
 ROPE_IN_QKV_EPILOGUE = os.environ.get("CLIPK_ROPE_EPILOGUE", "1") != "0"   # hd in {16, 32, 64}: rotate in the qkv GEMM's epilogue
 DIRECT_PARAM_GRADS = True      # weight-gradient kernels accumulate straight into existing .grad buffers
+# ESM heads whose dim does not tile the GEMM epilogue's 64-column wave slices (ESM-2-8M / 35M / 150M: 16 handled above, 24,
+# 32 ...): the q and k sections of the fused qkv projection are computed in PAIR-INTERLEAVED head order (bf16 weight copies
+# with permuted rows, csrc/common.h il_src), so that RoPE runs in the projection's epilogue on neighbouring columns - on the
+# f32 value, before its one bf16 rounding - and the attention forward neither rotates nor writes rotated rows back.  q . k
+# is invariant under a common order of the head dim; the backward's RoPE^T and the weight-gradient rows undo the order.
+# Whole-head attention shapes only (128 < L <= 256, head dim <= 32); CLIPK_ROPE_INTERLEAVED=0 keeps the in-place rotation.
+ROPE_INTERLEAVED = os.environ.get("CLIPK_ROPE_INTERLEAVED", "1") != "0"
 
 
 def _direct_ok(t):
@@ -88,8 +95,9 @@ def _ln_bwd(dy, x, w, b, mean, rstd, pool=None, **kw):
     return ops.layernorm_bwd(dy, x, w, None, mean, rstd, **kw)
 
 
-def _wgrad(dy, x, lin=None):
-    """dW, db = wgrad(dy, x), optionally enqueued on the calling stream's side stream."""
+def _wgrad(dy, x, lin=None, il=(0, 0)):
+    """dW, db = wgrad(dy, x), optionally enqueued on the calling stream's side stream.  il: dy's leading columns are in
+    pair-interleaved head order; the gradient rows land in the original order."""
     # With pre-allocated .grad buffers (FusedAdamW keeps them as views of one flat buffer) the reduce kernel adds
     # into them directly and autograd gets None: saves one torch `add` launch per parameter and step (289 of them
     # in the config-2 model) and the temporary.  Same semantics as AccumulateGrad: grad += dW.
@@ -98,6 +106,8 @@ def _wgrad(dy, x, lin=None):
     else:
         direct = DIRECT_PARAM_GRADS and lin is not None and _direct_ok(lin.w) and _direct_ok(lin.b)
         kw = dict(dw=lin.w.grad, dbias=lin.b.grad, accumulate=True) if direct else dict(want_bias=True)
+    if il[1]:
+        kw["il"] = il
     if not (WGRAD_SIDE_STREAM and dy.is_cuda):
         r = ops.gemm_wgrad(dy, x, **kw)
         return (None, None) if direct else r
@@ -157,12 +167,18 @@ def _bucket_done(module, grads):
 
 class _Lin:
     """Kernel-side view of one Linear: f32 master params + cached bf16 W / W^T.  gw / gb: explicit gradient buffers
-    (fused views of several parameters' .grad), used instead of w.grad / b.grad by the direct-accumulation path."""
+    (fused views of several parameters' .grad), used instead of w.grad / b.grad by the direct-accumulation path.
+    il_cache (optional): a second cache whose copies have their leading rows in pair-interleaved head order (`il`)."""
 
-    def __init__(self, w, b, cache: KF.WeightCache, gw=None, gb=None, version_fn=None):
+    def __init__(self, w, b, cache: KF.WeightCache, gw=None, gb=None, version_fn=None, il_cache=None):
         self.w, self.b = w, b
         self.gw, self.gb = gw, gb
-        self.wb, self.wtb = cache.get(w, version_fn)
+        self.il = (0, 0)
+        if il_cache is not None:                               # this forward uses the interleaved copies only
+            self.il = il_cache.il
+            self.wb, self.wtb = il_cache.get(w, version_fn)
+        else:
+            self.wb, self.wtb = cache.get(w, version_fn)
 
 
 # =================================================================================================
@@ -190,6 +206,13 @@ def _esm_layer_fwd(x, p, meta, keep=True):
         # heads that tile the GEMM's 64-column wave slices (ESM-2-650M: 20 x 64): q / k leave the projection's epilogue
         # already rotated - no second pass over them.  (hd = 24 of the 35M model does not tile: branch below.)
         qkv = ops.gemm_nt(h1, p["qkv"].wb, bias=p["qkv"].b, rope=(rope[0], rope[1], L, D, 2 * H * D))
+        ctx, lse = ops.attn_fwd(qkv, B, L, H, D, key_mask=mask, rope=None, q_scale=D ** -0.5)
+        x2 = ops.gemm_nt(ctx, p["out"].wb, bias=p["out"].b, residual=x, out_dtype=torch.float32)
+        return _esm_layer_ffn_fwd(x, x2, p, eps, keep, (h1, m1, r1, qkv, ctx, lse))
+    if p["qkv"].il[1]:
+        # pair-interleaved q / k (see ROPE_INTERLEAVED): rotated in the projection's epilogue; attention as it is
+        il_hd, il_rows = p["qkv"].il
+        qkv = ops.gemm_nt(h1, p["qkv"].wb, bias=p["qkv_b_il"], rope=(rope[0], rope[1], L, D, il_rows), rope_interleaved=True)
         ctx, lse = ops.attn_fwd(qkv, B, L, H, D, key_mask=mask, rope=None, q_scale=D ** -0.5)
         x2 = ops.gemm_nt(ctx, p["out"].wb, bias=p["out"].b, residual=x, out_dtype=torch.float32)
         return _esm_layer_ffn_fwd(x, x2, p, eps, keep, (h1, m1, r1, qkv, ctx, lse))
@@ -250,9 +273,9 @@ def _esm_layer_bwd(dy, dyb, p, saved, meta, need_dx_bf16, need_dx_f32=True):
                                    prerotated=_varlen_prerot(meta))
     else:
         dqkv = ops.attn_bwd(qkv, ctx, dctx, lse, B, L, H, D, key_mask=mask, rope=rope, q_scale=D ** -0.5,
-                            prerotated=PREROTATE_QK and rope is not None)
+                            prerotated=2 if p["qkv"].il[1] else (PREROTATE_QK and rope is not None))
     dh1 = ops.gemm_nt(dqkv, p["qkv"].wtb)
-    gr["qkv_w"], gr["qkv_b"] = _wgrad(dqkv, h1, p["qkv"])
+    gr["qkv_w"], gr["qkv_b"] = _wgrad(dqkv, h1, p["qkv"], il=p["qkv"].il)
     want32 = need_dx_f32 or not lowp
     dx, dxb, gr["ln1_w"], gr["ln1_b"] = _ln_bwd(dh1, x, p["ln1_w"], p["ln1_b"], m1, r1, dx_add=dx2b if lowp else dx2,
                                                 want_f32=want32, want_bf16=need_dx_bf16 or lowp)
@@ -281,14 +304,22 @@ class EsmStackFn(torch.autograd.Function):
         need_bwd = any(ctx.needs_input_grad)        # frozen encoder (3_esm_integration.py:83-84): keep no activations
         if need_bwd:
             _bucket_begin(module)
+        # head dims the tiled RoPE epilogue cannot take (24: ESM-2-35M) get the pair-interleaved one (ROPE_INTERLEAVED)
+        use_il = (ROPE_INTERLEAVED and PREROTATE_QK and ROPE_IN_QKV_EPILOGUE and seq is None and D % 8 == 0
+                  and D not in (16, 32, 64) and d % 32 == 0)
+        il_idx = module.il_index(ids.device) if use_il else None
         for i in range(nl):
             t = flat[3 + 12 * i: 3 + 12 * (i + 1)]
             caches = module.layer_caches[i]
             gw, gb = module._qkv_grads[i] if len(getattr(module, "_qkv_grads", ())) == nl else (None, None)
             # the fused qkv view's own _version never moves: its bf16 copy is keyed on the three source Parameters
-            p = {"ln1_w": t[0], "ln1_b": t[1], "qkv": _Lin(t[2], t[3], caches[0], gw, gb, module.qkv_version_fn(i)),
+            p = {"ln1_w": t[0], "ln1_b": t[1],
+                 "qkv": _Lin(t[2], t[3], caches[0], gw, gb, module.qkv_version_fn(i),
+                             il_cache=module.layer_caches_il[i] if use_il else None),
                  "out": _Lin(t[4], t[5], caches[1]),
                  "ln2_w": t[6], "ln2_b": t[7], "fc1": _Lin(t[8], t[9], caches[2]), "fc2": _Lin(t[10], t[11], caches[3])}
+            if use_il:
+                p["qkv_b_il"] = t[3].detach().index_select(0, il_idx)   # the bias in the projection's column order
             x, s = _esm_layer_fwd(x, p, meta, keep=need_bwd)
             layers.append(p)
             saved.append(s if need_bwd else None)
@@ -410,6 +441,10 @@ class ESM2Encoder(nn.Module):
         self.embeddings = _EsmEmbeddings(vocab_size, hidden_size, pad_token_id)
         self.encoder = _EsmEncoderModules(num_layers, hidden_size, intermediate_size, layer_norm_eps)
         self.layer_caches = [[KF.WeightCache() for _ in range(4)] for _ in range(num_layers)]
+        hd = hidden_size // num_heads
+        # bf16 copies of the fused qkv weight with the q and k rows in pair-interleaved head order (ROPE_INTERLEAVED)
+        self.layer_caches_il = [KF.WeightCache(il=(hd, 2 * hidden_size)) for _ in range(num_layers)]
+        self._il_idx = {}
         self._rope = {}
         self._fused = None
         self._init(initializer_range)
@@ -435,6 +470,14 @@ class ESM2Encoder(nn.Module):
         if key not in self._rope:
             self._rope[key] = _rope_tables(L, self.hidden_size // self.num_heads, device)
         return self._rope[key]
+
+    def il_index(self, device):
+        """int64 [3 d]: the original output column each column of the pair-interleaved qkv projection holds."""
+        key = str(device)
+        if key not in self._il_idx:
+            self._il_idx[key] = ops.il_source_rows(3 * self.hidden_size, self.hidden_size // self.num_heads,
+                                                   2 * self.hidden_size).to(device)
+        return self._il_idx[key]
 
     def qkv_version_fn(self, i):
         s = self.encoder.layer[i].attention.self

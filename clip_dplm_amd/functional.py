@@ -65,9 +65,10 @@ def _batched_refresh_covers(c, w, require_cuda: bool = True) -> bool:
 class WeightCache:
     """bf16 W [N,K] and W^T [K,N] of an f32 master weight, refreshed lazily (or all at once, refresh_weight_caches)."""
 
-    __slots__ = ("wb", "wtb", "key", "src", "src_version", "derived", "__weakref__")
+    __slots__ = ("wb", "wtb", "key", "src", "src_version", "derived", "il", "__weakref__")
 
-    def __init__(self):
+    def __init__(self, il=(0, 0)):
+        self.il = (int(il[0]), int(il[1]))   # (head rows, rows): those rows of both copies in pair-interleaved head order
         self.wb = self.wtb = None
         self.key = None
         self.src = None                      # the master weight this cache was last built from
@@ -90,7 +91,8 @@ class WeightCache:
             if not src.is_contiguous():
                 src = src.contiguous()
             self.wb, self.wtb = ops.cast_transpose(src, w_out=self.wb if self.wb is not None and self.wb.shape == w.shape else None,
-                                                   wt_out=self.wtb if self.wtb is not None and self.wtb.shape == (w.shape[1], w.shape[0]) else None)
+                                                   wt_out=self.wtb if self.wtb is not None and self.wtb.shape == (w.shape[1], w.shape[0]) else None,
+                                                   il=self.il)
             self.key = key
             self.src = w
         return self.wb, self.wtb
@@ -125,7 +127,8 @@ def refresh_weight_caches() -> int:
     for item in todo:
         by_dev.setdefault(item[1].device, []).append(item)
     for dev, items in by_dev.items():
-        rows = tuple((w.data_ptr(), c.wb.data_ptr(), c.wtb.data_ptr(), w.shape[0], w.shape[1]) for c, w, _ in items)
+        rows = tuple((w.data_ptr(), c.wb.data_ptr(), c.wtb.data_ptr(), w.shape[0], w.shape[1], c.il[0] if c.il[1] else 2, c.il[1])
+                     for c, w, _ in items)
         desc = _BATCH_DESC.get((dev, rows))
         if desc is None:
             _BATCH_DESC.clear()              # pointers changed (new model / reallocated flat buffer)

@@ -133,13 +133,15 @@ def workspace(nbytes: int, device, tag: str = "ws") -> torch.Tensor:
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, act=None,
             out_dtype=torch.bfloat16, residual: Optional[torch.Tensor] = None, out_preact: bool = False,
             dact_aux: Optional[torch.Tensor] = None, dact=None, alpha: float = 1.0,
-            out: Optional[torch.Tensor] = None, dropout=None, rope=None, aux_u8: bool = False):
+            out: Optional[torch.Tensor] = None, dropout=None, rope=None, aux_u8: bool = False,
+            rope_interleaved: bool = False):
     """C = epilogue(a[M,K] @ b[N,K]^T) with a, b bf16.  Returns C (and the bf16 pre-activation if asked).
     aux_u8 (act = "gelu", out_preact): the second output is GELU'(pre-activation) as 8-bit codes (uint8 [M, N]) instead of
     the bf16 pre-activation; a uint8 `dact_aux` (dact = "gelu") is read as such codes (clipk.h aux_dtype).
     dropout = (p, seed): nn.Dropout on the value after the activation (before act'(aux) and the residual add).
     rope = (cos, sin, L, hd, cols): rotate-half RoPE (tables f32 [L, hd/2], position = row mod L) on the first `cols`
-    output columns in the epilogue (ESM-2's fused qkv projection: cols = 2 * hidden)."""
+    output columns in the epilogue (ESM-2's fused qkv projection: cols = 2 * hidden).  rope_interleaved: those columns'
+    heads are in pair-interleaved order (b's rows permuted by cast_transpose(il=...)): partners are neighbours, any hd % 8 == 0."""
     _need_cuda(a, b, bias, residual, dact_aux, *(rope[:2] if rope else ()))
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
     assert a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[1]
@@ -175,7 +177,9 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = Non
         assert cos.shape == (rl, hd // 2) and sin.shape == (rl, hd // 2)
         args.rope_cos, args.rope_sin = cos.data_ptr(), sin.data_ptr()
         args.rope_L, args.rope_hd, args.rope_cols, args.rope_row0 = int(rl), int(hd), int(cols), 0
+        args.rope_interleaved = int(bool(rope_interleaved))
     else:
+        args.rope_interleaved = 0
         args.rope_cos, args.rope_sin = None, None
         args.rope_L = args.rope_hd = args.rope_cols = args.rope_row0 = 0
     # algorithmic bytes: both operands once, every output / epilogue operand once
@@ -203,8 +207,9 @@ def gelu_aux_u8_applies(k_in: int, n_ffn: int) -> bool:
 
 
 def gemm_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: Optional[torch.Tensor] = None,
-               dbias: Optional[torch.Tensor] = None, accumulate: bool = False, want_bias: bool = False):
-    """dW[N,K] (+)= dy[M,N]^T @ x[M,K] (f32), optionally db[N] = colsum(dy)."""
+               dbias: Optional[torch.Tensor] = None, accumulate: bool = False, want_bias: bool = False, il=(0, 0)):
+    """dW[N,K] (+)= dy[M,N]^T @ x[M,K] (f32), optionally db[N] = colsum(dy).  il = (head columns, il_cols): dy's first
+    il_cols columns are in pair-interleaved head order; dW / db come out in the original order (clipk.h)."""
     _need_cuda(dy, x)
     assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
     M, N = dy.shape
@@ -219,8 +224,8 @@ def gemm_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: Optional[torch.Tensor] = N
     ws = workspace(nbytes, dy.device, "wgrad")
     check(_timed("gemm_wgrad", 2.0 * M * N * K,
                  lambda: lib.clipk_gemm_wgrad(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(),
-                                              dw.stride(0), ptr(dbias), M, N, K, int(accumulate), ws.data_ptr(),
-                                              ws.numel(), _stream())), "clipk_gemm_wgrad")
+                                              dw.stride(0), ptr(dbias), M, N, K, int(accumulate), int(il[0]), int(il[1]),
+                                              ws.data_ptr(), ws.numel(), _stream())), "clipk_gemm_wgrad")
     return dw, dbias
 
 
@@ -563,19 +568,30 @@ def to_f32(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
-def cast_transpose(w: torch.Tensor, want_w=True, want_wt=True, w_out=None, wt_out=None):
+def il_source_rows(n_rows: int, hd: int, il_rows: int) -> torch.Tensor:
+    """int64 [n_rows]: the ORIGINAL row each row of a pair-interleaved copy holds (csrc/common.h il_src): within every
+    head of `hd` rows of the first `il_rows` rows, copy row 2 j / 2 j + 1 = original row j / j + hd / 2."""
+    r = torch.arange(n_rows, dtype=torch.int64)
+    d = r % hd
+    src = (r - d) + (d // 2) + (d % 2) * (hd // 2)
+    return torch.where(r < il_rows, src, r)
+
+
+def cast_transpose(w: torch.Tensor, want_w=True, want_wt=True, w_out=None, wt_out=None, il=(0, 0)):
+    """il = (head rows, il_rows): the first il_rows rows of both copies in pair-interleaved head order (clipk.h)."""
     _need_cuda(w)
     rows, cols = w.shape
     wb = w_out if w_out is not None else (torch.empty((rows, cols), dtype=torch.bfloat16, device=w.device) if want_w else None)
     wt = wt_out if wt_out is not None else (torch.empty((cols, rows), dtype=torch.bfloat16, device=w.device) if want_wt else None)
-    check(_lib().clipk_cast_transpose(w.data_ptr(), ptr(wb), ptr(wt), rows, cols, _stream()), "clipk_cast_transpose")
+    check(_lib().clipk_cast_transpose(w.data_ptr(), ptr(wb), ptr(wt), rows, cols, int(il[0]), int(il[1]), _stream()),
+          "clipk_cast_transpose")
     return wb, wt
 
 
 def cast_transpose_batched(desc: torch.Tensor):
-    """desc: int64 [n, 5] device tensor of (w_ptr, wb_ptr, wt_ptr, rows, cols): all n weights in one launch."""
+    """desc: int64 [n, 7] device tensor of (w_ptr, wb_ptr, wt_ptr, rows, cols, il_hd, il_rows): all n weights in one launch."""
     _need_cuda(desc)
-    assert desc.dtype == torch.int64 and desc.dim() == 2 and desc.shape[1] == 5 and desc.is_contiguous()
+    assert desc.dtype == torch.int64 and desc.dim() == 2 and desc.shape[1] == 7 and desc.is_contiguous()
     check(_lib().clipk_cast_transpose_batched(desc.data_ptr(), desc.shape[0], _stream()), "clipk_cast_transpose_batched")
 
 
@@ -656,7 +672,7 @@ def attn_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=None, rope=None, q_scale=
     check(_timed("attn_bwd", 10.0 * B * H * L * L * D,
                  lambda: _lib().clipk_attn_bwd(qkv.data_ptr(), ptr(key_mask), ptr(cos), ptr(sin), out.data_ptr(),
                                                dout.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), B, L,
-                                               H, D, float(q_scale), int(bool(prerotated)), *_drop(dropout),
+                                               H, D, float(q_scale), int(prerotated), *_drop(dropout),
                                                _stream())), "clipk_attn_bwd")
     return dqkv
 

@@ -97,6 +97,13 @@ typedef struct clipk_gemm_args {
    * (modeling_esm.py:517-521; run1/configuration_hybrid_clip.py:75 hidden_act), nothing but the backward's GELU' factor
    * is affected.  CLIPK_BF16 (0): the pre-activation itself, as before. */
   int aux_dtype;
+  /* rope_interleaved != 0 (with rope_cos / rope_sin / rope_L / rope_hd / rope_cols): the heads of the first rope_cols output
+   * columns are in PAIR-INTERLEAVED order - columns 2 j and 2 j + 1 of a head hold what rotate-half calls x[j] and
+   * x[j + hd/2] (the B operand's rows were permuted accordingly: clipk_cast_transpose il_hd / il_rows) - and are rotated as
+   * neighbours: out[2j] = x1 cos[pos, j] - x2 sin[pos, j], out[2j+1] = x2 cos[pos, j] + x1 sin[pos, j].  Any rope_hd % 8 == 0
+   * (ESM-2-35M's 24, which does not tile the kernels' 64-column slices).  q . k does not depend on a common order of the head
+   * dim, so attention runs on such q / k as it is (clipk_attn_fwd without tables; clipk_attn_bwd with prerotated = 2). */
+  int rope_interleaved;
 } clipk_gemm_args;
 int clipk_gemm_nt(const clipk_gemm_args* args, void* stream);
 
@@ -106,9 +113,12 @@ int clipk_gemm_nt(const clipk_gemm_args* args, void* stream);
  * when dbias != NULL.  accumulate != 0 adds into dW/dbias instead of overwriting.
  * Requirements: N % 8 == 0, K % 8 == 0. */
 size_t clipk_gemm_wgrad_workspace(int M, int N, int K);
+/* il_rows > 0: dY's first il_rows columns are in pair-interleaved head order (heads of il_hd columns: clipk_gemm_nt
+ * rope_interleaved, clipk_attn_bwd prerotated = 2); their gradient rows are written to the rows of dW / entries of dbias of
+ * the ORIGINAL order, so the master weights and their gradients never see the permutation. */
 int clipk_gemm_wgrad(const void* dY, int64_t lddy, const void* X, int64_t ldx,
                      float* dW, int64_t lddw, float* dbias,
-                     int M, int N, int K, int accumulate,
+                     int M, int N, int K, int accumulate, int il_hd, int il_rows,
                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -278,11 +288,14 @@ int clipk_l2norm_bwd(const float* dy, const float* y, const float* norm, float* 
 /* Elementwise helpers on f32/bf16 buffers (n elements, n % 8 == 0 not required). */
 int clipk_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 int clipk_cast_bf16_to_f32(const void* x, float* y, int64_t n, void* stream);
-/* W f32 [rows,cols] -> bf16 copy and bf16 transposed copy [cols,rows] (either may be NULL). */
-int clipk_cast_transpose(const float* w, void* w_bf16, void* wt_bf16, int rows, int cols, void* stream);
+/* W f32 [rows,cols] -> bf16 copy and bf16 transposed copy [cols,rows] (either may be NULL).
+ * il_rows > 0: rows [0, il_rows) of both copies are written in PAIR-INTERLEAVED head order for heads of il_hd rows - copy
+ * row 2 j (+1) of a head holds W row j (+ il_hd / 2) of that head - the order in which clipk_gemm_nt's interleaved RoPE
+ * epilogue (rope_interleaved) expects the q and k sections of ESM-2's fused qkv projection (modeling_esm.py:362-374). */
+int clipk_cast_transpose(const float* w, void* w_bf16, void* wt_bf16, int rows, int cols, int il_hd, int il_rows, void* stream);
 /* The same for n weights in one launch (what `optimizer.step()` leaves to do before the next forward: the reference
  * re-reads its f32 nn.Linear weights under autocast every step, old/clip.py:11).  desc_dev: device array of n
- * records {w, w_bf16, wt_bf16, rows, cols}, five int64 each (pointers as integers, either output may be 0). */
+ * records {w, w_bf16, wt_bf16, rows, cols, il_hd, il_rows}, seven int64 each (pointers as integers, either output may be 0). */
 int clipk_cast_transpose_batched(const void* desc_dev, int n, void* stream);
 /* y = act(x) / dx = dy * act'(x) on f32. */
 int clipk_act_fwd(const float* x, float* y, int act, int64_t n, void* stream);
@@ -307,7 +320,10 @@ int clipk_attn_fwd(const void* qkv, const uint8_t* key_mask, const float* rope_c
                    void* out, float* lse, int B, int L, int H, int D, float q_scale, float dropout_p,
                    uint32_t dropout_seed, void* stream);
 /* Backward: dqkv bf16 [B*L, 3*H*D] from dout bf16 [B*L, H*D]; recomputes P from qkv + lse.
- * delta: f32 [B,H,L] scratch (rowsum(dout*out)) provided by the caller. */
+ * delta: f32 [B,H,L] scratch (rowsum(dout*out)) provided by the caller.
+ * prerotated: 0 = q / k in qkv are un-rotated (the kernels rotate at staging when given tables); 1 = already rotated
+ * (clipk_rope_qk / clipk_attn_fwd_rot / clipk_gemm_nt's RoPE epilogue), rotate-half column order; 2 = already rotated, heads in
+ * PAIR-INTERLEAVED column order (clipk_gemm_nt rope_interleaved): the gradients leave through the matching RoPE^T. */
 int clipk_attn_bwd(const void* qkv, const uint8_t* key_mask, const float* rope_cos, const float* rope_sin,
                    const void* out, const void* dout, const float* lse, float* delta, void* dqkv,
                    int B, int L, int H, int D, float q_scale, int prerotated, float dropout_p, uint32_t dropout_seed,

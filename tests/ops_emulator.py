@@ -67,7 +67,7 @@ def gelu_grad_code(x):
 
 
 def gemm_nt(a, b, bias=None, act=None, out_dtype=BF, residual=None, out_preact=False, dact_aux=None, dact=None,
-            alpha=1.0, out=None, dropout=None, rope=None, aux_u8=False):
+            alpha=1.0, out=None, dropout=None, rope=None, aux_u8=False, rope_interleaved=False):
     aux8 = bool(aux_u8 and out_preact) or (dact_aux is not None and dact_aux.dtype == torch.uint8)
     if aux8 and (a.shape[1] % 32 or b.shape[0] % 8):      # as the kernels: generic-K GEMM has no 8-bit aux (gemm_nt.hip)
         raise RuntimeError("clipk_gemm_nt failed: unsupported shape for the gfx950 kernels (emulated: u8 aux needs "
@@ -75,7 +75,15 @@ def gemm_nt(a, b, bias=None, act=None, out_dtype=BF, residual=None, out_preact=F
     v = (a.float() @ b.float().t()) * alpha
     if bias is not None:
         v = v + bias
-    if rope is not None:                                  # rotate-half on the first `cols` columns, heads of hd columns
+    if rope is not None and rope_interleaved:              # neighbouring pairs (2 j, 2 j + 1) share angle j
+        cos, sin, L, hd, cols = rope
+        M_ = v.shape[0]
+        pos = torch.arange(M_) % L
+        x = v[:, :cols].reshape(M_, cols // hd, hd // 2, 2)
+        c, s_ = cos[pos][:, None, :], sin[pos][:, None, :]
+        y = torch.stack([x[..., 0] * c - x[..., 1] * s_, x[..., 1] * c + x[..., 0] * s_], -1)
+        v = torch.cat([y.reshape(M_, cols), v[:, cols:]], 1)
+    elif rope is not None:                                # rotate-half on the first `cols` columns, heads of hd columns
         cos, sin, L, hd, cols = rope
         M_ = v.shape[0]
         pos = torch.arange(M_) % L
@@ -106,9 +114,14 @@ def gelu_aux_u8_applies(k_in, n_ffn):
     return k_in % 32 == 0 and n_ffn % 8 == 0
 
 
-def gemm_wgrad(dy, x, dw=None, dbias=None, accumulate=False, want_bias=False):
+def gemm_wgrad(dy, x, dw=None, dbias=None, accumulate=False, want_bias=False, il=(0, 0)):
     g = dy.float().t() @ x.float()
     b = dy.float().sum(0)
+    if il[1]:                                              # rows of the permuted order -> rows of the original order
+        src = il_source_rows(g.shape[0], il[0], il[1])
+        g2, b2 = torch.empty_like(g), torch.empty_like(b)
+        g2[src], b2[src] = g, b
+        g, b = g2, b2
     if dw is None:
         dw = g
     else:
@@ -327,7 +340,15 @@ def to_f32(x):
     return x.float()
 
 
-def cast_transpose(w, want_w=True, want_wt=True, w_out=None, wt_out=None):
+def il_source_rows(n_rows, hd, il_rows):
+    r = torch.arange(n_rows, dtype=torch.int64)
+    d = r % hd
+    return torch.where(r < il_rows, (r - d) + (d // 2) + (d % 2) * (hd // 2), r)
+
+
+def cast_transpose(w, want_w=True, want_wt=True, w_out=None, wt_out=None, il=(0, 0)):
+    if il[1]:
+        w = w[il_source_rows(w.shape[0], il[0], il[1])]
     wb = w.to(BF)
     return wb, wb.t().contiguous()
 
@@ -379,6 +400,16 @@ def attn_fwd(qkv, B, L, H, D, key_mask=None, rope=None, q_scale=1.0, dropout=Non
     return o.to(BF), lse
 
 
+def _rope_qk_il(x, B, L, H, D, rope):
+    """as _rope_qk for heads in pair-interleaved column order: columns 2 j, 2 j + 1 are a pair with angle j"""
+    cos, sin = rope
+    v = x.view(B, L, 3, H, D // 2, 2)
+    c, s_ = cos[None, :, None, None, :], sin[None, :, None, None, :]
+    qk = v[:, :, :2]
+    y = torch.stack([qk[..., 0] * c - qk[..., 1] * s_, qk[..., 1] * c + qk[..., 0] * s_], -1)
+    return torch.cat([y, v[:, :, 2:]], 2).reshape(B * L, 3 * H * D)
+
+
 def _rope_qk(x, B, L, H, D, rope):
     """rotate the q and k sections of x [B*L, 3*H*D] (f32 math)"""
     cos, sin = rope
@@ -411,7 +442,8 @@ def attn_bwd(qkv, out, dout, lse, B, L, H, D, key_mask=None, rope=None, q_scale=
             o, _ = _attn_math(q, B, L, H, D, key_mask, None, q_scale)
             g_rot, = torch.autograd.grad(o, q, dout.float())
             z = torch.zeros_like(q).requires_grad_(True)
-            g, = torch.autograd.grad(_rope_qk(z, B, L, H, D, rope), z, g_rot)
+            rot = _rope_qk_il if int(prerotated) == 2 else _rope_qk       # 2: pair-interleaved head order (clipk.h)
+            g, = torch.autograd.grad(rot(z, B, L, H, D, rope), z, g_rot)
         else:
             o, _ = _attn_math(q, B, L, H, D, key_mask, rope, q_scale, dropout, row0, Lstride)
             g, = torch.autograd.grad(o, q, dout.float())

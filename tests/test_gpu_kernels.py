@@ -180,13 +180,19 @@ def test_cast_transpose_batched(dev):
     ops = _ops()
     shapes = [(480, 480), (1440, 480), (100, 72), (8, 1920), (513, 65)]
     ws = [_rand(sh, dev, 40 + i) for i, sh in enumerate(shapes)]
-    ref = [ops.cast_transpose(w) for w in ws]
+    ils = [(0, 0), (24, 960), (0, 0), (0, 0), (0, 0)]             # the fused qkv weight: q and k sections pair-interleaved
+    ref = [ops.cast_transpose(w, il=il) for w, il in zip(ws, ils)]
     outs = [(torch.zeros_like(a), torch.zeros_like(b)) for a, b in ref]
-    desc = torch.tensor([(w.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), w.shape[0], w.shape[1])
-                         for w, o in zip(ws, outs)], dtype=torch.int64).to(dev)
+    desc = torch.tensor([(w.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), w.shape[0], w.shape[1], il[0] or 2, il[1])
+                         for w, o, il in zip(ws, outs, ils)], dtype=torch.int64).to(dev)
     ops.cast_transpose_batched(desc)
     for (a, b), (oa, ob) in zip(ref, outs):
         assert torch.equal(a, oa) and torch.equal(b, ob)
+    # pair-interleaved head order: copy row 2 j / 2 j + 1 of a head = original row j / j + 12
+    src = ops.il_source_rows(1440, 24, 960).to(dev)
+    assert src[:6].tolist() == [0, 12, 1, 13, 2, 14] and src[24:28].tolist() == [24, 36, 25, 37] and src[960] == 960
+    assert torch.equal(ref[1][0], ws[1][src].to(torch.bfloat16))
+    assert torch.equal(ref[1][1], ws[1][src].t().contiguous().to(torch.bfloat16))
 
 
 def test_weight_cache_batched_refresh(dev):
@@ -1160,3 +1166,83 @@ def test_gelu_grad_code_grid_has_zero_and_one_as_code_points(dev, kopt, kernel):
     d = ops.gemm_nt(x, b, dact_aux=q, dact="gelu").float()
     assert torch.equal(d[:, N // 2:], ref[:, N // 2:])                                      # x 1.0 exactly
     assert d[:, : N // 2].abs().max().item() <= 4e-9 * ref.abs().max().item()              # x 1.9e-9
+
+
+# ------------------------------------------------------------------------------------------------ pair-interleaved RoPE
+def _il_perm(n, hd, il_rows, dev):
+    from clip_dplm_amd import ops
+    return ops.il_source_rows(n, hd, il_rows).to(dev)
+
+
+@pytest.mark.parametrize("kernel,M", [("v2", 1000), ("v3", 2048 + 24), ("v4", 2048 + 24)])
+@pytest.mark.parametrize("H,D", [(20, 24), (4, 24), (3, 64), (5, 40), (6, 16)])
+def test_gemm_nt_rope_interleaved_epilogue(dev, kopt, kernel, M, H, D):
+    """clipk_gemm_nt with rope_interleaved (EPI_ROPE_IL): the fused qkv projection computed with pair-interleaved q / k rows
+    (cast_transpose il) and rotated as neighbouring pairs in the epilogue, for head dims the tiled RoPE epilogue cannot take
+    (24, 40) and those it can: against the f32 rotate-half rotation of the plain projection, column for column (undoing the
+    permutation), within one bf16 rounding; v section = the plain epilogue's bits."""
+    ops = _ops()
+    kopt("gemm_kernel", _GEMM_KERNEL[kernel])
+    d, L = H * D, 100
+    K = 96 if d % 32 else d
+    a = _rand((M, K), dev, 101, dtype=torch.bfloat16)
+    w = _rand((3 * d, K), dev, 102, 0.2)
+    bias = _rand((3 * d,), dev, 103)
+    cos, sin = _rope_tables(L, D, dev)
+    src = _il_perm(3 * d, D, 2 * d, dev)
+    wb_il, _ = ops.cast_transpose(w, il=(D, 2 * d))
+    out = ops.gemm_nt(a, wb_il, bias=bias[src].contiguous(), rope=(cos, sin, L, D, 2 * d), rope_interleaved=True)
+    # reference: plain product in the ORIGINAL column order, rotate-half in f32
+    pre = a.float() @ w.to(torch.bfloat16).float().t() + bias
+    pos = torch.arange(M, device=dev) % L
+    c = torch.cat([cos[pos], cos[pos]], -1)[:, None, :]
+    s_ = torch.cat([sin[pos], sin[pos]], -1)[:, None, :]
+    x = pre[:, : 2 * d].reshape(M, 2 * H, D)
+    rot = torch.cat([-x[..., D // 2:], x[..., : D // 2]], -1)
+    ref = torch.cat([(x * c + rot * s_).reshape(M, 2 * d), pre[:, 2 * d:]], 1)
+    got = torch.empty_like(ref)
+    got[:, src] = out.float()                                 # permuted column j holds original column src[j]
+    err = (got - ref).abs()
+    assert (err <= 2.0 ** -8 * ref.abs() + 2e-3).all(), float(err.max())
+    plain = ops.gemm_nt(a, wb_il, bias=bias[src].contiguous())
+    assert torch.equal(out[:, 2 * d:], plain[:, 2 * d:])
+
+
+@pytest.mark.parametrize("B,L,H,D", [(8, 256, 20, 24), (3, 190, 4, 24), (2, 100, 4, 24), (2, 300, 2, 24)])
+def test_attention_bwd_interleaved_rope_equals_rotate_half(dev, B, L, H, D):
+    """clipk_attn_bwd(prerotated = 2): q / k rotated and laid out in pair-interleaved head order give the gradients of the
+    rotate-half layout, column for column (q . k does not depend on a common order of the head dim; RoPE^T knows the order)
+    - whole-head fused kernel (128 < L <= 256) and the general dQ / dK-dV pair."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(7)
+    qkv = (torch.randn(B * L, 3 * H * D, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    dout = (torch.randn(B * L, H * D, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    cos, sin = _rope_tables(L, D, dev)
+    std = ops.rope_qk_(qkv.clone(), B, L, H, D, (cos, sin))              # rotated, rotate-half column order
+    src = _il_perm(3 * H * D, D, 2 * H * D, dev)
+    il = std[:, src].contiguous()                                         # the same values, pair-interleaved
+    o1, lse1 = ops.attn_fwd(std, B, L, H, D, rope=None, q_scale=D ** -0.5)
+    o2, lse2 = ops.attn_fwd(il, B, L, H, D, rope=None, q_scale=D ** -0.5)
+    assert (o1.float() - o2.float()).abs().max().item() < 2e-2 and (lse1 - lse2).abs().max().item() < 1e-4
+    d1 = ops.attn_bwd(std, o1, dout, lse1, B, L, H, D, rope=(cos, sin), q_scale=D ** -0.5, prerotated=1)
+    d2 = ops.attn_bwd(il, o2, dout, lse2, B, L, H, D, rope=(cos, sin), q_scale=D ** -0.5, prerotated=2)
+    a, b = d1.float(), torch.empty_like(d1.float())
+    b[:, src] = d2.float()
+    assert (a - b).abs().max().item() <= 2e-2 * max(1.0, a.abs().max().item())
+    assert torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item() > 0.9999
+
+
+@pytest.mark.parametrize("M,N,K,hd,ilr", [(4096, 1440, 480, 24, 960), (20000, 1440, 480, 24, 960), (3000, 288, 96, 24, 192)])
+def test_gemm_wgrad_interleaved_rows_land_in_the_original_order(dev, M, N, K, hd, ilr):
+    """clipk_gemm_wgrad with (il_hd, il_rows): dY's leading columns are in pair-interleaved head order; dW rows and dbias
+    entries are written (and accumulated) in the ORIGINAL order - bit-identical to the plain call on the un-permuted dY."""
+    ops = _ops()
+    dy = _rand((M, N), dev, 111, dtype=torch.bfloat16)
+    x = _rand((M, K), dev, 112, dtype=torch.bfloat16)
+    src = _il_perm(N, hd, ilr, dev)
+    dw0, db0 = ops.gemm_wgrad(dy, x, want_bias=True)
+    dw1, db1 = ops.gemm_wgrad(dy[:, src].contiguous(), x, want_bias=True, il=(hd, ilr))
+    assert torch.equal(dw0, dw1) and torch.equal(db0, db1)
+    acc_w, acc_b = torch.ones_like(dw0), torch.ones_like(db0)
+    ops.gemm_wgrad(dy[:, src].contiguous(), x, dw=acc_w, dbias=acc_b, accumulate=True, il=(hd, ilr))
+    assert torch.equal(acc_w, dw0 + 1.0) and torch.equal(acc_b, db0 + 1.0)

@@ -820,14 +820,20 @@ def _ragged_batch(B, L, seed, dim):
     return rna, ids, rmask, pmask
 
 
-def test_packed_varlen_path_equals_padded_path(dev):
+@pytest.mark.parametrize("interleaved", [False, True])
+def test_packed_varlen_path_equals_padded_path(dev, interleaved, monkeypatch):
     """the packed variable-length path (no padded row reaches any kernel: cu_seqlens attention, packed
     Linear / LayerNorm / pooling) against the padded path with key-padding masks on the same ragged batch: loss and
-    every parameter gradient.  Same kernels and the same per-row arithmetic, so the agreement is far inside the bf16
-    level (only GEMM tile membership of a row and the split-M order of the weight-gradient sums differ)."""
+    every parameter gradient.  interleaved = False: both paths rotate q / k in place (the packed path always does: the
+    epilogue's position is a row index modulo L) - same kernels and the same per-row arithmetic, so the agreement is far
+    inside the bf16 level (only GEMM tile membership of a row and the split-M order of the weight-gradient sums differ).
+    interleaved = True (the padded path's default): RoPE in the qkv projection's epilogue on the f32 value, one bf16 rounding
+    instead of two - the two paths then differ by that rounding (bound 1e-3)."""
     import clip_dplm_amd as K
+    import clip_dplm_amd.encoders as enc
     from clip_dplm_amd.data import unpad
     from clip_dplm_amd.encoders import ESM2_SHAPES
+    monkeypatch.setattr(enc, "ROPE_INTERLEAVED", interleaved)
     ESM2_SHAPES["test_packed"] = (2, 96, 4, 384)
     torch.manual_seed(0)
     m = K.ProteinRNACLIP(esm="test_packed", rna_dim=64, rna_layers=2, rna_heads=8, rna_ffn=128, projection_dim=64).eval()
@@ -842,7 +848,7 @@ def test_packed_varlen_path_equals_padded_path(dev):
     assert rp.shape[0] == int(rmask.sum()) and ip.shape[0] == int(pmask.sum())
     loss_pk = m.loss_packed(rp.to(dev), rcu.to(dev), rmax, ip.to(dev), icu.to(dev), imax)
     loss_pk.backward()
-    assert abs(loss_pad.item() - loss_pk.item()) < 2e-4, (loss_pad.item(), loss_pk.item())
+    assert abs(loss_pad.item() - loss_pk.item()) < (1e-3 if interleaved else 2e-4), (loss_pad.item(), loss_pk.item())
     for n, p in m.named_parameters():
         if p.grad is None:
             continue
@@ -850,7 +856,7 @@ def test_packed_varlen_path_equals_padded_path(dev):
         if b.abs().max() < 1e-10:
             continue
         cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
-        assert cos > 0.999, (n, cos)
+        assert cos > (0.995 if interleaved else 0.999), (n, cos)
 
 
 @pytest.mark.parametrize("precision", ["bf16", "f32"])

@@ -35,7 +35,8 @@ CASES = [
     ("trimodal_bf16", T.test_trimodal_contrastive_model_golden, {"precision": "bf16"}),
     ("trimodal_slice", T.test_trimodal_position0_slice_is_exact, {}),
     ("trimodal_loss", T.test_trimodal_loss_pairs_kernels_vs_f64, {}),
-    ("packed_varlen", T.test_packed_varlen_path_equals_padded_path, {}),
+    ("packed_varlen", T.test_packed_varlen_path_equals_padded_path, {"interleaved": False, "monkeypatch": None}),
+    ("packed_varlen_il", T.test_packed_varlen_path_equals_padded_path, {"interleaved": True, "monkeypatch": None}),
     ("dropout_layer_bf16", T.test_dropout_layer_vs_masked_oracle, {"precision": "bf16"}),
     ("dropout_layer_f32", T.test_dropout_layer_vs_masked_oracle, {"precision": "f32"}),
     ("clip_opt_b128", T.test_clip_opt_b128_golden_loss_at_the_north_star_bar, {}),
@@ -50,4 +51,6 @@ CASES = [
 @pytest.mark.parametrize("name,fn,kw", CASES, ids=[c[0] for c in CASES])
 def test_emulated(monkeypatch, name, fn, kw):
     ops_emulator.install(monkeypatch)
+    if "monkeypatch" in kw:
+        kw = dict(kw, monkeypatch=monkeypatch)
     fn(torch.device("cpu"), **kw)
