@@ -39,6 +39,9 @@ tools/probes/libgemm_trace32.so: clip_dplm_amd/csrc/gemm_nt_v3.hip clip_dplm_amd
 # experiment build of the attention kernels with phase stamps in the whole-head backward (tools/exp_attn_trace.py)
 tools/probes/libattn_trace.so: clip_dplm_amd/csrc/attention.hip clip_dplm_amd/csrc/core.hip clip_dplm_amd/csrc/common.h
 	$(HIPCC) $(HIPFLAGS) -DCLIPK_ATTN_TRACE -shared -o $@ clip_dplm_amd/csrc/attention.hip clip_dplm_amd/csrc/core.hip
+# timing-only build: q / k / v / dO of the whole-head kernels addressed head-major (tools/exp_attn_headmajor.py)
+tools/probes/libattn_hm.so: clip_dplm_amd/csrc/attention.hip clip_dplm_amd/csrc/core.hip clip_dplm_amd/csrc/common.h
+	$(HIPCC) $(HIPFLAGS) -DCLIPK_ATTN_HM_PROBE -shared -o $@ clip_dplm_amd/csrc/attention.hip clip_dplm_amd/csrc/core.hip
 # experiment build of the whole library (timing ablations behind option gemm_abl; results garbage):
 #   BENCH_LIB=tools/probes/libclipk_exp.so BENCH_ABL="1 4" python3 tools/bench_kernels.py gemm
 tools/probes/libclipk_exp.so: $(SRC) $(wildcard clip_dplm_amd/csrc/*.h) include/clipk.h

@@ -1071,6 +1071,24 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
     // no branch around the loads (a lane whose chunk is the zero pad re-reads the last real chunk and drops it at
     // staging time): loads under a divergent branch make every later s_waitcnt assume they may not have been issued
     const unsigned int cc = 8u * (ci < cpr ? ci : cpr - 1);
+#ifdef CLIPK_ATTN_HM_PROBE
+    // TIMING-ONLY experiment (tools/exp_attn_headmajor.py): q, k, v and dO addressed as if they were stored head-major
+    // ([B][H][3][L][D] / [B][H][L][D]: a head's rows contiguous).  The bytes read are not the head's: results garbage.
+    const unsigned short* qh = p.qkv + (long)(b_ * H + h_) * 3 * p.L * D;
+    const unsigned short* dh = p.dout + (long)(b_ * H + h_) * p.L * D;
+    const unsigned int LD = (unsigned int)(p.L * D);
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+      int row = ps * (NT / 4) + r0; row = row < L ? row : L - 1;
+      const unsigned int ho = (unsigned int)row * D + cc, oo = (unsigned int)row * HD + cc;
+      R.q[ps] = *reinterpret_cast<const u32x4*>(qh + ho);
+      R.k[ps] = *reinterpret_cast<const u32x4*>(qh + (ho + LD));
+      R.v[ps] = *reinterpret_cast<const u32x4*>(qh + (ho + 2u * LD));
+      R.d[ps] = *reinterpret_cast<const u32x4*>(dh + ho);
+      R.o[ps] = *reinterpret_cast<const u32x4*>(ob + oo);
+    }
+    (void)qb; (void)dob;
+#else
 #pragma unroll
     for (int ps = 0; ps < NPS; ++ps) {
       int row = ps * (NT / 4) + r0; row = row < L ? row : L - 1;
@@ -1081,6 +1099,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_bwd_fused32_ker
       R.d[ps] = *reinterpret_cast<const u32x4*>(dob + oo);
       R.o[ps] = *reinterpret_cast<const u32x4*>(ob + oo);
     }
+#endif
     R.lse = p.lse[stat_at(p, b_, h_, H, L, row0_, t < L ? t : L - 1)];
     const int lane_ = t & 63, wid_ = t >> 6;
 #pragma unroll
@@ -2067,6 +2086,17 @@ __global__ __launch_bounds__(256, ROT ? 3 : 4) void attn_fwd_whole32_kernel(cons
     const unsigned int HD = (unsigned int)(H * D), cc = 8u * (ci < cpr ? ci : cpr - 1);
     const unsigned short* qb = p.qkv + row0 * 3 * (long)HD + (long)h * D;
     u32x4 ck[4], cv[4];
+#ifdef CLIPK_ATTN_HM_PROBE
+    const unsigned short* qhm = p.qkv + (long)(b * H + h) * 3 * p.L * D;      // timing only, see attn_bwd_fused32_kernel
+    const unsigned int LDm = (unsigned int)(p.L * D);
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      int row = ps * 64 + r0; row = row < L ? row : L - 1;
+      const unsigned int ho = (unsigned int)row * D + cc;
+      if (!ROT) ck[ps] = *reinterpret_cast<const u32x4*>(qhm + (ho + LDm));
+      cv[ps] = *reinterpret_cast<const u32x4*>(qhm + (ho + 2u * LDm));
+    }
+#else
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
       int row = ps * 64 + r0; row = row < L ? row : L - 1;
@@ -2074,6 +2104,7 @@ __global__ __launch_bounds__(256, ROT ? 3 : 4) void attn_fwd_whole32_kernel(cons
       if (!ROT) ck[ps] = *reinterpret_cast<const u32x4*>(qb + (qo + HD));
       cv[ps] = *reinterpret_cast<const u32x4*>(qb + (qo + 2u * HD));
     }
+#endif
     RowRegs<4> rk, rq;                                     // ROT: thread t owns row t of K and of Q
     const int pc = tid < L ? tid : L - 1;
     if (ROT) {
@@ -2086,6 +2117,10 @@ __global__ __launch_bounds__(256, ROT ? 3 : 4) void attn_fwd_whole32_kernel(cons
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
           int row = qh * 128 + wid * 32 + qt * 16 + li; row = row < L ? row : L - 1;
+#ifdef CLIPK_ATTN_HM_PROBE
+          if (!ROT) qfr[qh][qt] = *reinterpret_cast<const u32x4*>(qhm + ((unsigned int)row * D + 8u * (g < cpr ? g : cpr - 1)));
+          else
+#endif
           qfr[qh][qt] = *reinterpret_cast<const u32x4*>(qb + ((unsigned int)row * 3u * HD + 8u * (g < cpr ? g : cpr - 1)));
         }
     }

@@ -4,9 +4,10 @@ RNA heads 8 x 96) a few times, for rocprofv3 --pmc / --stats passes (tools/pmc_a
 
     python3 tools/prof_attn.py [B] [launches]
 
-The kernels are exactly the ones the training step launches: `clipk_attn_fwd_rot` (whole-head forward that rotates q / k
-in place) + whole-head fused backward on pre-rotated rows for the ESM shape; general forward + dQ / dK-dV pair for
-the RNA shape."""
+The kernels are exactly the ones the training step launches (round 4): whole-head forward on q / k the qkv projection's
+epilogue already rotated (pair-interleaved heads) + whole-head fused backward with the interleaved RoPE^T for the ESM
+shape; general forward + eight-wave whole-head backward for the RNA shape.  PROF_ATTN_ROT=1: the round-3 pair
+(`clipk_attn_fwd_rot`, rotate-half backward) instead."""
 import os
 import sys
 
@@ -34,12 +35,19 @@ r = rope_tables(D)
 qkv0 = rnd((B * L, 3 * H * D))
 dout = rnd((B * L, H * D))
 qkv = qkv0.clone()
-out, lse = ops.attn_fwd_rot_(qkv, B, L, H, D, r, q_scale=D ** -0.5)
+ROT = os.environ.get("PROF_ATTN_ROT") == "1"
+if ROT:
+    out, lse = ops.attn_fwd_rot_(qkv, B, L, H, D, r, q_scale=D ** -0.5)
+else:
+    out, lse = ops.attn_fwd(qkv, B, L, H, D, rope=None, q_scale=D ** -0.5)
 for _ in range(N):
     q2 = qkv0.clone()
-    ops.attn_fwd_rot_(q2, B, L, H, D, r, q_scale=D ** -0.5)
+    if ROT:
+        ops.attn_fwd_rot_(q2, B, L, H, D, r, q_scale=D ** -0.5)
+    else:
+        ops.attn_fwd(q2, B, L, H, D, rope=None, q_scale=D ** -0.5)
 for _ in range(N):
-    ops.attn_bwd(qkv, out, dout, lse, B, L, H, D, rope=r, q_scale=D ** -0.5, prerotated=True)
+    ops.attn_bwd(qkv, out, dout, lse, B, L, H, D, rope=r, q_scale=D ** -0.5, prerotated=True if ROT else 2)
 torch.cuda.synchronize()
 del qkv0, qkv, out, lse, dout, q2
 
