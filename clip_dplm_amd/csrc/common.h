@@ -5,7 +5,7 @@
 #include <stdint.h>
 #include "../../include/clipk.h"
 
-#define CLIPK_ABI_VERSION 5
+#define CLIPK_ABI_VERSION 6
 #define WAVE 64
 
 // Kernel-selection options (core.hip): set explicitly through clipk_set_option(), never read from the environment.

@@ -361,6 +361,77 @@ int launch_skinny(const GP& p, hipStream_t st) {
   return clipk_check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Parameter gradients of an exact-f32 Linear whose input has FEW rows (M <= 64: the position-0 models, M = batch = 32):
+//   dW[N, K] (+)= dY[M, N]^T X[M, K]        db[N] (+)= sum over rows of dY
+// Such a product is ONE PASS OVER dW - 2 M FLOP per 4 (8 when accumulating) bytes of dW - and the tiled kernel above gave
+// every 64 x 64 tile a staging round through LDS, two barriers and a two-step main loop: 16 us for 6.5 - 26 MB, plus a
+// column-reduce launch for db (53 + 52 launches per step of the notebook model).  Here a wave owns a 32 x 32 block of dW:
+// each lane loads its dY / X values straight into the f32 MFMA's operand registers (for one m: 32 lanes = 128 contiguous
+// bytes of the row), ceil(M / 2) MFMAs, read-add-write of 128-byte row segments.  No LDS, no barrier; every load of a wave
+// is in flight before its first MFMA.  The waves of column block 0 also sum their dY operands: db comes out of the same
+// launch.  Contraction order = the tiled kernel's (m = 16 ks + 8 j + 4 h + e, steps (ks, j, e) ascending): dW is
+// bit-identical to clipk_gemm_f32(transA, transB) on the same operands.
+struct WGP {
+  const float* dY; long lddy; const float* X; long ldx;
+  float* dW; long lddw; float* db;
+  int M, N, K, accumulate;
+};
+
+template <int MT>                                            // MT = ceil(M / 32): 16 MT MFMAs per block
+__global__ __launch_bounds__(256) void wgrad_f32_small_kernel(const WGP p) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.y * 32, k0 = (blockIdx.x * 4 + wid) * 32;
+  if (k0 >= p.K) return;                                      // (wave-uniform; no barrier in this kernel)
+  const int gn = n0 + li, gk = k0 + li;
+  const bool n_ok = gn < p.N, k_ok = gk < p.K;
+  // clamped addresses + masks instead of branches around the loads: every load is issued before the first wait
+  const float* ap = p.dY + (n_ok ? gn : 0);
+  const float* bp = p.X + (k_ok ? gk : 0);
+  float a[16 * MT], b[16 * MT];
+#pragma unroll
+  for (int s = 0; s < 16 * MT; ++s) {
+    const int m = (s >> 3) * 16 + ((s >> 2) & 1) * 8 + (s & 3) + 4 * h;
+    const int mc = m < p.M ? m : 0;
+    a[s] = ap[(long)mc * p.lddy];
+    b[s] = bp[(long)mc * p.ldx];
+  }
+  f32x16 old;
+  if (p.accumulate) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int gr = n0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      old[r] = p.dW[(long)(gr < p.N ? gr : 0) * p.lddw + (k_ok ? gk : 0)];     // (clamped; used under the store's mask)
+    }
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;
+#pragma unroll
+  for (int s = 0; s < 16 * MT; ++s) {
+    const int m = (s >> 3) * 16 + ((s >> 2) & 1) * 8 + (s & 3) + 4 * h;
+    const float av = (m < p.M && n_ok) ? a[s] : 0.f;
+    const float bv = (m < p.M && k_ok) ? b[s] : 0.f;
+    bsum += av;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int gr = n0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (gr < p.N && k_ok) {
+      float v = acc[r];
+      if (p.accumulate) v += old[r];
+      p.dW[(long)gr * p.lddw + gk] = v;
+    }
+  }
+  if (p.db != nullptr && k0 == 0) {                           // (wave-uniform) db[n] = sum_m dY[m][n]: both lane halves
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (h == 0 && n_ok) p.db[gn] = p.accumulate ? p.db[gn] + bsum : bsum;
+  }
+}
+
 }  // namespace
 
 extern "C" size_t clipk_gemm_f32_workspace(int M, int N, int K, int transA, int transB) {
@@ -399,3 +470,36 @@ extern "C" int clipk_gemm_f32(const float* A, int64_t lda, int transA, const flo
     hipLaunchKernelGGL((gemm_f32_kernel<2, 2>), dim3((unsigned)t64), dim3(256), 0, (hipStream_t)stream, p);
   return clipk_check_launch();
 }
+
+extern "C" int clipk_colsum_f32(const float* x, int rows, int cols, float* out, int accumulate, void* stream);
+extern "C" int clipk_gemm_f32(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB,
+                              int M, int N, int K, const float* alpha, const float* bias, const float* addend,
+                              int64_t ldadd, const float* addend_scale, float* out, int64_t ldo,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
+extern "C" int clipk_gemm_wgrad_f32(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw,
+                                    float* dbias, int M, int N, int K, int accumulate, void* stream) {
+  if (!dY || !X || (!dW && !dbias) || M <= 0 || N <= 0 || K <= 0) return CLIPK_ERR_BAD_ARG;
+  if (dW && M <= 64) {
+    WGP p;
+    p.dY = dY; p.lddy = lddy; p.X = X; p.ldx = ldx; p.dW = dW; p.lddw = lddw; p.db = dbias;
+    p.M = M; p.N = N; p.K = K; p.accumulate = accumulate;
+    const dim3 grid((unsigned)((K + 127) / 128), (unsigned)((N + 31) / 32));
+    if (grid.y > 65535u) return CLIPK_ERR_UNSUPPORTED;
+    if (M <= 32) hipLaunchKernelGGL((wgrad_f32_small_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((wgrad_f32_small_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    return clipk_check_launch();
+  }
+  // many rows: the tiled kernel (contraction-major operands) and the column reduce
+  if (dW) {
+    const int rc = clipk_gemm_f32(dY, lddy, 1, X, ldx, 1, N, K, M, nullptr, nullptr, accumulate ? dW : nullptr, lddw, nullptr,
+                                  dW, lddw, nullptr, 0, stream);
+    if (rc != CLIPK_OK) return rc;
+  }
+  if (dbias) {
+    if (lddy != N) return CLIPK_ERR_UNSUPPORTED;             // (the column reduce takes dense rows)
+    return clipk_colsum_f32(dY, M, N, dbias, accumulate, stream);
+  }
+  return CLIPK_OK;
+}
+

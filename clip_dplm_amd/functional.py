@@ -201,16 +201,28 @@ class LinearF32Fn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = ops.gemm_f32(dy, weight, trans_b=True) if ctx.needs_input_grad[0] else None
         dw = db = None
-        if ctx.needs_input_grad[1]:
-            if _grad_in_place(weight):       # dW added straight into the parameter's .grad (a view of FusedAdamW's flat
-                ops.gemm_f32(dy, x, trans_a=True, trans_b=True, addend=weight.grad, out=weight.grad)     # buffer): no
-            else:                            # temporary, no AccumulateGrad add launch per parameter
-                dw = ops.gemm_f32(dy, x, trans_a=True, trans_b=True)
-        if bias is not None and ctx.needs_input_grad[2]:
-            if _grad_in_place(bias):
-                ops.colsum_f32(dy, out=bias.grad, accumulate=True)
+        want_w = ctx.needs_input_grad[1]
+        want_b = bias is not None and ctx.needs_input_grad[2]
+        # dW / db added straight into the parameters' .grad (views of FusedAdamW's flat buffer) where those exist: no
+        # temporary, no AccumulateGrad add launch per parameter.  Both gradients of a Linear come from ONE launch when they
+        # go the same way (clipk_gemm_wgrad_f32)
+        w_here, b_here = want_w and _grad_in_place(weight), want_b and _grad_in_place(bias)
+        if want_w and want_b and w_here == b_here:
+            if w_here:
+                ops.gemm_wgrad_f32(dy, x, dw=weight.grad, dbias=bias.grad, accumulate=True)
             else:
-                db = ops.colsum_f32(dy)
+                dw, db = ops.gemm_wgrad_f32(dy, x)
+        else:
+            if want_w:
+                if w_here:
+                    ops.gemm_wgrad_f32(dy, x, dw=weight.grad, accumulate=True, want_bias=False)
+                else:
+                    dw, _ = ops.gemm_wgrad_f32(dy, x, want_bias=False)
+            if want_b:
+                if b_here:
+                    ops.colsum_f32(dy, out=bias.grad, accumulate=True)
+                else:
+                    db = ops.colsum_f32(dy)
         return dx, dw, db, (dy if len(ctx.needs_input_grad) > 3 and ctx.needs_input_grad[3] else None)
 
 

@@ -368,6 +368,41 @@ def colsum_f32(x, out=None, accumulate=False):
     return out
 
 
+def gemm_wgrad_f32(dy, x, dw=None, dbias=None, accumulate=False, want_bias=True):
+    """Parameter gradients of an exact-f32 Linear: dW[N, K] (+)= dy[M, N]^T @ x[M, K], db[N] (+)= dy.sum(0), one launch when
+    M <= 64.  dw / dbias: write (accumulate: add) into these tensors, e.g. the parameters' .grad; otherwise new tensors
+    (want_bias=False and no dbias: no bias gradient).  Returns (dw, dbias)."""
+    _need_cuda(dy, x, dw, dbias)
+    assert dy.dtype == torch.float32 and x.dtype == torch.float32 and dy.dim() == 2 and x.dim() == 2
+    assert dy.shape[0] == x.shape[0]
+    if dy.stride(1) != 1:
+        dy = dy.contiguous()
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    M, N = dy.shape
+    K = x.shape[1]
+    fresh = dw is None
+    if fresh:
+        dw = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    if dbias is None and want_bias:
+        assert fresh or not accumulate, "accumulate with a new dbias tensor"
+        dbias = torch.empty(N, dtype=torch.float32, device=dy.device)
+    assert dw.dtype == torch.float32 and dw.shape == (N, K) and dw.stride(1) == 1
+    assert dbias is None or (dbias.dtype == torch.float32 and dbias.numel() == N and dbias.is_contiguous())
+    acc = bool(accumulate and not fresh)
+    if M > 64:                 # many rows: the tiled kernel (its wrapper pads odd leading dimensions) + the column reduce
+        gemm_f32(dy, x, trans_a=True, trans_b=True, addend=dw if acc else None, out=dw)
+        if dbias is not None:
+            colsum_f32(dy.contiguous(), out=dbias, accumulate=acc)
+        return dw, dbias
+    lib = _lib()
+    check(_timed("gemm_f32", 2.0 * M * N * K,
+                 lambda: lib.clipk_gemm_wgrad_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(),
+                                                  dw.stride(0), ptr(dbias), M, N, K, int(acc), _stream()),
+                 4.0 * (M * (N + K) + N * K * (2 if acc else 1))), "clipk_gemm_wgrad_f32")
+    return dw, dbias
+
+
 def gemm_f32(a, b, trans_a=False, trans_b=False, bias=None, addend=None, addend_scale=None, alpha=None, out=None):
     """Exact-f32 out[M, N] = alpha * opA(a) @ opB(b) (+ bias) (+ addend_scale * addend) on the tiled f32-MFMA kernel
     (alpha / addend_scale: 1-element device tensors).

@@ -227,6 +227,16 @@ int clipk_gemm_f32(const float* A, int64_t lda, int transA, const float* B, int6
  * (old/clip.py:11,27,31 under autograd), accumulated straight into the parameter's .grad; fixed summation order. */
 int clipk_colsum_f32(const float* x, int rows, int cols, float* out, int accumulate, void* stream);
 
+/* Both parameter gradients of an exact-f32 Linear in one call: dW[N, K] (+)= dY[M, N]^T X[M, K], dbias[N] (+)= dY.sum(0)
+ * (what autograd computes for nn.Linear under the reference's fp32 callers: old/clip.py:11,27,31; the Linear layers of
+ * RNARBPCLIPModel / ContrastiveModel, current/rna_clip_codes.ipynb:1911-1954) - the f32 sibling of clipk_gemm_wgrad.
+ * dW or dbias may be NULL (not both).  accumulate != 0 adds into dW / dbias (a parameter's .grad).  M <= 64 (the models
+ * sliced to the one position they pool: M = batch rows): ONE launch, one pass over dW with dbias from the same operand
+ * registers; more rows: the tiled clipk_gemm_f32 (contraction-major operands) + clipk_colsum_f32 (needs lddy == N).
+ * dW is bit-identical to clipk_gemm_f32(dY, transA = 1, X, transB = 1, addend = dW) either way. */
+int clipk_gemm_wgrad_f32(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw,
+                         float* dbias, int M, int N, int K, int accumulate, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Row-wise normalisation kernels (one wave per row, f32 statistics).
  * LayerNorm forward:  y = (x-mean)*rstd*gamma + beta, optional activation fused after it

@@ -198,6 +198,20 @@ def colsum_f32(x, out=None, accumulate=False):
     return out
 
 
+def gemm_wgrad_f32(dy, x, dw=None, dbias=None, accumulate=False, want_bias=True):
+    w_ = dy.t() @ x
+    b_ = dy.sum(0)
+    if dw is None:
+        dw = w_
+    else:
+        dw.copy_(dw + w_ if accumulate else w_)
+    if dbias is None:
+        dbias = b_ if want_bias else None
+    else:
+        dbias.copy_(dbias + b_ if accumulate else b_)
+    return dw, dbias
+
+
 def gemm_f32(a, b, trans_a=False, trans_b=False, bias=None, addend=None, addend_scale=None, alpha=None, out=None):
     r = (a.t() if trans_a else a) @ (b if trans_b else b.t())
     if alpha is not None:

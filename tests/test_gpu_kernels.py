@@ -852,6 +852,35 @@ def test_gemm_f32_all_layouts(dev, M, N, K, ta, tb):
     assert torch.equal(out, ops.gemm_f32(a, b, trans_a=ta, trans_b=tb))        # deterministic
 
 
+@pytest.mark.parametrize("M,N,K", [(32, 1280, 1280), (32, 512, 1280), (7, 40, 100), (33, 65, 129), (64, 96, 200),
+                                   (1, 32, 32), (100, 64, 72)])
+def test_gemm_wgrad_f32_one_launch_for_few_rows(dev, M, N, K):
+    """clipk_gemm_wgrad_f32: dW = dy^T x and db = dy.sum(0) of an exact-f32 Linear (reference: autograd of nn.Linear,
+    old/clip.py:11; rna_clip_codes.ipynb:1911-1954 at M = batch rows).  M <= 64 is the one-pass kernel (ragged M / N / K, both
+    MT forms), M = 100 the tiled fallback; dW must be bit-identical to clipk_gemm_f32 on contraction-major operands (same
+    contraction order), db against f64; accumulate adds into existing buffers, also through a row stride."""
+    ops = _ops()
+    dy, x = _rand((M, N), dev, 71), _rand((M, K), dev, 72)
+    dw, db = ops.gemm_wgrad_f32(dy, x)
+    assert torch.equal(dw, ops.gemm_f32(dy, x, trans_a=True, trans_b=True))
+    ref_w, ref_b = dy.double().t() @ x.double(), dy.double().sum(0)
+    assert ((dw.double() - ref_w).abs() <= 4e-7 * (dy.double().abs().t() @ x.double().abs()) + 1e-6).all()
+    assert ((db.double() - ref_b).abs() <= 4e-7 * dy.double().abs().sum(0) + 1e-6).all()
+    # accumulate into a strided dW (a slice of a wider buffer, like a parameter's .grad view) and an existing db
+    wide = _rand((N, K + 4), dev, 73)
+    w0, b0 = wide.clone(), _rand((N,), dev, 74)
+    bacc = b0.clone()
+    ops.gemm_wgrad_f32(dy, x, dw=wide[:, :K], dbias=bacc, accumulate=True)
+    assert torch.equal(wide[:, :K], ops.gemm_f32(dy, x, trans_a=True, trans_b=True, addend=w0[:, :K]))
+    assert torch.equal(wide[:, K:], w0[:, K:])                                  # nothing written past the K columns
+    assert ((bacc.double() - (b0.double() + ref_b)).abs() <= 4e-7 * dy.double().abs().sum(0) + 2e-6).all()
+    # overwrite form and the weight-only form
+    ops.gemm_wgrad_f32(dy, x, dw=wide[:, :K], dbias=bacc, accumulate=False)
+    assert torch.equal(wide[:, :K], dw) and torch.equal(bacc, db)
+    dw2, none = ops.gemm_wgrad_f32(dy, x, want_bias=False)
+    assert none is None and torch.equal(dw2, dw)
+
+
 def test_embed_fwd_out_of_range_id_is_loud(dev):
     """An id outside the table must never read memory: its row is NaN, every other row is exact."""
     ops = _ops()
