@@ -77,6 +77,7 @@ def parse_args():
     ap.add_argument("--dual-stream", action="store_true",
                     help="enqueue the two towers on separate HIP streams (a kernel's HIP-event time then includes "
                          "waiting for the other tower's kernels)")
+    ap.add_argument("--single-stream", action="store_true", help="--config notebook: towers on one HIP stream in the captured step")
     ap.add_argument("--micro-batches", type=int, default=1, help="with --dual-stream: stream pairs per step")
     ap.add_argument("--wgrad-stream", action="store_true", help="weight-gradient GEMMs on a side stream per tower")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
@@ -797,6 +798,9 @@ def bench_notebook(args):
     rna_d, rbp_d = rna.to(dev), rbp.to(dev)
     with torch.no_grad():
         loss_gpu0 = float(model(rna_d, rbp_d)[2].item())
+    # the two towers as parallel branches of the captured step (default for the replayed step; eager launches are
+    # host-bound either way): --single-stream switches it off, --dual-stream forces it for --eager
+    model.dual_stream = bool(args.dual_stream) or (not args.eager and not args.single_stream)
     opt = K.FusedAdamW(model, lr=1e-4, weight_decay=0.01, max_grad_norm=1.0)
 
     def step():
@@ -852,7 +856,8 @@ def bench_notebook(args):
            "config": {"workload": f"RNARBPCLIPModel(120, 1280, 512), {nparam} parameters, rna [{B}, {Lr}, 120] x rbp "
                                   f"[{B}, {Lp}, 1280] with ragged NaN padding, training step (fwd + symmetric InfoNCE + bwd + "
                                   f"clip + fused AdamW), variant {args.variant}, "
-                                  + ("launches issued eagerly" if args.eager else "step replayed from one hipGraph")},
+                                  + ("launches issued eagerly" if args.eager else "step replayed from one hipGraph"),
+                      "hip_streams": 2 if model.dual_stream else 1},
            "loss": round(float(loss.item()), 5), "roofline": roof, "kernels": kernels,
            "step_hbm_floor": {"algorithmic_bytes_per_step": int(step_bytes),
                               "ms_at_8TBps": round(step_bytes / 8e12 * 1e3, 4),

@@ -818,6 +818,14 @@ class TransformerSeqEncoder(nn.Module):
         for i, l in enumerate(self.layers):
             a = l.self_attn
             dr = None if drop is None else [(drop[0], sd) for sd in drop[1][i]]      # attn, drop1, ffn, drop2
+            if dr is None:                 # no active dropout: each half of the layer is one autograd node
+                s1 = KF.AttnBlockF32Fn.apply(h, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
+                                             B, L, H, D, mask_u8, float(D) ** -0.5)
+                x1 = KF.layer_norm(s1, l.norm1.weight, l.norm1.bias, self.eps)
+                s2 = KF.FFNBlockF32Fn.apply(x1, l.linear1.weight, l.linear1.bias, l.linear2.weight, l.linear2.bias,
+                                            self.activation)
+                h = KF.layer_norm(s2, l.norm2.weight, l.norm2.bias, self.eps)
+                continue
             qkv = KF.linear_f32(h, a.in_proj_weight, a.in_proj_bias)
             ctx = KF.attention_f32(qkv, B, L, H, D, mask_u8, float(D) ** -0.5, dr[0] if dr else None)
             if dr:

@@ -200,30 +200,135 @@ class LinearF32Fn(torch.autograd.Function):
         bias = ctx.bias
         dy = dy.contiguous()
         dx = ops.gemm_f32(dy, weight, trans_b=True) if ctx.needs_input_grad[0] else None
-        dw = db = None
-        want_w = ctx.needs_input_grad[1]
-        want_b = bias is not None and ctx.needs_input_grad[2]
-        # dW / db added straight into the parameters' .grad (views of FusedAdamW's flat buffer) where those exist: no
-        # temporary, no AccumulateGrad add launch per parameter.  Both gradients of a Linear come from ONE launch when they
-        # go the same way (clipk_gemm_wgrad_f32)
-        w_here, b_here = want_w and _grad_in_place(weight), want_b and _grad_in_place(bias)
-        if want_w and want_b and w_here == b_here:
-            if w_here:
-                ops.gemm_wgrad_f32(dy, x, dw=weight.grad, dbias=bias.grad, accumulate=True)
-            else:
-                dw, db = ops.gemm_wgrad_f32(dy, x)
-        else:
-            if want_w:
-                if w_here:
-                    ops.gemm_wgrad_f32(dy, x, dw=weight.grad, accumulate=True, want_bias=False)
-                else:
-                    dw, _ = ops.gemm_wgrad_f32(dy, x, want_bias=False)
-            if want_b:
-                if b_here:
-                    ops.colsum_f32(dy, out=bias.grad, accumulate=True)
-                else:
-                    db = ops.colsum_f32(dy)
+        dw, db = _linear_f32_param_grads(dy, x, weight, bias, ctx.needs_input_grad[1],
+                                         bias is not None and ctx.needs_input_grad[2])
         return dx, dw, db, (dy if len(ctx.needs_input_grad) > 3 and ctx.needs_input_grad[3] else None)
+
+
+def _linear_f32_param_grads(dy, x, weight, bias, want_w, want_b):
+    """(dW, db) of an exact-f32 Linear for autograd - or (None, None) after adding them straight into the parameters'
+    .grad (views of FusedAdamW's flat buffer) where those exist: no temporary, no AccumulateGrad add launch per
+    parameter.  Both gradients come from ONE launch when they go the same way (clipk_gemm_wgrad_f32)."""
+    dw = db = None
+    w_here, b_here = want_w and _grad_in_place(weight), want_b and _grad_in_place(bias)
+    if want_w and want_b and w_here == b_here:
+        if w_here:
+            ops.gemm_wgrad_f32(dy, x, dw=weight.grad, dbias=bias.grad, accumulate=True)
+        else:
+            dw, db = ops.gemm_wgrad_f32(dy, x)
+    else:
+        if want_w:
+            if w_here:
+                ops.gemm_wgrad_f32(dy, x, dw=weight.grad, accumulate=True, want_bias=False)
+            else:
+                dw, _ = ops.gemm_wgrad_f32(dy, x, want_bias=False)
+        if want_b:
+            if b_here:
+                ops.colsum_f32(dy, out=bias.grad, accumulate=True)
+            else:
+                db = ops.colsum_f32(dy)
+    return dw, db
+
+
+class JoinStreamsFn(torch.autograd.Function):
+    """Identity on tensors that branches of the model produced on side HIP streams (the caller has already made its stream
+    wait for them).  Its backward is the FIRST node of the backward pass to run; it asks the autograd engine to make the
+    calling stream wait for the side streams once the pass is over.  The engine replays each branch on the stream of its
+    forward and only syncs the streams of AccumulateGrad leaves - gradients the kernels add straight into `.grad` buffers
+    on a side stream would otherwise race the optimiser."""
+
+    @staticmethod
+    def forward(ctx, streams, *tensors):
+        ctx.streams = streams
+        return tensors if len(tensors) > 1 else tensors[0]
+
+    @staticmethod
+    def backward(ctx, *grads):
+        streams = ctx.streams
+
+        def join():
+            cur = torch.cuda.current_stream()
+            for s in streams:
+                cur.wait_stream(s)
+
+        torch.autograd.Variable._execution_engine.queue_callback(join)
+        return (None,) + grads
+
+
+def parallel_branches(streams, thunks, inputs=()):
+    """Run independent branches of a model (the towers of a contrastive model up to the loss) on HIP streams of their own:
+    thunks[i]() is enqueued on streams[i] and returns ONE tensor; inputs[i] are the tensors it reads that the calling
+    stream allocated.  The calling stream forks before and joins after (forward), autograd replays every branch on its
+    stream (backward), JoinStreamsFn joins again when the backward pass ends.  Inside a hipGraph capture the branches become
+    parallel branches of the graph.  Returns the outputs in order."""
+    main = torch.cuda.current_stream()
+    outs = []
+    for s, f in zip(streams, thunks):
+        s.wait_stream(main)
+        with torch.cuda.stream(s):
+            outs.append(f())
+    for s, ins in zip(streams, inputs):
+        for t in ins:
+            if t is not None and t.is_cuda:
+                t.record_stream(s)
+    for s in streams:
+        main.wait_stream(s)
+    for t in outs:
+        t.record_stream(main)
+    return JoinStreamsFn.apply(tuple(streams), *outs)
+
+
+class AttnBlockF32Fn(torch.autograd.Function):
+    """s = h + out_proj(attention(in_proj(h))) of nn.TransformerEncoderLayer (rna_clip_codes.ipynb:1911-1921), exact f32,
+    no active dropout, as ONE autograd node: the residual's gradient rides the in_proj input-gradient GEMM as its addend
+    (per-op composition leaves that sum to an autograd `add` launch per block) and the host walks one node instead of three."""
+
+    @staticmethod
+    def forward(ctx, h, w_in, b_in, w_out, b_out, B, L, H, D, key_mask, q_scale):
+        h = h.contiguous()
+        qkv = ops.gemm_f32(h, w_in, bias=b_in)
+        att, lse = ops.attn_f32_fwd(qkv, B, L, H, D, key_mask=key_mask, q_scale=q_scale)
+        ctx.meta = (B, L, H, D, key_mask, q_scale)
+        ctx.save_for_backward(h, w_in, b_in, w_out, b_out, qkv, att, lse)
+        return ops.gemm_f32(att, w_out, bias=b_out, addend=h)
+
+    @staticmethod
+    def backward(ctx, ds):
+        h, w_in, b_in, w_out, b_out, qkv, att, lse = ctx.saved_tensors
+        B, L, H, D, key_mask, q_scale = ctx.meta
+        ds = ds.contiguous()
+        need = ctx.needs_input_grad
+        dwo, dbo = _linear_f32_param_grads(ds, att, w_out, b_out, need[3], b_out is not None and need[4])
+        datt = ops.gemm_f32(ds, w_out, trans_b=True)
+        dqkv = ops.attn_f32_bwd(qkv, att, datt, lse, B, L, H, D, key_mask=key_mask, q_scale=q_scale)
+        dwi, dbi = _linear_f32_param_grads(dqkv, h, w_in, b_in, need[1], b_in is not None and need[2])
+        dh = ops.gemm_f32(dqkv, w_in, trans_b=True, addend=ds) if need[0] else None
+        return dh, dwi, dbi, dwo, dbo, None, None, None, None, None, None
+
+
+class FFNBlockF32Fn(torch.autograd.Function):
+    """s = x + linear2(act(linear1(x))) of nn.TransformerEncoderLayer, exact f32, no active dropout, as one autograd node
+    (see AttnBlockF32Fn)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, act):
+        x = x.contiguous()
+        u = ops.gemm_f32(x, w1, bias=b1)
+        g = ops.act_fwd(u, act)
+        ctx.act = act
+        ctx.save_for_backward(x, w1, b1, w2, b2, u, g)
+        return ops.gemm_f32(g, w2, bias=b2, addend=x)
+
+    @staticmethod
+    def backward(ctx, ds):
+        x, w1, b1, w2, b2, u, g = ctx.saved_tensors
+        ds = ds.contiguous()
+        need = ctx.needs_input_grad
+        dw2, db2 = _linear_f32_param_grads(ds, g, w2, b2, need[3], b2 is not None and need[4])
+        du = ops.act_bwd(ops.gemm_f32(ds, w2, trans_b=True), u, ctx.act)
+        dw1, db1 = _linear_f32_param_grads(du, x, w1, b1, need[1], b1 is not None and need[2])
+        dx = ops.gemm_f32(du, w1, trans_b=True, addend=ds) if need[0] else None
+        return dx, dw1, db1, dw2, db2, None
 
 
 def _grad_in_place(p) -> bool:
@@ -328,6 +433,11 @@ class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, gamma, beta, mean, rstd = ctx.saved_tensors
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and _grad_in_place(gamma) and _grad_in_place(beta):
+            # the column reduce adds straight into the parameters' .grad (no AccumulateGrad add launch per parameter)
+            dx = ops.layernorm_bwd(dy.contiguous(), x, gamma, beta, mean, rstd, act=ctx.act, want_f32=True,
+                                   dgamma=gamma.grad, dbeta=beta.grad, accumulate=True)[0]
+            return dx, None, None, None, None
         dx, _, dg, db = ops.layernorm_bwd(dy.contiguous(), x, gamma, beta, mean, rstd, act=ctx.act, want_f32=True)
         return dx, dg, db, None, None
 

@@ -71,6 +71,12 @@ class RNARBPCLIPModel(nn.Module):
         self.rbp_projection = RNARBPCLIPProjectionHead(rbp_dim, projection_dim)
         self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
         self.slice_first_position = bool(slice_first_position)
+        # opt-in: the two towers on two HIP streams.  Sliced to position 0 each tower is a chain of ~10 us kernels, and the
+        # rna tower's (d = 120) do not fill a tenth of the chip: side by side the short chain hides under the long one, in
+        # the forward and - autograd replays each node on its forward stream - in the backward; in a captured step they
+        # are two branches of the hipGraph
+        self.dual_stream = False
+        self._streams = None
         KF.set_linear_precision(self, precision)
 
     def _encode(self, encoder, emb):
@@ -84,8 +90,17 @@ class RNARBPCLIPModel(nn.Module):
         return y[0]                                                       # == enc[:, 0] in the notebook's layout
 
     def forward(self, rna_emb, rbp_emb):
-        rna_embed = KF.l2_normalize(self.rna_projection(self._encode(self.rna_encoder, rna_emb)))
-        rbp_embed = KF.l2_normalize(self.rbp_projection(self._encode(self.rbp_encoder, rbp_emb)))
+        if self.dual_stream and rna_emb.is_cuda:
+            if self._streams is None:
+                self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
+            rna_embed, rbp_embed = KF.parallel_branches(
+                self._streams,
+                (lambda: KF.l2_normalize(self.rna_projection(self._encode(self.rna_encoder, rna_emb))),
+                 lambda: KF.l2_normalize(self.rbp_projection(self._encode(self.rbp_encoder, rbp_emb)))),
+                ((rna_emb,), (rbp_emb,)))
+        else:
+            rna_embed = KF.l2_normalize(self.rna_projection(self._encode(self.rna_encoder, rna_emb)))
+            rbp_embed = KF.l2_normalize(self.rbp_projection(self._encode(self.rbp_encoder, rbp_emb)))
         loss = clip_loss(rna_embed, rbp_embed, self.logit_scale.exp(), symmetric=True, group=None)
         return rna_embed, rbp_embed, loss
 

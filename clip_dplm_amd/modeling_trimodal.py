@@ -169,6 +169,8 @@ class ContrastiveModel(nn.Module):
         self.protein_projection = ProjectionHead(protein_dim, projection_dim)
         self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
         self.slice_first_position = bool(slice_first_position)
+        self.multi_stream = False
+        self._streams = None
         KF.set_linear_precision(self, precision)
 
     @staticmethod
@@ -179,14 +181,19 @@ class ContrastiveModel(nn.Module):
         return x[:, :1] if (self.slice_first_position and x.dim() == 3) else x
 
     def forward(self, cell_state, connectivity, gene_esm_embeddings, gene_values, protein_emb, group=None):
-        cell_enc = self.cell_encoder(cell_state, connectivity)
         if self.slice_first_position and gene_esm_embeddings.dim() == 3:
             gene_esm_embeddings, gene_values = gene_esm_embeddings[:, :1], gene_values[:, :1]
-        pert_enc = self.pert_encoder(gene_esm_embeddings, gene_values)
-        protein_enc = self.protein_encoder(self._sl(protein_emb))
-        cell_embed = KF.l2_normalize(self.cell_projection(self._first(cell_enc)))
-        pert_embed = KF.l2_normalize(self.pert_projection(self._first(pert_enc)))
-        protein_embed = KF.l2_normalize(self.protein_projection(self._first(protein_enc)))
+        cell = lambda: KF.l2_normalize(self.cell_projection(self._first(self.cell_encoder(cell_state, connectivity))))
+        pert = lambda: KF.l2_normalize(self.pert_projection(self._first(self.pert_encoder(gene_esm_embeddings, gene_values))))
+        prot = lambda: KF.l2_normalize(self.protein_projection(self._first(self.protein_encoder(self._sl(protein_emb)))))
+        if self.multi_stream and cell_state.is_cuda:       # opt-in: the three towers on three HIP streams (RNARBPCLIPModel)
+            if self._streams is None:
+                self._streams = tuple(torch.cuda.Stream() for _ in range(3))
+            cell_embed, pert_embed, protein_embed = KF.parallel_branches(
+                self._streams, (cell, pert, prot),
+                ((cell_state, connectivity), (gene_esm_embeddings, gene_values), (protein_emb,)))
+        else:
+            cell_embed, pert_embed, protein_embed = cell(), pert(), prot()
         out = {"cell_embed": cell_embed, "pert_embed": pert_embed, "protein_embed": protein_embed}
         out.update(tri_modal_loss(cell_embed, pert_embed, protein_embed, self.logit_scale.exp(), group=group))
         return out

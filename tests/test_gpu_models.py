@@ -488,21 +488,24 @@ def test_training_trajectory_matches_the_oracle(dev):
         assert d.max().item() <= 6.5e-4 and d.mean().item() <= 1e-5, (n, d.max().item(), d.mean().item())
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16"])
-def test_graphed_train_step_equals_eager_steps(dev, precision):
+@pytest.mark.parametrize("precision,two_streams", [("f32", False), ("bf16", False), ("f32", True), ("bf16", True)])
+def test_graphed_train_step_equals_eager_steps(dev, precision, two_streams):
     """training.GraphedTrainStep: the whole training step (zero_grad -> forward -> symmetric InfoNCE -> backward -> clip ->
     AdamW, rna_clip_codes.ipynb:2061-2089) replayed from ONE hipGraph, inputs and AdamW's per-step scalars in device memory.
     Five steps on five different batches: losses and every weight bit-identical to the same steps issued eagerly, the
-    model untouched by the capture's warm-up, and the optimiser's step count advanced by the replays."""
+    model untouched by the capture's warm-up, and the optimiser's step count advanced by the replays.
+    two_streams: the captured model runs its towers as two parallel branches of the graph (`dual_stream`), the eager one on
+    one stream - same bits."""
     import clip_dplm_amd as K
     from clip_dplm_amd.training import GraphedTrainStep
 
-    def build():
+    def build(dual=False):
         torch.manual_seed(1)
         m = K.RNARBPCLIPModel(rna_dim=40, rbp_dim=128, projection_dim=64, dropout=0.0, precision=precision)
         for mod in m.modules():
             if isinstance(mod, torch.nn.Dropout):
                 mod.p = 0.0
+        m.dual_stream = dual
         return m.to(dev).train()
     g = torch.Generator().manual_seed(3)
     batches = []
@@ -520,7 +523,7 @@ def test_graphed_train_step_equals_eager_steps(dev, precision):
         loss.backward()
         oe.step(lr=1e-3 * (1 + i))                          # a schedule: the learning rate changes every step
         eager.append(loss.item())
-    mg = build()
+    mg = build(two_streams)
     og = K.FusedAdamW(mg, lr=1e-3, weight_decay=0.01, max_grad_norm=1.0)
     w0 = og.flat.data.clone()
     step = GraphedTrainStep(mg, og, lambda a, b: mg(a, b)[2], batches[0])
@@ -531,6 +534,61 @@ def test_graphed_train_step_equals_eager_steps(dev, precision):
     for (n, p), (_, q) in zip(me.named_parameters(), mg.named_parameters()):
         assert torch.equal(p, q), n
     assert eager[-1] < eager[0]
+
+
+@pytest.mark.parametrize("model_name", ["notebook", "trimodal"])
+def test_towers_on_side_streams_give_the_same_step(dev, model_name):
+    """`RNARBPCLIPModel.dual_stream` / `ContrastiveModel.multi_stream`: the towers (independent up to the loss,
+    rna_clip_codes.ipynb:1944-1953, tf_clip_codes (1).ipynb:13140-13176) enqueued on HIP streams of their own, issued
+    eagerly.  Loss and EVERY parameter gradient - the kernels add them into FusedAdamW's .grad views on the side streams -
+    must be bit-identical to the one-stream step when read right after backward() (the join is an autograd-engine callback),
+    and so must the weights after three optimiser steps."""
+    import clip_dplm_amd as K
+    g = torch.Generator().manual_seed(11)
+    if model_name == "notebook":
+        def build(par):
+            torch.manual_seed(2)
+            m = K.RNARBPCLIPModel(rna_dim=40, rbp_dim=256, projection_dim=64, dropout=0.0)
+            m.dual_stream = par
+            return m
+        rna, rbp = torch.randn(32, 5, 40, generator=g), torch.randn(32, 7, 256, generator=g)
+        rna[3, 2:] = float("nan")
+        inputs = (rna.to(dev), rbp.to(dev))
+        loss_of = lambda m: m(*inputs)[2]
+    else:
+        def build(par):
+            torch.manual_seed(2)
+            m = K.ContrastiveModel(21, 64, projection_dim=64, esm_dim=40)
+            m.multi_stream = par
+            return m
+        z, _ = load("trimodal_model.npz")
+        inputs = tuple(t(z, k, dev) for k in ("cell_state", "connectivity", "gene_esm", "gene_values", "protein_emb"))
+        loss_of = lambda m: m(*inputs)["loss"]
+    runs = []
+    for par in (False, True):
+        m = build(par)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        m = m.to(dev).train()
+        opt = K.FusedAdamW(m, lr=1e-3, weight_decay=0.01, max_grad_norm=1.0)
+        opt.zero_grad()
+        loss = loss_of(m)
+        loss.backward()
+        grads = opt.flat.grad.clone() if getattr(opt.flat, "grad", None) is not None else \
+            torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+        losses = [loss.item()]
+        opt.step()
+        for _ in range(2):
+            opt.zero_grad()
+            loss = loss_of(m)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        runs.append((losses, grads, opt.flat.data.clone()))
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    assert torch.equal(runs[0][1], runs[1][1]) and float(runs[0][1].abs().max()) > 0
+    assert torch.equal(runs[0][2], runs[1][2])
 
 
 def test_icnn_transport_golden(dev):
