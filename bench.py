@@ -77,7 +77,7 @@ def parse_args():
     ap.add_argument("--dual-stream", action="store_true",
                     help="enqueue the two towers on separate HIP streams (a kernel's HIP-event time then includes "
                          "waiting for the other tower's kernels)")
-    ap.add_argument("--single-stream", action="store_true", help="--config notebook: towers on one HIP stream in the captured step")
+    ap.add_argument("--single-stream", action="store_true", help="--config notebook / c1: towers on one HIP stream in the captured step")
     ap.add_argument("--micro-batches", type=int, default=1, help="with --dual-stream: stream pairs per step")
     ap.add_argument("--wgrad-stream", action="store_true", help="weight-gradient GEMMs on a side stream per tower")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
@@ -690,6 +690,7 @@ def bench_c1(args):
     xa_d, xb_d = xa.to(dev), xb.to(dev)
     with torch.no_grad():
         loss_gpu0 = float(model.loss(xa_d, xb_d, symmetric=False).item())
+    model.dual_stream = bool(args.dual_stream) or (not args.eager and not args.single_stream)   # towers = graph branches
     opt = K.FusedAdamW(model, lr=1e-4, weight_decay=0.01, max_grad_norm=None)
 
     def step():
@@ -744,7 +745,8 @@ def bench_c1(args):
            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": f"BASELINE config 1: old/clip.py RNAProteinCLIPModule (2 layers, d=128, P=128), B={B} "
                                   "random pairs, training step (fwd + one-sided CE + bwd + fused AdamW), "
-                                  + ("launches issued eagerly" if args.eager else "step replayed from one hipGraph")},
+                                  + ("launches issued eagerly" if args.eager else "step replayed from one hipGraph"),
+                      "hip_streams": 2 if model.dual_stream else 1},
            "loss": round(float(loss.item()), 5),
            "roofline": {"bound": "mfma", "kernel": "clipk_gemm_nt (launch-latency bound at these sizes: 8.4 MFLOP per launch)",
                         "achieved": round(ach, 3), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -108,12 +108,20 @@ class _PairCLIPModule(nn.Module):
                                                         output_dim=config.projection_dim,
                                                         hidden_dim=config.projection_dim * 2))
         self.logit_scale = nn.Parameter(torch.ones([]) * config.logit_scale_init_value)
+        self.dual_stream = False       # opt-in: the two towers on two HIP streams (functional.parallel_branches)
+        self._streams = None
 
     def embed(self, a_values, b_values):
         a, b = self.A, self.B
-        ea = getattr(self, f"{a}_projection")(getattr(self, f"{a}_model")(a_values))
-        eb = getattr(self, f"{b}_projection")(getattr(self, f"{b}_model")(b_values))
-        return KF.l2_normalize(ea), KF.l2_normalize(eb)
+        ta = lambda: KF.l2_normalize(getattr(self, f"{a}_projection")(getattr(self, f"{a}_model")(a_values)))
+        tb = lambda: KF.l2_normalize(getattr(self, f"{b}_projection")(getattr(self, f"{b}_model")(b_values)))
+        if self.dual_stream and a_values.is_cuda:
+            # each tower is a chain of microsecond kernels on 256 rows: side by side (in a captured step: two branches of
+            # the hipGraph) one hides under the other, forward and backward
+            if self._streams is None:
+                self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
+            return KF.parallel_branches(self._streams, (ta, tb), ((a_values,), (b_values,)))
+        return ta(), tb()
 
     def forward(self, a_values, b_values):
         ea, eb = self.embed(a_values, b_values)

@@ -536,7 +536,7 @@ def test_graphed_train_step_equals_eager_steps(dev, precision, two_streams):
     assert eager[-1] < eager[0]
 
 
-@pytest.mark.parametrize("model_name", ["notebook", "trimodal"])
+@pytest.mark.parametrize("model_name", ["notebook", "trimodal", "pair_clip"])
 def test_towers_on_side_streams_give_the_same_step(dev, model_name):
     """`RNARBPCLIPModel.dual_stream` / `ContrastiveModel.multi_stream`: the towers (independent up to the loss,
     rna_clip_codes.ipynb:1944-1953, tf_clip_codes (1).ipynb:13140-13176) enqueued on HIP streams of their own, issued
@@ -555,6 +555,19 @@ def test_towers_on_side_streams_give_the_same_step(dev, model_name):
         rna[3, 2:] = float("nan")
         inputs = (rna.to(dev), rbp.to(dev))
         loss_of = lambda m: m(*inputs)[2]
+    elif model_name == "pair_clip":                       # old/clip.py's module (BASELINE config 1), bf16 Linears
+        from types import SimpleNamespace as NS
+        sub = lambda hh: NS(hidden_size=hh, num_hidden_layers=2, layer_norm_eps=1e-12)
+        cfg = NS(rna_config=sub(128), protein_config=sub(128), diffmap_config=sub(128), projection_dim=128,
+                 logit_scale_init_value=2.6592)
+
+        def build(par):
+            torch.manual_seed(2)
+            m = K.RNAProteinCLIPModule(cfg)
+            m.dual_stream = par
+            return m
+        inputs = (torch.randn(256, 128, generator=g).to(dev), torch.randn(256, 128, generator=g).to(dev))
+        loss_of = lambda m: m.loss(*inputs, symmetric=False)
     else:
         def build(par):
             torch.manual_seed(2)
