@@ -990,7 +990,9 @@ def bench_c5(args):
         out_ = model(cell, pert, prot)
     torch.cuda.synchronize()
     dt_eager = time.perf_counter() - t0
-    # launch-bound in eager mode (~45 small launches per step): replay the same launches from one hipGraph
+    # launch-bound in eager mode (~45 small launches per step): replay the same launches from one hipGraph, the three
+    # maps as three parallel branches of it (--single-stream: one chain)
+    model.multi_stream = not args.single_stream
     graphed = icnn.GraphedTransport(model, cell, pert, prot)
     for _ in range(args.warmup):
         graphed(cell, pert, prot)

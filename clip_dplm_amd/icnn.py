@@ -394,12 +394,27 @@ class TripleTransportMaps(nn.Module):
         self.cell_to_pert = SingleCellTransport(cell_dim, pert_dim, config)
         self.cell_to_protein = SingleCellTransport(cell_dim, protein_dim, config)
         self.pert_to_protein = SingleCellTransport(pert_dim, protein_dim, config)
+        self.multi_stream = False          # opt-in (eval): the maps on HIP streams of their own (KF.parallel_branches)
+        self._streams = None
 
     def forward(self, cell_states, pert_states=None, protein_states=None) -> Dict[str, Union[torch.Tensor, TransportOutput]]:
         if self.training and pert_states is not None and protein_states is not None:
             # the reference's ConsistencyChecker calls a tensor (`pert_protein(cell_pert)`, :242) and raises TypeError
             raise TypeError("'Tensor' object is not callable  (reference 4_transport_maps.py:242: training with all three "
                             "modalities is broken upstream, SURVEY App. A-12; train two modalities per call)")
+        if (self.multi_stream and not self.training and cell_states.is_cuda
+                and pert_states is not None and protein_states is not None):
+            # eval: three independent chains of ~15 launches each (T(x) of one map only reads its source) - side by side
+            # on three streams; replayed from a hipGraph (GraphedTransport) they are three branches of it
+            from . import functional as KF
+            if self._streams is None:
+                self._streams = tuple(torch.cuda.Stream() for _ in range(3))
+            a, b, c = KF.parallel_branches(
+                self._streams,
+                (lambda: self.cell_to_pert(cell_states, pert_states), lambda: self.cell_to_protein(cell_states, protein_states),
+                 lambda: self.pert_to_protein(pert_states, protein_states)),
+                ((cell_states, pert_states), (cell_states, protein_states), (pert_states, protein_states)))
+            return {"cell_to_pert": a, "cell_to_protein": b, "pert_to_protein": c}
         out = {}
         if pert_states is not None:
             out["cell_to_pert"] = self.cell_to_pert(cell_states, pert_states)

@@ -630,6 +630,29 @@ def test_icnn_transport_golden(dev):
         model(t(z, "cell", dev), t(z, "pert", dev), t(z, "protein", dev))
 
 
+def test_icnn_transport_maps_as_graph_branches_give_the_same_output(dev):
+    """`TripleTransportMaps.multi_stream` (eval): the three maps (4_transport_maps.py:147-224, each reads only its source)
+    on three HIP streams, issued eagerly and replayed from one hipGraph (`GraphedTransport`: three branches) - outputs
+    bit-identical to the one-stream call, also for a second batch copied into the graph's static inputs."""
+    from clip_dplm_amd import icnn
+    torch.manual_seed(4)
+    model = icnn.create_transport_system(96, 96, 96, hidden_dims=[96, 96, 48]).to(dev).eval()
+    g = torch.Generator().manual_seed(5)
+    mk = lambda: tuple(torch.randn(200, 96, generator=g).to(dev) for _ in range(3))
+    x1, x2 = mk(), mk()
+    ref1 = {k: v.clone() for k, v in model(*x1).items()}
+    ref2 = {k: v.clone() for k, v in model(*x2).items()}
+    model.multi_stream = True
+    out = model(*x1)
+    torch.cuda.synchronize()
+    assert set(out) == set(ref1) and all(torch.equal(out[k], ref1[k]) for k in ref1)
+    graphed = icnn.GraphedTransport(model, *x1)
+    for x, ref in ((x1, ref1), (x2, ref2), (x1, ref1)):
+        o = graphed(*x)
+        torch.cuda.synchronize()
+        assert all(torch.equal(o[k], ref[k]) for k in ref)
+
+
 @pytest.mark.parametrize("case", ["A", "B"])
 def test_icnn_training_through_transport_map_golden(dev, case):
     """BASELINE config 5, training branch: cost and d cost / d parameters THROUGH T(x) = dPsi/dx (second derivatives
