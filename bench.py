@@ -77,6 +77,9 @@ def parse_args():
     ap.add_argument("--dual-stream", action="store_true",
                     help="enqueue the two towers on separate HIP streams (a kernel's HIP-event time then includes "
                          "waiting for the other tower's kernels)")
+    ap.add_argument("--dropout", type=float, default=0.0,
+                    help="--config notebook: dropout of the encoder layers and projection heads in the timed training step "
+                         "(the notebook trains with 0.1; 0 = the parity configuration)")
     ap.add_argument("--single-stream", action="store_true", help="--config notebook / c1: towers on one HIP stream in the captured step")
     ap.add_argument("--micro-batches", type=int, default=1, help="with --dual-stream: stream pairs per step")
     ap.add_argument("--wgrad-stream", action="store_true", help="weight-gradient GEMMs on a side stream per tower")
@@ -780,7 +783,8 @@ def bench_notebook(args):
     B, Lr, Lp = args.batch or 32, 48, args.seq_len or 600
     sliced, prec = args.variant.startswith("sliced"), args.variant.split("-")[1]
     torch.manual_seed(0)
-    model = K.RNARBPCLIPModel(rna_dim=120, rbp_dim=1280, projection_dim=512, dropout=0.0, precision=prec,
+    pdrop = float(args.dropout)          # 0 (parity / metric runs) or the notebook's own 0.1
+    model = K.RNARBPCLIPModel(rna_dim=120, rbp_dim=1280, projection_dim=512, dropout=pdrop, precision=prec,
                               slice_first_position=sliced)
     nparam = sum(p.numel() for p in model.parameters())
     sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
@@ -793,13 +797,14 @@ def bench_notebook(args):
     for i in range(B):
         rna[i, lr_[i]:] = float("nan")
         rbp[i, lp_[i]:] = float("nan")
-    model = model.to(dev).train()
+    model = model.to(dev).eval()
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):
-            m.p = 0.0
+            m.p = pdrop                                       # (the heads' nn.Dropout(0.1) of ipynb:1887-1903)
     rna_d, rbp_d = rna.to(dev), rbp.to(dev)
     with torch.no_grad():
-        loss_gpu0 = float(model(rna_d, rbp_d)[2].item())
+        loss_gpu0 = float(model(rna_d, rbp_d)[2].item())      # eval forward: what the oracle computes
+    model.train()
     # the two towers as parallel branches of the captured step (default for the replayed step; eager launches are
     # host-bound either way): --single-stream switches it off, --dual-stream forces it for --eager
     model.dual_stream = bool(args.dual_stream) or (not args.eager and not args.single_stream)
@@ -859,7 +864,7 @@ def bench_notebook(args):
                                   f"[{B}, {Lp}, 1280] with ragged NaN padding, training step (fwd + symmetric InfoNCE + bwd + "
                                   f"clip + fused AdamW), variant {args.variant}, "
                                   + ("launches issued eagerly" if args.eager else "step replayed from one hipGraph"),
-                      "hip_streams": 2 if model.dual_stream else 1},
+                      "hip_streams": 2 if model.dual_stream else 1, "dropout": pdrop},
            "loss": round(float(loss.item()), 5), "roofline": roof, "kernels": kernels,
            "step_hbm_floor": {"algorithmic_bytes_per_step": int(step_bytes),
                               "ms_at_8TBps": round(step_bytes / 8e12 * 1e3, 4),

@@ -51,9 +51,10 @@ struct AP {
   // current/rna_clip_codes.ipynb:1915): P~ = P * keep / (1 - p) feeds P·V; the softmax normaliser uses P.  drop_thr = 0:
   // off.  Element index = ((token row of the query) * H + h) * L + key (L = p.L, the padded / longest length).
   unsigned drop_thr, drop_seed; float drop_scale;
+  const unsigned* drop_epoch;       // common.h drop_seed_eff: read once per kernel (dseed), nullptr outside a captured step
 };
-__device__ __forceinline__ float attn_drop(const AP& p, long qrow, int h, int key) {
-  return drop_mul(p.drop_seed, ((unsigned long long)qrow * p.H + h) * (unsigned long long)p.L + key, p.drop_thr, p.drop_scale);
+__device__ __forceinline__ float attn_drop(const AP& p, unsigned dseed, long qrow, int h, int key) {
+  return drop_mul(dseed, ((unsigned long long)qrow * p.H + h) * (unsigned long long)p.L + key, p.drop_thr, p.drop_scale);
 }
 
 // first token row and length of sequence b (L comes in as p.L)
@@ -303,6 +304,7 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_FWD) void attn_fwd_kernel(const AP
   constexpr int RS = Geo<DP>::RS, KS = Geo<DP>::KS, DT = Geo<DP>::DT, NCH = Geo<DP>::NCH, KVB = Geo<DP>::KVB;
   constexpr int NSUB = KVB / 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned dseed = DROP ? drop_seed_eff(p.drop_seed, p.drop_epoch) : 0u;   // one scalar load per kernel
   char* ktile = smem;
   char* vtile = smem + KVB * RS;
   unsigned char* mask_l = reinterpret_cast<unsigned char*>(smem + 2 * KVB * RS);
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_FWD) void attn_fwd_kernel(const AP
           for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              s[kt][qt][r] *= attn_drop(p, qrow, h, kb * KVB + sub * 64 + kt * 16 + 4 * g + r);
+              s[kt][qt][r] *= attn_drop(p, dseed, qrow, h, kb * KVB + sub * 64 + kt * 16 + 4 * g + r);
         }
         pb[qt][0] = pack_acc_pair(s[0][qt], s[1][qt]);
         pb[qt][1] = pack_acc_pair(s[2][qt], s[3][qt]);
@@ -588,6 +590,7 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dq_kernel(const
   constexpr int RS = Geo<DP>::RS, KS = Geo<DP>::KS, DT = Geo<DP>::DT, NCH = Geo<DP>::NCH, KVB = Geo<DP>::KVB;
   constexpr int NSUB = KVB / 64, ILD = DP + 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned dseed = DROP ? drop_seed_eff(p.drop_seed, p.drop_epoch) : 0u;   // one scalar load per kernel
   char* ktile = smem;
   char* vtile = smem + KVB * RS;
   // rows [0,128) and [128,256) of smem stage Q and dO in the prologue (the region holds >= 256 rows)
@@ -742,7 +745,7 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dq_kernel(const
             float dpv = dp[kt][qt][r];                             // dP - delta
             if constexpr (DROP) {                                  // dP passes through the dropout mask, delta does not
               const long qrow = row0 + q0 + wid * 32 + qt * 16 + li;
-              const float ms = attn_drop(p, qrow, h, kb * KVB + sub * 64 + kt * 16 + 4 * g + r);
+              const float ms = attn_drop(p, dseed, qrow, h, kb * KVB + sub * 64 + kt * 16 + 4 * g + r);
               dpv = (dpv + dl[qt]) * ms - dl[qt];
             }
             s[kt][qt][r] = pv * dpv;                               // dS^T (w.r.t. the scaled score)
@@ -800,6 +803,7 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dkv_kernel(cons
   constexpr int KTW = KPB / 64;                           // 16-key tiles per wave
   constexpr int KPW = 16 * KTW, QB = KVB, NS2 = QB / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned dseed = DROP ? drop_seed_eff(p.drop_seed, p.drop_epoch) : 0u;   // one scalar load per kernel
   char* qtile = smem;                                     // [QB q][RS]   (first holds this workgroup's K rows)
   char* dotile = smem + QB * RS;                          // [QB q][RS]   (first holds this workgroup's V rows)
   float* lse_l = reinterpret_cast<float*>(smem + 2 * QB * RS);   // [QB]
@@ -907,7 +911,7 @@ __global__ __launch_bounds__(256, Geo<DP>::WG_BWD) void attn_bwd_dkv_kernel(cons
             float pd = pv, dpv = dp[kt][r];
             if constexpr (DROP) {                               // dV sees the dropped-out P; dP passes through the mask
               const long qrow = row0 + qb * QB + (2 * s2 + qq) * 16 + 4 * g + r;
-              const float ms = attn_drop(p, qrow, h, k0 + wid * KPW + kt * 16 + li);
+              const float ms = attn_drop(p, dseed, qrow, h, k0 + wid * KPW + kt * 16 + li);
               pd = pv * ms;
               dpv = (dpv - nd[r]) * ms + nd[r];                 // nd = -delta
             }
@@ -2473,6 +2477,7 @@ int check_common(const void* qkv, int B, int L, int H, int D, bool rope) {
 
 static inline int set_dropout(AP& p, float dropout_p, unsigned seed) {
   if (!(dropout_p >= 0.f) || dropout_p >= 1.f) return CLIPK_ERR_BAD_ARG;
+  p.drop_epoch = clipk_drop_epoch();
   if (dropout_p == 0.f) { p.drop_thr = 0; p.drop_seed = 0; p.drop_scale = 1.f; return CLIPK_OK; }
   double t = (double)dropout_p * 4294967296.0;
   p.drop_thr = t < 1.0 ? 1u : (t >= 4294967295.0 ? 4294967295u : (unsigned)t);

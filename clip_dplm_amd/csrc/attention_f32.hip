@@ -34,6 +34,7 @@ struct AF {
   int B, L, H, D;
   float scale;
   unsigned drop_thr, drop_seed; float drop_scale;
+  const unsigned* drop_epoch;       // common.h drop_seed_eff (nullptr outside a captured step)
 };
 
 constexpr int KB = 64;        // keys (dQ / forward) or queries (dK/dV) per LDS block = one per lane
@@ -43,8 +44,8 @@ constexpr int NW = 4;         // waves per workgroup; each owns RW rows (templat
 
 __host__ __device__ inline int row_stride(int D) { return 4 * ((((D + 3) >> 2)) | 1); }   // floats; S / 4 odd
 
-__device__ __forceinline__ float drop_at(const AF& p, long qrow, int h, int key) {
-  return drop_mul(p.drop_seed, ((unsigned long long)qrow * p.H + h) * (unsigned long long)p.L + key, p.drop_thr, p.drop_scale);
+__device__ __forceinline__ float drop_at(const AF& p, unsigned dseed, long qrow, int h, int key) {
+  return drop_mul(dseed, ((unsigned long long)qrow * p.H + h) * (unsigned long long)p.L + key, p.drop_thr, p.drop_scale);
 }
 
 // rows [r0, r0 + nrows) of one head-slice of a [B*L, ld] f32 tensor -> LDS rows of stride S, columns >= D and rows past
@@ -83,6 +84,7 @@ template <int DT, int RW>
 __global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const AF p) {
   constexpr int RB = NW * RW;
   extern __shared__ float smem[];
+  const unsigned dseed = p.drop_thr ? drop_seed_eff(p.drop_seed, p.drop_epoch) : 0u;
   const int L = p.L, H = p.H, D = p.D, S = row_stride(D), D4 = (D + 3) & ~3;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * RB;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const AF p) {
         for (int t = 0; t < DT; ++t) acc[r][t] *= corr;
         m[r] = m_new;
       }
-      if (p.drop_thr) pv *= drop_at(p, row0 + q0 + w * RW + r, h, key);
+      if (p.drop_thr) pv *= drop_at(p, dseed, row0 + q0 + w * RW + r, h, key);
       pt[r] = pv;
     }
 #pragma unroll
@@ -164,6 +166,7 @@ template <int DT, int RW>
 __global__ __launch_bounds__(256) void attn_f32_bwd_dq_kernel(const AF p) {
   constexpr int RB = NW * RW;
   extern __shared__ float smem[];
+  const unsigned dseed = p.drop_thr ? drop_seed_eff(p.drop_seed, p.drop_epoch) : 0u;
   const int L = p.L, H = p.H, D = p.D, S = row_stride(D), D4 = (D + 3) & ~3;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * RB;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(256) void attn_f32_bwd_dq_kernel(const AF p) {
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
       const float pv = (valid && lse[r] != -INFINITY) ? expf(s[r] - lse[r]) : 0.f;
-      const float dm = p.drop_thr ? drop_at(p, row0 + q0 + w * RW + r, h, key) : 1.f;
+      const float dm = p.drop_thr ? drop_at(p, dseed, row0 + q0 + w * RW + r, h, key) : 1.f;
       dst[r] = pv * fmaf(dp[r], dm, -delta[r]);              // dS = P o (dP~ - delta)
     }
 #pragma unroll
@@ -250,6 +253,7 @@ template <int DT, int RW>
 __global__ __launch_bounds__(256) void attn_f32_bwd_dkv_kernel(const AF p) {
   constexpr int RB = NW * RW;
   extern __shared__ float smem[];
+  const unsigned dseed = p.drop_thr ? drop_seed_eff(p.drop_seed, p.drop_epoch) : 0u;
   const int L = p.L, H = p.H, D = p.D, S = row_stride(D), D4 = (D + 3) & ~3;
   const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * RB;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(256) void attn_f32_bwd_dkv_kernel(const AF p) {
 #pragma unroll
     for (int r = 0; r < RW; ++r) {
       const float pv = (kvalid[r] && lse != -INFINITY) ? expf(s[r] - lse) : 0.f;
-      const float dm = p.drop_thr ? drop_at(p, row0 + q, h, k0 + w * RW + r) : 1.f;
+      const float dm = p.drop_thr ? drop_at(p, dseed, row0 + q, h, k0 + w * RW + r) : 1.f;
       pt[r] = pv * dm;
       dst[r] = pv * fmaf(dp[r], dm, -delta);
     }
@@ -367,7 +371,7 @@ int launch_bwd(const AF& p, hipStream_t st) {
 
 int set_dropout(AF& p, float dropout_p, unsigned seed) {
   if (!(dropout_p >= 0.f) || dropout_p >= 1.f) return CLIPK_ERR_BAD_ARG;
-  p.drop_thr = 0; p.drop_seed = 0; p.drop_scale = 1.f;
+  p.drop_thr = 0; p.drop_seed = 0; p.drop_scale = 1.f; p.drop_epoch = clipk_drop_epoch();
   if (dropout_p == 0.f) return CLIPK_OK;
   const double t = (double)dropout_p * 4294967296.0;
   p.drop_thr = t < 1.0 ? 1u : (t >= 4294967295.0 ? 4294967295u : (unsigned)t);

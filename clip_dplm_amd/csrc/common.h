@@ -226,6 +226,15 @@ __device__ __forceinline__ bool drop_keep(unsigned seed, unsigned long long idx,
 __device__ __forceinline__ float drop_mul(unsigned seed, unsigned long long idx, unsigned thr, float scale) {
   return drop_keep(seed, idx, thr) ? scale : 0.f;
 }
+// Dropout under hipGraph replay: a captured launch carries its seed as a constant, so every replay would draw the same
+// mask.  clipk_set_dropout_epoch(ptr) registers ONE device word that every dropout site adds (times an odd constant) to
+// its seed when the launch is made while the pointer is registered: the captured step increments the word once per replay
+// (after the backward, which recomputes the masks) and each replay drops different elements.  nullptr (the default): the
+// seed as given - eager behaviour, bit for bit.
+__device__ __forceinline__ unsigned drop_seed_eff(unsigned seed, const unsigned* epoch) {
+  return epoch ? seed + epoch[0] * 0x9E3779B9u : seed;
+}
+const unsigned* clipk_drop_epoch();                      // host side: the registered pointer or nullptr (core.hip)
 
 // ---- pair-interleaved head order (round 4: RoPE of the hd-24 ESM heads in the qkv GEMM's epilogue).  The first il_rows
 // output columns of a fused [q | k | v] projection (the q and k sections) are computed in an order in which the two

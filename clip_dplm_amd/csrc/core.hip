@@ -41,6 +41,13 @@ int opt_index(const char* name) {
 }
 }  // namespace
 
+namespace { std::atomic<const unsigned*> g_drop_epoch{nullptr}; }
+const unsigned* clipk_drop_epoch() { return g_drop_epoch.load(std::memory_order_relaxed); }
+extern "C" int clipk_set_dropout_epoch(const uint32_t* epoch_dev) {
+  g_drop_epoch.store(reinterpret_cast<const unsigned*>(epoch_dev), std::memory_order_relaxed);
+  return CLIPK_OK;
+}
+
 int clipk_opt_get(int which) {
   opts_init();
   return g_opts[which].load(std::memory_order_relaxed);

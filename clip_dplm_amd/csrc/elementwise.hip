@@ -118,7 +118,8 @@ __global__ void axpby_dev_kernel(const float* a, const float* b, const float* s,
 // y = x * keep(seed, i) / (1 - p) (+ addend): nn.Dropout on an f32 tensor with the kernels' counter-based mask (index =
 // the element's row-major position), optionally followed by the residual add it sits in front of
 __global__ void dropout_f32_kernel(const float* x, const float* addend, float* y, long n, unsigned thr, unsigned seed,
-                                   float scale) {
+                                   float scale, const unsigned* epoch) {
+  seed = drop_seed_eff(seed, epoch);
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) {
     const float v = x[i] * drop_mul(seed, (unsigned long long)i, thr, scale);
@@ -517,7 +518,7 @@ extern "C" int clipk_dropout_f32(const float* x, const float* addend, float* y, 
   const double t = (double)p * 4294967296.0;
   const unsigned thr = p == 0.f ? 0u : (t < 1.0 ? 1u : (t >= 4294967295.0 ? 4294967295u : (unsigned)t));
   hipLaunchKernelGGL(dropout_f32_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, x, addend, y,
-                     (long)n, thr, seed, 1.0f / (1.0f - p));
+                     (long)n, thr, seed, 1.0f / (1.0f - p), clipk_drop_epoch());
   return clipk_check_launch();
 }
 

@@ -27,6 +27,7 @@ struct EpiArgs {
   int aux_u8;       // out_preact / dact_aux hold 8-bit GELU' codes (clipk.h aux_dtype) instead of the bf16 pre-activation
   int nt;           // 1: non-temporal (streaming) output stores (epi_args_from decides)
   unsigned drop_thr, drop_seed; float drop_scale;   // dropout after the activation (generic epilogue only); thr 0 = off
+  const unsigned* drop_epoch;                       // common.h drop_seed_eff (nullptr outside a captured step)
   const float* rope_cos; const float* rope_sin; int rope_L, rope_hd, rope_cols, rope_row0;   // EPI_ROPE only
 };
 
@@ -412,8 +413,9 @@ __device__ __forceinline__ void gemm_epilogue(const EpiArgs& p, f32x4 (&acc)[4][
           }
           if (p.drop_thr) {                                   // nn.Dropout on this tensor: index = m * N + n
             const unsigned long long base = (unsigned long long)gm * (unsigned)N + (unsigned)gn;
+            const unsigned dseed = drop_seed_eff(p.drop_seed, p.drop_epoch);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) v[c] *= drop_mul(p.drop_seed, base + c, p.drop_thr, p.drop_scale);
+            for (int c = 0; c < 8; ++c) v[c] *= drop_mul(dseed, base + c, p.drop_thr, p.drop_scale);
           }
           if (p.dact_aux && p.aux_u8) {
             const u32x2 a = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned char*>(p.dact_aux) + (long)gm * p.ldd + gn);
@@ -477,7 +479,7 @@ static inline EpiArgs epi_args_from(const clipk_gemm_args* a) {
   e.nt = clipk_opt_get(OPT_EPI_NT);
   e.rope_cos = a->rope_cos; e.rope_sin = a->rope_sin; e.rope_L = a->rope_L; e.rope_hd = a->rope_hd;
   e.rope_cols = a->rope_cols; e.rope_row0 = a->rope_row0;
-  e.drop_thr = 0; e.drop_seed = a->drop_seed; e.drop_scale = 1.f;
+  e.drop_thr = 0; e.drop_seed = a->drop_seed; e.drop_scale = 1.f; e.drop_epoch = clipk_drop_epoch();
   if (a->drop_p > 0.f && a->drop_p < 1.f) {
     const double t = (double)a->drop_p * 4294967296.0;
     e.drop_thr = t < 1.0 ? 1u : (t >= 4294967295.0 ? 4294967295u : (unsigned)t);

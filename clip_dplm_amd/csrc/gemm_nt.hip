@@ -43,7 +43,7 @@ struct Params {
   const void* residual; long ldr; int r_f32;
   float alpha;
   int ntn;
-  unsigned drop_thr, drop_seed; float drop_scale;
+  unsigned drop_thr, drop_seed; float drop_scale; const unsigned* drop_epoch;
 };
 
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(const Params p) {
@@ -177,8 +177,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_nt_kernel(const Params p) {
     }
     if (p.drop_thr) {                                         // nn.Dropout on this tensor: index = m * N + n
       const unsigned long long base = (unsigned long long)gm * (unsigned)p.N + (unsigned)gn;
+      const unsigned dseed = drop_seed_eff(p.drop_seed, p.drop_epoch);
 #pragma unroll
-      for (int c = 0; c < 8; ++c) v[c] *= drop_mul(p.drop_seed, base + c, p.drop_thr, p.drop_scale);
+      for (int c = 0; c < 8; ++c) v[c] *= drop_mul(dseed, base + c, p.drop_thr, p.drop_scale);
     }
     if (p.dact_aux) {
       const u32x4 a = *reinterpret_cast<const u32x4*>(p.dact_aux + (long)gm * p.ldd + gn);
@@ -294,7 +295,8 @@ static int gemm_nt_one(const clipk_gemm_args* a, void* stream) {
   p.dact_aux = (const unsigned short*)a->dact_aux; p.ldd = a->ldd; p.dact = a->dact;
   p.residual = a->residual; p.ldr = a->ldr; p.r_f32 = (a->r_dtype == CLIPK_F32);
   p.alpha = a->alpha;
-  { const EpiArgs e = epi_args_from(a); p.drop_thr = e.drop_thr; p.drop_seed = e.drop_seed; p.drop_scale = e.drop_scale; }
+  { const EpiArgs e = epi_args_from(a); p.drop_thr = e.drop_thr; p.drop_seed = e.drop_seed; p.drop_scale = e.drop_scale;
+    p.drop_epoch = e.drop_epoch; }
   const int ntm = (a->M + BM - 1) / BM, ntn = (a->N + BN - 1) / BN;
   p.ntn = ntn;
   static std::atomic<uint64_t> attr_set{0};

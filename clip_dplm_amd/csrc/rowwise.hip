@@ -187,6 +187,7 @@ struct LnBwd {
   // POOLED row, f32 [rows / pool_L][cols]; row r receives dy[r / pool_L] * wrow[r] (1 / #valid rows of its sample, or 0:
   // written by ln_pool_fwd_kernel next to mean / rstd, so that the row's scalars are three independent loads)
   const float* wrow; int pool_L;
+  const unsigned* drop_epoch;   // common.h drop_seed_eff (last member: the aggregate initialisers below leave it nullptr)
 };
 
 template <int VPL, bool DYBF16, bool XBF16, bool ADD16 = false, bool POOL = false>
@@ -274,8 +275,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
         if (p.dx_bf16) {
           if (p.drop_thr) {
             const unsigned long long base = (unsigned long long)row * (unsigned)p.cols + 4u * c;
+            const unsigned dseed = drop_seed_eff(p.drop_seed, p.drop_epoch);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dx[e] *= drop_mul(p.drop_seed, base + e, p.drop_thr, p.drop_scale);
+            for (int e = 0; e < 4; ++e) dx[e] *= drop_mul(dseed, base + e, p.drop_thr, p.drop_scale);
           }
           store4_bf16(p.dx_bf16, (long)row * p.lddx + 4 * c, dx);
         }
@@ -597,6 +599,7 @@ extern "C" int clipk_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, c
   LnBwd p{dy, (long)lddy, x, (long)ldx, gamma, beta, mean, rstd, act, dx_add, dx_f32, dx_bf16, (long)lddx,
           (float*)workspace, rows, cols, 0u, drop_seed, 1.0f, (dx_add && dx_add_dtype == CLIPK_BF16) ? 1 : 0,
           nullptr, 1};
+  p.drop_epoch = clipk_drop_epoch();
   if (drop_p > 0.f && drop_p < 1.f) {
     const double t = (double)drop_p * 4294967296.0;
     p.drop_thr = t < 1.0 ? 1u : (t >= 4294967295.0 ? 4294967295u : (unsigned)t);

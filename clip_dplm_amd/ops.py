@@ -357,6 +357,21 @@ def transpose_scale_f32(x, scale=None):
     return out
 
 
+_DROP_EPOCH = None
+
+
+def set_dropout_epoch(epoch: Optional[torch.Tensor]) -> None:
+    """Register (or, with None, clear) the device word every dropout site adds to its seed (clipk_set_dropout_epoch): int32 /
+    uint32 tensor with one element, kept alive here while registered.  Used by training.GraphedTrainStep so that a replayed
+    step draws new masks; eager code never needs it."""
+    global _DROP_EPOCH
+    if epoch is not None:
+        _need_cuda(epoch)
+        assert epoch.numel() == 1 and epoch.element_size() == 4 and epoch.dtype in (torch.int32, torch.uint32)
+    check(_lib().clipk_set_dropout_epoch(0 if epoch is None else epoch.data_ptr()), "clipk_set_dropout_epoch")
+    _DROP_EPOCH = epoch
+
+
 def colsum_f32(x, out=None, accumulate=False):
     """out[c] (+)= sum_r x[r, c] (f32): bias gradients, written straight into `out` (e.g. a parameter's .grad)."""
     _need_cuda(x, out)

@@ -20,6 +20,7 @@ from typing import Any, Callable, Dict, Iterable, Optional
 import torch
 
 from . import functional as KF
+from . import ops
 
 
 class CosineAnnealingLR:
@@ -162,21 +163,24 @@ class GraphedTrainStep:
         step = GraphedTrainStep(model, opt, lambda rna, rbp: model(rna, rbp)[2], (rna, rbp))
         for rna, rbp in loader: loss = step(rna, rbp)           # same shapes as the example inputs
 
-    Restrictions: fixed input shapes; no active dropout (the masks' seeds are drawn on the host per forward: they would
-    repeat with every replay) - use dropout = 0 or hand-written eager steps for that; single process (no collectives).
-    The returned loss is a static device tensor overwritten by the next call (`.item()` / `.clone()` it to keep it)."""
+    Dropout (nn.TransformerEncoderLayer's 0.1 in train() mode, ipynb:1915): the kernels' masks are counter-based,
+    keep(seed, element index), and a captured launch carries its host-drawn seed as a constant - so the step registers a
+    device word (`ops.set_dropout_epoch`) that every dropout site adds to its seed when the kernel runs, and increments it
+    at the end of the captured step: replay k drops with seed + k * 0x9E3779B9, its backward re-draws the same masks.
+    torch's own `nn.Dropout` modules (the projection heads') are replay-safe by themselves: torch's device generator hands a
+    captured kernel its Philox offset through device memory and advances it per replay.
+
+    Restrictions: fixed input shapes; single process (no collectives).  The returned loss is a static device tensor
+    overwritten by the next call (`.item()` / `.clone()` it to keep it)."""
 
     def __init__(self, model, optimizer, loss_fn, example_inputs, warmup: int = 3):
-        for m in model.modules():
-            p = getattr(m, "dropout", None) if not isinstance(m, torch.nn.Dropout) else m.p
-            if model.training and isinstance(p, float) and p > 0.0:
-                raise ValueError("GraphedTrainStep: dropout is active (its seeds are host-side): build the model with "
-                                 "dropout = 0.0 or call .eval()-style p = 0 before capturing")
         if getattr(optimizer, "group", None) is not None:
             raise ValueError("GraphedTrainStep captures single-process steps only")
         self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
         self.static_in = [t.detach().clone().contiguous() for t in example_inputs]
         optimizer.enable_device_hyper()
+        dev = optimizer.flat.data.device
+        self.drop_epoch = torch.zeros(1, dtype=torch.int32, device=dev) if dev.type == "cuda" else None
         # the warm-up steps are real optimiser steps on the example inputs: put weights and optimiser state back afterwards
         saved = (optimizer.flat.data.clone(), optimizer.m.clone(), optimizer.v.clone(), optimizer.step_count)
         side = torch.cuda.Stream()
@@ -188,14 +192,20 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         optimizer._graph_body = True
         KF.set_capture_force(True)                         # bf16 weight copies: rebuilt at their point of use, in the graph
+        ops.set_dropout_epoch(self.drop_epoch)             # launches captured from here on read their seed offset from it
         try:
             optimizer.prepare_step()                       # the captured step is a real one, too
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.static_loss = self._body()
+                if self.drop_epoch is not None:
+                    self.drop_epoch.add_(1)                # after the backward: the next replay draws new masks
         finally:
             optimizer._graph_body = False
             KF.set_capture_force(False)
+            ops.set_dropout_epoch(None)                    # eager launches elsewhere keep their plain seeds
+        if self.drop_epoch is not None:
+            self.drop_epoch.zero_()
         optimizer.flat.data.copy_(saved[0])
         optimizer.m.copy_(saved[1])
         optimizer.v.copy_(saved[2])

@@ -368,6 +368,14 @@ int clipk_attn_f32_bwd(const float* qkv, const uint8_t* key_mask, const float* o
  * the counter-based mask of the GEMM epilogues (element index = row-major position); the backward is the same call on
  * the gradient.  addend may be NULL; y may alias x. */
 int clipk_dropout_f32(const float* x, const float* addend, float* y, int64_t n, float p, uint32_t seed, void* stream);
+/* Dropout under hipGraph replay (training.GraphedTrainStep with nn.TransformerEncoderLayer's dropout = 0.1 active,
+ * rna_clip_codes.ipynb:1915, :2061-2089): a captured launch carries its seed as a constant, so every replay would repeat
+ * the mask.  While a device word is registered here, EVERY dropout site of the library (clipk_gemm_nt's drop_p,
+ * clipk_attn_*'s dropout_p, clipk_attn_f32_*, clipk_dropout_f32, clipk_layernorm_bwd's drop_p) uses
+ * seed + *epoch_dev * 0x9E3779B9 instead of seed, read when the kernel RUNS: the captured step increments the word once per
+ * replay, after its backward (which re-draws the forward's masks from the same seeds).  NULL (the default) restores the
+ * plain seeds; launches made while nothing is registered are unaffected, bit for bit.  Process-wide. */
+int clipk_set_dropout_epoch(const uint32_t* epoch_dev);
 
 /* ------------------------------------------------------------------------------------------------
  * Token embedding (ESM-2): x[t,:] = table[ids[t],:] * scale[b] * mask[t], with the token-dropout

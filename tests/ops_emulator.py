@@ -51,8 +51,19 @@ def drop_hash32(seed, idx):
     return h ^ (h >> 16)
 
 
+_DROP_EPOCH = None
+
+
+def set_dropout_epoch(epoch):
+    """csrc/common.h drop_seed_eff: while a one-element tensor is registered, every site uses seed + epoch * 0x9E3779B9."""
+    global _DROP_EPOCH
+    _DROP_EPOCH = epoch
+
+
 def drop_mult(p, seed, idx):
     """keep / (1 - p) multiplier for element indices idx (any shape, int64)."""
+    if _DROP_EPOCH is not None:
+        seed = (int(seed) + (int(_DROP_EPOCH.item()) & 0xFFFFFFFF) * 0x9E3779B9) & 0xFFFFFFFF
     t = p * 4294967296.0
     thr = 1 if t < 1.0 else (4294967295 if t >= 4294967295.0 else int(t))
     return (drop_hash32(seed, idx) >= thr).float() / (1.0 - p)

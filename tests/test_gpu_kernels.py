@@ -881,6 +881,49 @@ def test_gemm_wgrad_f32_one_launch_for_few_rows(dev, M, N, K):
     assert none is None and torch.equal(dw2, dw)
 
 
+def test_dropout_epoch_word_shifts_the_seed_of_every_site(dev):
+    """clipk_set_dropout_epoch (hipGraph replay of a training step with nn.TransformerEncoderLayer's dropout active,
+    rna_clip_codes.ipynb:1915): while a device word e is registered every dropout site must behave exactly as with
+    seed + e * 0x9E3779B9 and nothing registered; after clearing it the plain seed is back.  Sites: f32 dropout, GEMM
+    epilogue, bf16 and f32 attention (forward and backward), LayerNorm-backward's bf16 output."""
+    ops = _ops()
+    p, seed, e = 0.25, 1234567, 3
+    seed2 = (seed + e * 0x9E3779B9) & 0xFFFFFFFF
+    B, L, H, D = 2, 64, 2, 32
+    x = _rand((96, 160), dev, 81)
+    a16, b16 = _rand((96, 64), dev, 82).to(torch.bfloat16), _rand((160, 64), dev, 83).to(torch.bfloat16)
+    qkv16 = _rand((B * L, 3 * H * D), dev, 84).to(torch.bfloat16)
+    do16 = _rand((B * L, H * D), dev, 85).to(torch.bfloat16)
+    qkv32, do32 = qkv16.float(), do16.float()
+    gamma, beta = _rand((160,), dev, 86), _rand((160,), dev, 87)
+    _, _, mean, rstd = ops.layernorm_fwd(x, gamma, beta, 1e-5)
+
+    def run(sd):
+        out = [ops.dropout_f32(x, (p, sd)), ops.gemm_nt(a16, b16, dropout=(p, sd))]
+        o, lse = ops.attn_fwd(qkv16, B, L, H, D, q_scale=D ** -0.5, dropout=(p, sd))
+        out += [o, ops.attn_bwd(qkv16, o, do16, lse, B, L, H, D, q_scale=D ** -0.5, dropout=(p, sd))]
+        o32, lse32 = ops.attn_f32_fwd(qkv32, B, L, H, D, q_scale=D ** -0.5, dropout=(p, sd))
+        out += [o32, ops.attn_f32_bwd(qkv32, o32, do32, lse32, B, L, H, D, q_scale=D ** -0.5, dropout=(p, sd))]
+        out.append(ops.layernorm_bwd(x, x, gamma, beta, mean, rstd, want_f32=False, want_bf16=True, dropout_bf16=(p, sd))[1])
+        return [t.clone() for t in out]
+    plain, shifted = run(seed), run(seed2)
+    assert not torch.equal(plain[0], shifted[0])
+    word = torch.tensor([e], dtype=torch.int32, device=dev)
+    ops.set_dropout_epoch(word)
+    try:
+        with_word = run(seed)
+        word.fill_(0)
+        zero_word = run(seed)
+    finally:
+        ops.set_dropout_epoch(None)
+    for i, (a, b) in enumerate(zip(with_word, shifted)):
+        assert torch.equal(a, b), f"site {i}: epoch word != shifted seed"
+    for i, (a, b) in enumerate(zip(zero_word, plain)):
+        assert torch.equal(a, b), f"site {i}: epoch 0 != plain seed"
+    for i, (a, b) in enumerate(zip(run(seed), plain)):
+        assert torch.equal(a, b), f"site {i}: cleared word still in effect"
+
+
 def test_embed_fwd_out_of_range_id_is_loud(dev):
     """An id outside the table must never read memory: its row is NaN, every other row is exact."""
     ops = _ops()

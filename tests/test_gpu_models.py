@@ -536,6 +536,63 @@ def test_graphed_train_step_equals_eager_steps(dev, precision, two_streams):
     assert eager[-1] < eager[0]
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_graphed_train_step_with_active_dropout_draws_new_masks_per_replay(dev, precision, monkeypatch):
+    """GraphedTrainStep with nn.TransformerEncoderLayer's dropout ACTIVE (the configuration the notebook trains,
+    rna_clip_codes.ipynb:1915, :2061-2089).  Replay k must be the eager step whose dropout sites use seed + k * 0x9E3779B9
+    (the epoch word the captured step increments): with the encoders' host seeds pinned, three replays equal three eager
+    steps made with the word set to 0, 1, 2 - losses and every weight, bit for bit - and differ from steps that repeat
+    epoch 0's masks."""
+    import clip_dplm_amd as K
+    from clip_dplm_amd import ops
+    from clip_dplm_amd.encoders import TransformerSeqEncoder
+    from clip_dplm_amd.training import GraphedTrainStep
+    pdrop = 0.2
+    monkeypatch.setattr(TransformerSeqEncoder, "_draw_dropout",
+                        lambda self: (pdrop, [[101 + 4 * i, 102 + 4 * i, 103 + 4 * i, 104 + 4 * i]
+                                              for i in range(self.num_layers)]) if self.training else None)
+
+    def build():
+        torch.manual_seed(1)
+        m = K.RNARBPCLIPModel(rna_dim=40, rbp_dim=128, projection_dim=64, dropout=pdrop, precision=precision)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0                                 # torch's own generator is not what this test pins
+        return m.to(dev).train()
+    g = torch.Generator().manual_seed(3)
+    rna, rbp = torch.randn(32, 6, 40, generator=g).to(dev), torch.randn(32, 9, 128, generator=g).to(dev)
+
+    def eager(epochs):
+        m = build()
+        o = K.FusedAdamW(m, lr=1e-3, weight_decay=0.01, max_grad_norm=1.0)
+        word = torch.zeros(1, dtype=torch.int32, device=dev)
+        ops.set_dropout_epoch(word)
+        try:
+            losses = []
+            for e in epochs:
+                word.fill_(e)
+                o.zero_grad()
+                loss = m(rna, rbp)[2]
+                loss.backward()
+                o.step()
+                losses.append(loss.item())
+        finally:
+            ops.set_dropout_epoch(None)
+        return losses, o.flat.data.clone()
+    want, w_want = eager([0, 1, 2])
+    same_masks, _ = eager([0, 0, 0])
+    mg = build()
+    og = K.FusedAdamW(mg, lr=1e-3, weight_decay=0.01, max_grad_norm=1.0)
+    step = GraphedTrainStep(mg, og, lambda a, b: mg(a, b)[2], (rna, rbp))
+    got = [step(rna, rbp).item() for _ in range(3)]
+    assert got == want, (got, want)
+    assert torch.equal(og.flat.data, w_want)
+    assert got[1:] != same_masks[1:]
+    no_drop = build().eval()
+    with torch.no_grad():
+        assert abs(no_drop(rna, rbp)[2].item() - want[0]) > 1e-4       # the dropout was really active
+
+
 @pytest.mark.parametrize("model_name", ["notebook", "trimodal", "pair_clip"])
 def test_towers_on_side_streams_give_the_same_step(dev, model_name):
     """`RNARBPCLIPModel.dual_stream` / `ContrastiveModel.multi_stream`: the towers (independent up to the loss,
