@@ -55,11 +55,37 @@ __device__ __forceinline__ void stage_rows(float* dst, const float* src, long ld
                                            int S, float mul, int tid) {
   const int lpr_log = D <= 16 ? 4 : (D <= 32 ? 5 : 6);
   const int tx = tid & ((1 << lpr_log) - 1), ty = tid >> lpr_log, rows_per_pass = 256 >> lpr_log;
-  for (int j = ty; j < nrows; j += rows_per_pass) {
-    const int r = r0 + j;
-    const float* s = src + (row0 + (r < L ? r : 0)) * ld;
-    for (int d = tx; d < S; d += (1 << lpr_log)) dst[j * S + d] = (r < L && d < D) ? s[d] * mul : 0.f;
+  // Up to 4 rows x 4 column strides = 16 loads in flight per thread before the first LDS store: left as one load -> wait ->
+  // store per iteration (run-time trip counts, no unrolling) a 64-row tile was 48 dependent memory round trips - 20 us of the
+  // 27-us forward of the sliced notebook model (L = 32 samples, D = 160).  Clamped addresses + selects: no branch around a
+  // load; rows past the sequence end are zero-filled without touching memory.
+  constexpr int U = 4, C = 4;                                  // S <= 196 floats = 4 strides of 64 (3 of 16 / 32 for short heads)
+  const float* base = src + row0 * ld;
+  const int live = L - r0 < nrows ? (L - r0 > 0 ? L - r0 : 0) : nrows;      // rows [0, live) exist
+  for (int j0 = ty; j0 < live; j0 += rows_per_pass * U) {
+    float v[U][C];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = r0 + j0 + u * rows_per_pass;
+      const unsigned ro = (unsigned)(r < L ? r : 0) * (unsigned)ld;     // 32-bit offsets from one uniform base: L * ld < 2^31
+#pragma unroll                                                          // (checked on the host), one VGPR per address
+      for (int c = 0; c < C; ++c) {
+        const int d = tx + (c << lpr_log);
+        v[u][c] = base[ro + (unsigned)(d < D ? d : 0)];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u * rows_per_pass;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const int d = tx + (c << lpr_log);
+        if (j < live && d < S) dst[j * S + d] = d < D ? v[u][c] * mul : 0.f;
+      }
+    }
   }
+  for (int j = live + ty; j < nrows; j += rows_per_pass)
+    for (int d = tx; d < S; d += (1 << lpr_log)) dst[j * S + d] = 0.f;
 }
 
 // acc[r] += <rowsA[r] (wave-uniform rows, broadcast reads), rowB (this lane's row)> over the padded head dim, d ascending
@@ -382,7 +408,7 @@ int set_dropout(AF& p, float dropout_p, unsigned seed) {
 
 int check(const void* qkv, int B, int L, int H, int D) {
   if (!qkv || B <= 0 || L <= 0 || H <= 0 || D <= 0) return CLIPK_ERR_BAD_ARG;
-  if (D > 192 || H > 65535 || B > 65535) return CLIPK_ERR_UNSUPPORTED;
+  if (D > 192 || H > 65535 || B > 65535 || (long)L * 3 * H * D >= (1L << 31)) return CLIPK_ERR_UNSUPPORTED;
   if (!aligned16(qkv)) return CLIPK_ERR_BAD_ARG;
   return CLIPK_OK;
 }
