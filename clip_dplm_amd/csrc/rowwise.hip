@@ -89,6 +89,72 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwd p) {
   }
 }
 
+// Wide rows (cols > 2048: the 2560-wide hidden LayerNorms of the notebook's projection heads, rna_clip_codes.ipynb:1887-1903):
+// one WORKGROUP per row, the four waves take interleaved 256-float segments (chunk = lane + 64 (4 v + wave)), row sums meet
+// in LDS.  The one-wave-per-row form needs 20 float4 per lane and array (560 registers in the backward: it lived in scratch,
+// 48 us for 32 rows).  f32 in / f32 or bf16 out like the narrow kernel; the row statistics are sums of four wave sums.
+template <int VPW, bool XBF16>
+__global__ __launch_bounds__(256) void ln_fwd_wide_kernel(const LnFwd p) {
+  __shared__ float red[2][4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nch = p.cols >> 2;
+  f32x4 g[VPW], b[VPW];
+#pragma unroll
+  for (int v = 0; v < VPW; ++v) {
+    const int c = lane + 64 * (4 * v + wid);
+    g[v] = f32x4{0.f, 0.f, 0.f, 0.f}; b[v] = g[v];
+    if (c < nch) {
+      g[v] = *reinterpret_cast<const f32x4*>(p.gamma + 4 * c);
+      b[v] = *reinterpret_cast<const f32x4*>(p.beta + 4 * c);
+    }
+  }
+  const float inv_n = 1.0f / (float)p.cols;
+  for (int row = blockIdx.x; row < p.rows; row += gridDim.x) {
+    f32x4 x[VPW];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPW; ++v) {
+      const int c = lane + 64 * (4 * v + wid);
+      x[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < nch) x[v] = load4<XBF16>(p.x, (long)row * p.ldx + 4 * c);
+      s += (x[v][0] + x[v][1]) + (x[v][2] + x[v][3]);
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[0][wid] = s;
+    __syncthreads();
+    const float mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPW; ++v) {
+      const int c = lane + 64 * (4 * v + wid);
+      if (c < nch) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = x[v][e] - mean; q += d * d; }
+      }
+    }
+    q = wave_sum(q);
+    if (lane == 0) red[1][wid] = q;
+    __syncthreads();                       // (also: every wave has read red[0] before the next row overwrites it)
+    const float var = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) * inv_n;
+    const float rstd = rsqrtf(var + p.eps);
+    if (threadIdx.x == 0) {
+      if (p.mean) p.mean[row] = mean;
+      if (p.rstd) p.rstd[row] = rstd;
+    }
+#pragma unroll
+    for (int v = 0; v < VPW; ++v) {
+      const int c = lane + 64 * (4 * v + wid);
+      if (c < nch) {
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = act_apply((x[v][e] - mean) * rstd * g[v][e] + b[v][e], p.act);
+        if (p.y_f32) *reinterpret_cast<f32x4*>(p.y_f32 + (long)row * p.ldy + 4 * c) = y;
+        if (p.y_bf16) store4_bf16(p.y_bf16, (long)row * p.ldy + 4 * c, y);
+      }
+    }
+  }
+}
+
 // LayerNorm + masked mean over the L rows of each sample in one pass (the encoders' final LayerNorm followed by the
 // pooling of configuration_hybrid_clip.py:109 use_mean_pooling / tf_clip_codes (1).ipynb:1188): the normalised rows
 // are never written (2 x rows x cols x 4 B less per tower and step: one write here, one read by the pooling kernel).
@@ -300,6 +366,91 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwd p) {
     float a = 0.f;
     for (int w = 0; w < nw; ++w) a += sm[w * 2 * p.cols + i];
     p.part[(long)blockIdx.x * 2 * p.cols + i] = a;
+  }
+}
+
+// Wide rows, backward (see ln_fwd_wide_kernel): one workgroup per row, f32 dy / x, optional f32 residual-path gradient;
+// every wave keeps the dgamma / dbeta partials of ITS columns and writes them to the block's partial row itself.
+template <int VPW>
+__global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const LnBwd p) {
+  __shared__ float red[2][4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nch = p.cols >> 2;
+  f32x4 g[VPW], b[VPW], dg[VPW], db[VPW];
+#pragma unroll
+  for (int v = 0; v < VPW; ++v) {
+    const int c = lane + 64 * (4 * v + wid);
+    g[v] = f32x4{0.f, 0.f, 0.f, 0.f}; b[v] = g[v]; dg[v] = g[v]; db[v] = g[v];
+    if (c < nch) {
+      g[v] = *reinterpret_cast<const f32x4*>(p.gamma + 4 * c);
+      if (p.act != CLIPK_ACT_NONE) b[v] = *reinterpret_cast<const f32x4*>(p.beta + 4 * c);
+    }
+  }
+  const float inv_n = 1.0f / (float)p.cols;
+  for (int row = blockIdx.x; row < p.rows; row += gridDim.x) {
+    const float mean = p.mean[row], rstd = p.rstd[row];
+    f32x4 xh[VPW], gy[VPW], addv[VPW];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPW; ++v) {
+      const int c = lane + 64 * (4 * v + wid);
+      addv[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.dx_add && c < nch) addv[v] = load4<false>(p.dx_add, (long)row * p.lddx + 4 * c);
+    }
+#pragma unroll
+    for (int v = 0; v < VPW; ++v) {
+      const int c = lane + 64 * (4 * v + wid);
+      xh[v] = f32x4{0.f, 0.f, 0.f, 0.f}; gy[v] = xh[v];
+      if (c < nch) {
+        const f32x4 xv = load4<false>(p.x, (long)row * p.ldx + 4 * c);
+        f32x4 dyv = load4<false>(p.dy, (long)row * p.lddy + 4 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xhat = (xv[e] - mean) * rstd;
+          if (p.act != CLIPK_ACT_NONE) dyv[e] *= act_grad(xhat * g[v][e] + b[v][e], p.act);
+          xh[v][e] = xhat;
+          dg[v][e] += dyv[e] * xhat;
+          db[v][e] += dyv[e];
+          const float gg = dyv[e] * g[v][e];
+          gy[v][e] = gg;
+          s1 += gg; s2 += gg * xhat;
+        }
+      }
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    __syncthreads();                       // the previous row's sums have been read by every wave
+    if (lane == 0) { red[0][wid] = s1; red[1][wid] = s2; }
+    __syncthreads();
+    const float c1 = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) * inv_n;
+    const float c2 = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) * inv_n;
+#pragma unroll
+    for (int v = 0; v < VPW; ++v) {
+      const int c = lane + 64 * (4 * v + wid);
+      if (c < nch) {
+        f32x4 dx;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dx[e] = rstd * (gy[v][e] - c1 - xh[v][e] * c2);
+        dx += addv[v];
+        if (p.dx_f32) *reinterpret_cast<f32x4*>(p.dx_f32 + (long)row * p.lddx + 4 * c) = dx;
+        if (p.dx_bf16) {
+          if (p.drop_thr) {
+            const unsigned long long base = (unsigned long long)row * (unsigned)p.cols + 4u * c;
+            const unsigned dseed = drop_seed_eff(p.drop_seed, p.drop_epoch);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dx[e] *= drop_mul(dseed, base + e, p.drop_thr, p.drop_scale);
+          }
+          store4_bf16(p.dx_bf16, (long)row * p.lddx + 4 * c, dx);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < VPW; ++v) {            // this block's partial row: every wave writes its own columns
+    const int c = lane + 64 * (4 * v + wid);
+    if (c < nch) {
+      *reinterpret_cast<f32x4*>(p.part + (long)blockIdx.x * 2 * p.cols + 4 * c) = dg[v];
+      *reinterpret_cast<f32x4*>(p.part + (long)blockIdx.x * 2 * p.cols + p.cols + 4 * c) = db[v];
+    }
   }
 }
 
@@ -571,6 +722,12 @@ extern "C" int clipk_layernorm_fwd(const void* x, int x_dtype, int64_t ldx, cons
   LnFwd p{x, (long)ldx, gamma, beta, eps, act, y_f32, y_bf16, (long)ldy, mean, rstd, rows, cols};
   const int blocks = ln_blocks_fwd(rows);
   hipStream_t st = (hipStream_t)stream;
+  if (cols > 2048 && cols <= 5120) {                        // wide rows: one workgroup per row (the choice depends on the
+    const int wb = rows < 2048 ? rows : 2048;               // row WIDTH only: a row's arithmetic never depends on the batch)
+    if (x_dtype == CLIPK_BF16) hipLaunchKernelGGL((ln_fwd_wide_kernel<5, true>), dim3(wb), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((ln_fwd_wide_kernel<5, false>), dim3(wb), dim3(256), 0, st, p);
+    return clipk_check_launch();
+  }
 #define CALL(V)                                                                                   \
   if (x_dtype == CLIPK_BF16) hipLaunchKernelGGL((ln_fwd_kernel<V, true>), dim3(blocks), dim3(256), 0, st, p); \
   else hipLaunchKernelGGL((ln_fwd_kernel<V, false>), dim3(blocks), dim3(256), 0, st, p)
@@ -607,8 +764,12 @@ extern "C" int clipk_layernorm_bwd(const void* dy, int dy_dtype, int64_t lddy, c
   }
   hipStream_t st = (hipStream_t)stream;
   const size_t lds = (size_t)4 * 2 * cols * sizeof(float);
+  const bool wide = cols > 2048 && cols <= 5120 && dy_dtype == CLIPK_F32 && x_dtype == CLIPK_F32 && !p.add_bf16;
+  if (wide)                                     // one workgroup per row (ln_bwd_wide_kernel); `blocks` partial rows as below
+    hipLaunchKernelGGL((ln_bwd_wide_kernel<5>), dim3(blocks), dim3(256), 0, st, p);
 #define CALL(V)                                                                                                   \
   do {                                                                                                            \
+    if (wide) break;                                                                                              \
     if (p.add_bf16)                             /* bf16 gradient stream: bf16 dy, f32 x (checked above) */       \
       launch_ln_bwd<V, true, false, true>(p, blocks, lds, st);                                                    \
     else if (dy_dtype == CLIPK_BF16 && x_dtype == CLIPK_BF16)                                                     \

@@ -340,9 +340,12 @@ def test_simce_sharded_equals_global(dev):
 
 
 # ------------------------------------------------------------------------------------------------ row-wise
-@pytest.mark.parametrize("rows,cols", [(256, 128), (1000, 480), (64, 1024), (33, 2560), (512, 768), (16, 120)])
+@pytest.mark.parametrize("rows,cols", [(256, 128), (1000, 480), (64, 1024), (33, 2560), (512, 768), (16, 120),
+                                       (2500, 2560), (7, 5120), (9, 4100)])
 @pytest.mark.parametrize("xdt", [torch.float32, torch.bfloat16])
 def test_layernorm(dev, rows, cols, xdt):
+    """clipk_layernorm_fwd / _bwd against torch autograd; cols > 2048 take the one-workgroup-per-row kernels (forward both
+    input types, backward f32), with more rows than workgroups and a ragged width among the cases."""
     ops = _ops()
     x = _rand((rows, cols), dev, 20, 2.0).to(xdt)
     g, b = _rand((cols,), dev, 21) * 0.2 + 1.0, _rand((cols,), dev, 22) * 0.1
