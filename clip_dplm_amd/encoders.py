@@ -845,9 +845,9 @@ class TransformerSeqEncoder(nn.Module):
             return pool(y, None if mask_u8 is None else mask_u8.view(B, L), "mean")
         return y
 
-    def forward(self, x, src_key_padding_mask=None, _pool=False):
+    def forward(self, x, src_key_padding_mask=None, _pool=False, _valid_u8=None):
         B, L, E = x.shape
-        mask_u8 = None
+        mask_u8 = _valid_u8                 # (internal callers that already hold the kernels' form: uint8 [B, L], 1 = valid)
         if src_key_padding_mask is not None:
             mask_u8 = (~src_key_padding_mask.bool()).to(torch.uint8).contiguous()      # kernels take 1 = valid
         if self.precision == "f32":

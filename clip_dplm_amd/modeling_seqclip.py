@@ -86,7 +86,9 @@ class RNARBPCLIPModel(nn.Module):
             emb = emb[:, :1]                                              # position 0 is all `enc[:, 0]` depends on
         valid = create_padding_mask(emb)                                  # [B, L]
         x = torch.nan_to_num(emb, 0.0).transpose(0, 1).contiguous()       # [L, B, D]
-        y = encoder(x, src_key_padding_mask=~valid.transpose(0, 1))       # keys = samples
+        # keys = samples.  The kernels take 1 = valid as bytes: the bool mask reinterpreted, instead of the round trip
+        # through nn.TransformerEncoder's padding-mask convention (~valid here, ~mask and a cast inside: three launches)
+        y = encoder(x, _valid_u8=valid.transpose(0, 1).contiguous().view(torch.uint8))
         return y[0]                                                       # == enc[:, 0] in the notebook's layout
 
     def forward(self, rna_emb, rbp_emb):
@@ -219,6 +221,11 @@ class ProteinRNACLIP(nn.Module):
             main.wait_stream(s)
         for t in ers + eps:
             t.record_stream(main)
+        # the backward replays each tower on its stream and the kernels add parameter gradients straight into .grad views
+        # there: JoinStreamsFn makes the calling stream wait for the tower streams when the backward pass ends (the
+        # autograd engine itself only syncs the streams of AccumulateGrad leaves)
+        joined = KF.JoinStreamsFn.apply(tuple(self._streams), *(ers + eps))
+        ers, eps = list(joined[:nmb]), list(joined[nmb:])
         er = ers[0] if nmb == 1 else torch.cat(ers, 0)
         ep = eps[0] if nmb == 1 else torch.cat(eps, 0)
         return er, ep
