@@ -202,6 +202,13 @@ __global__ void wgrad_reduce_kernel(const float* slab, const float* bslab, int s
     const long sstride = (long)N * K / 4;
     const f32x4* src = reinterpret_cast<const f32x4*>(slab) + i;
     int s = 0;
+    for (; s + 8 <= splits; s += 8) {                        // eight loads in flight (16 - 64 slabs: the launch is a chain of
+      f32x4 v[8];                                            // memory round trips); same summation order as the 4-wide step
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = src[(long)(s + e) * sstride];
+      a += (v[0] + v[1]) + (v[2] + v[3]);
+      a += (v[4] + v[5]) + (v[6] + v[7]);
+    }
     for (; s + 4 <= splits; s += 4) {                        // four loads in flight; fixed summation order
       const f32x4 v0 = src[(long)s * sstride], v1 = src[(long)(s + 1) * sstride];
       const f32x4 v2 = src[(long)(s + 2) * sstride], v3 = src[(long)(s + 3) * sstride];
