@@ -170,8 +170,9 @@ class GraphedTrainStep:
     torch's own `nn.Dropout` modules (the projection heads') are replay-safe by themselves: torch's device generator hands a
     captured kernel its Philox offset through device memory and advances it per replay.
 
-    Restrictions: fixed input shapes; single process (no collectives).  The returned loss is a static device tensor
-    overwritten by the next call (`.item()` / `.clone()` it to keep it)."""
+    Inputs of another shape than the example (the short last batch of an epoch) run the same step eagerly (`eager_step`).
+    Restrictions: single process (no collectives).  The returned loss of a replay is a static device tensor overwritten by
+    the next replay (`.item()` / `.clone()` it to keep it)."""
 
     def __init__(self, model, optimizer, loss_fn, example_inputs, warmup: int = 3):
         if getattr(optimizer, "group", None) is not None:
@@ -228,7 +229,20 @@ class GraphedTrainStep:
         self.opt.step()
         return loss.detach()
 
+    def eager_step(self, *inputs, lr=None):
+        """The same training step issued eagerly on `inputs` of any shape (what __call__ falls back to)."""
+        KF.mark_weights_dirty()        # replays changed the weights behind the host's back: per-call bf16 copies are rebuilt
+        self.opt.zero_grad()
+        loss = self.loss_fn(*inputs)
+        loss.backward()
+        self.opt.step(lr=lr)
+        return loss.detach()
+
     def __call__(self, *inputs, lr=None):
+        if any(tuple(src.shape) != tuple(dst.shape) for dst, src in zip(self.static_in, inputs)):
+            # another shape than the captured one - the short last batch of an epoch (rna_clip_codes.ipynb:2061-2089 iterates
+            # a DataLoader without drop_last): the same step, issued eagerly; optimiser state and step count carry on
+            return self.eager_step(*inputs, lr=lr)
         for dst, src in zip(self.static_in, inputs):
             dst.copy_(src, non_blocking=True)
         self.opt.prepare_step(lr)

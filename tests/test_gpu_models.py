@@ -537,6 +537,40 @@ def test_graphed_train_step_equals_eager_steps(dev, precision, two_streams):
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_graphed_train_step_falls_back_to_eager_for_a_short_last_batch(dev, precision):
+    """An epoch's last batch is shorter than the captured shape (the notebook's DataLoader has no drop_last,
+    rna_clip_codes.ipynb:2061-2089): GraphedTrainStep runs that step eagerly and carries on replaying - losses and weights of
+    [full, full, short, full] identical to the same four steps issued eagerly."""
+    import clip_dplm_amd as K
+    from clip_dplm_amd.training import GraphedTrainStep
+
+    def build():
+        torch.manual_seed(1)
+        m = K.RNARBPCLIPModel(rna_dim=40, rbp_dim=128, projection_dim=64, dropout=0.0, precision=precision)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        return m.to(dev).train()
+    g = torch.Generator().manual_seed(3)
+    batches = [(torch.randn(b, 6, 40, generator=g).to(dev), torch.randn(b, 9, 128, generator=g).to(dev)) for b in (32, 32, 20, 32)]
+    me = build()
+    oe = K.FusedAdamW(me, lr=1e-3, weight_decay=0.01, max_grad_norm=1.0)
+    eager = []
+    for rna, rbp in batches:
+        oe.zero_grad()
+        loss = me(rna, rbp)[2]
+        loss.backward()
+        oe.step()
+        eager.append(loss.item())
+    mg = build()
+    og = K.FusedAdamW(mg, lr=1e-3, weight_decay=0.01, max_grad_norm=1.0)
+    step = GraphedTrainStep(mg, og, lambda a, b: mg(a, b)[2], batches[0])
+    got = [step(rna, rbp).item() for rna, rbp in batches]
+    assert got == eager, (got, eager)
+    assert og.step_count == 4 and torch.equal(og.flat.data, oe.flat.data)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
 def test_graphed_train_step_with_active_dropout_draws_new_masks_per_replay(dev, precision, monkeypatch):
     """GraphedTrainStep with nn.TransformerEncoderLayer's dropout ACTIVE (the configuration the notebook trains,
     rna_clip_codes.ipynb:1915, :2061-2089).  Replay k must be the eager step whose dropout sites use seed + k * 0x9E3779B9
