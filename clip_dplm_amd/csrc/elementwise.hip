@@ -112,7 +112,7 @@ __global__ void act_bwd_kernel(const float* dy, const float* x, float* dx, int a
 __global__ void axpby_dev_kernel(const float* a, const float* b, const float* s, float* y, long n) {
   const float sc = s[0];
   const long stride = (long)gridDim.x * blockDim.x;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) y[i] = a[i] + sc * b[i];
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += stride) y[i] = a ? a[i] + sc * b[i] : sc * b[i];
 }
 
 // y = x * keep(seed, i) / (1 - p) (+ addend): nn.Dropout on an f32 tensor with the kernels' counter-based mask (index =
@@ -507,7 +507,7 @@ extern "C" int clipk_dact(const void* dy, int dy_dtype, const void* aux_bf16, in
   return clipk_check_launch();
 }
 extern "C" int clipk_axpby_dev(const float* a, const float* b, const float* s, float* y, int64_t n, void* stream) {
-  if (!a || !b || !s || !y || n <= 0) return CLIPK_ERR_BAD_ARG;
+  if (!b || !s || !y || n <= 0) return CLIPK_ERR_BAD_ARG;        // a == NULL: y = s * b
   hipLaunchKernelGGL(axpby_dev_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, a, b, s, y, (long)n);
   return clipk_check_launch();
 }

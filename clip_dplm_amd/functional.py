@@ -495,7 +495,7 @@ class SkipScaleFn(torch.autograd.Function):
     def backward(ctx, dy):
         proj, scale = ctx.saved_tensors
         dy = dy.contiguous()
-        dproj = ops.axpby_dev(torch.zeros_like(dy), dy, scale)
+        dproj = ops.axpby_dev(None, dy, scale)
         dscale = (dy * proj).sum().reshape(scale.shape)          # scalar reduction: plumbing
         return dy, dproj, dscale
 

@@ -89,7 +89,8 @@ class RNARBPCLIPModel(nn.Module):
         # keys = samples.  The kernels take 1 = valid as bytes: the bool mask reinterpreted, instead of the round trip
         # through nn.TransformerEncoder's padding-mask convention (~valid here, ~mask and a cast inside: three launches)
         y = encoder(x, _valid_u8=valid.transpose(0, 1).contiguous().view(torch.uint8))
-        return y[0]                                                       # == enc[:, 0] in the notebook's layout
+        # == enc[:, 0] in the notebook's layout (one position: a view - a select's backward is a zero-fill + a copy launch)
+        return y.view(y.shape[1], y.shape[2]) if y.shape[0] == 1 else y[0]
 
     def forward(self, rna_emb, rbp_emb):
         if self.dual_stream and rna_emb.is_cuda:

@@ -175,7 +175,9 @@ class ContrastiveModel(nn.Module):
 
     @staticmethod
     def _first(enc):
-        return enc[:, 0] if enc.dim() == 3 else enc        # see the module docstring (upstream defect A-19)
+        if enc.dim() == 3:                                 # see the module docstring (upstream defect A-19)
+            return enc.reshape(enc.shape[0], enc.shape[2]) if enc.shape[1] == 1 else enc[:, 0]
+        return enc
 
     def _sl(self, x):
         return x[:, :1] if (self.slice_first_position and x.dim() == 3) else x

@@ -666,8 +666,9 @@ def dact(dy, aux_bf16, act):
 
 
 def axpby_dev(a, b, s):
-    y = torch.empty_like(a)
-    check(_lib().clipk_axpby_dev(a.data_ptr(), b.data_ptr(), s.data_ptr(), y.data_ptr(), a.numel(), _stream()),
+    """a + s * b with s a 1-element device tensor (a = None: s * b)."""
+    y = torch.empty_like(b)
+    check(_lib().clipk_axpby_dev(ptr(a), b.data_ptr(), s.data_ptr(), y.data_ptr(), b.numel(), _stream()),
           "clipk_axpby_dev")
     return y
 

@@ -312,7 +312,7 @@ int clipk_act_fwd(const float* x, float* y, int act, int64_t n, void* stream);
 int clipk_act_bwd(const float* dy, const float* x, float* dx, int act, int64_t n, void* stream);
 /* out_bf16 = dy * act'(aux_bf16): activation backward between two Linear layers; dy f32 or bf16. */
 int clipk_dact(const void* dy, int dy_dtype, const void* aux_bf16, int act, void* out_bf16, int64_t n, void* stream);
-/* y = a + s[0] * b  (skip + layer_scale * projected, old/clip_opt.py:41-44), f32. */
+/* y = a + s[0] * b  (skip + layer_scale * projected, old/clip_opt.py:41-44), f32; a == NULL: y = s[0] * b (its backward). */
 int clipk_axpby_dev(const float* a, const float* b, const float* s, float* y, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

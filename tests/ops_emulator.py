@@ -391,7 +391,7 @@ def dact(dy, aux_bf16, act):
 
 
 def axpby_dev(a, b, s):
-    return a + s * b
+    return s * b if a is None else a + s * b
 
 
 def _attn_math(qkv, B, L, H, D, key_mask, rope, q_scale, dropout=None, row0=0, Lstride=None):
