@@ -58,6 +58,8 @@ SIGNATURES = {
     "clipk_simce_workspace": (_sz, [_i, _i, _i]),
     "clipk_simce_lse": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "clipk_simce_grad": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _sz, _vp]),
+    "clipk_simce_grad_scaled": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "clipk_ce_combine": (_i, [_vp, _vp, _vp, _vp, _i, _f, _f, _f, _vp, _vp]),
     "clipk_simce_pairs_workspace": (_sz, [_i, _i, _i]),
     "clipk_simce_lse_pairs": (_i, [_vp, _i, _i, _i, C.POINTER(_i), _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "clipk_simce_grad_pairs": (_i, [_vp, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), _i, _vp, _vp, _f, _f, _f, _vp, _vp,

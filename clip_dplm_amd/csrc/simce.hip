@@ -43,6 +43,7 @@ struct SP {
   // grad
   const float* lse_x; const float* lse_y;
   float w_row, w_col, inv_bg;
+  const float* upstream;   // device scalar multiplied into inv_bg (the loss' incoming gradient), or null
   float* slab;         // [ksplit][Mx][P]
   float* dsc_part;     // [ksplit][Mx]
   // logits / f32 Linear epilogue
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(512) void simce_kernel(const SP p) {
   const int label = p.label_offset + qg;        // its positive key
   float m_run = -INFINITY, l_run = 0.f, pos_v = 0.f;
   bool pos_hit = false;
+  const float ibg = (MODE == MODE_GRAD && p.upstream) ? p.inv_bg * p.upstream[0] : p.inv_bg;
   float lse_xi = 0.f, dsc = 0.f;
   f32x16 dx[PWMAX / 32];
   if (MODE == MODE_GRAD) {
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(512) void simce_kernel(const SP p) {
             gv += p.w_col * expf(sv - lse_yb[key]);
             if (key == label) gv -= (p.w_row + p.w_col);
           }
-          gv *= p.inv_bg;
+          gv *= ibg;
         }
         g[r] = gv;
         dsc += gv * s[r];
@@ -364,10 +366,6 @@ extern "C" int clipk_simce_lse_tiled_launch(const float* X, int Mx, const float*
                                             const float* scale, int label_offset, float* part_ml, float* pos,
                                             void* stream);
 extern "C" void clipk_simce_grad_tiled_plan(int Mx, int Nkeys, int* nqb, int* ksplit, int* tps, int* ntiles);
-extern "C" int clipk_simce_grad_tiled_launch(const float* X, int Mx, const float* Y, int Ny, const float* Yc, int Nc,
-                                             int P, const float* scale, int label_offset, const float* lse_x,
-                                             const float* lse_y, float w_row, float w_col, float inv_bg, float* slab,
-                                             float* dsc_part, void* stream);
 static bool use_tiled_grad(int Mx, int Nkeys, int P, int Pw) {
   const int mode = clipk_opt_get(OPT_SIMCE_KERNEL);
   if (P > 512) return false;
@@ -428,11 +426,65 @@ extern "C" int clipk_simce_lse(const float* X, int Mx, const float* Y, int Ny, c
   return clipk_check_launch();
 }
 
+// loss = (w_row * sum(lse_r - pos_r) + w_col * sum(lse_c - pos_c)) / bg in ONE launch (fixed summation order: strided
+// partial sums per thread, then a tree over the 256 threads): the reference's two F.cross_entropy means and their
+// average (rna_clip_codes.ipynb:1952-1953, old/ablation.py:16) were eight elementwise / reduce launches of 4.5 us each on
+// [B] vectors - a fifth of config 1's captured step.
+namespace {
+__global__ __launch_bounds__(256) void ce_combine_kernel(const float* lse_r, const float* pos_r, const float* lse_c,
+                                                         const float* pos_c, int n, float w_row, float w_col, float bg,
+                                                         float* loss) {
+  __shared__ float sr[256], sc[256];
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    a += lse_r[i] - pos_r[i];
+    if (lse_c) b += lse_c[i] - pos_c[i];
+  }
+  sr[threadIdx.x] = a; sc[threadIdx.x] = b;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { sr[threadIdx.x] += sr[threadIdx.x + s]; sc[threadIdx.x] += sc[threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float local = w_row * sr[0];
+    if (lse_c) local = local + w_col * sc[0];
+    loss[0] = local / bg;
+  }
+}
+}  // namespace
+extern "C" int clipk_ce_combine(const float* lse_r, const float* pos_r, const float* lse_c, const float* pos_c, int n,
+                                float w_row, float w_col, float bg, float* loss, void* stream) {
+  if (!lse_r || !pos_r || !loss || n <= 0 || (lse_c && !pos_c) || !(bg > 0.f)) return CLIPK_ERR_BAD_ARG;
+  hipLaunchKernelGGL(ce_combine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, lse_r, pos_r, lse_c, pos_c, n, w_row,
+                     w_col, bg, loss);
+  return clipk_check_launch();
+}
+
+extern "C" int clipk_simce_grad_tiled_launch(const float* X, int Mx, const float* Y, int Ny, const float* Yc, int Nc,
+                                             int P, const float* scale, int label_offset, const float* lse_x,
+                                             const float* lse_y, float w_row, float w_col, float inv_bg,
+                                             const float* upstream, float* slab, float* dsc_part, void* stream);
+
+extern "C" int clipk_simce_grad_scaled(const float* X, int Mx, const float* Y, int Ny, const float* Yc, int Nc,
+                                       int P, const float* scale, int label_offset,
+                                       const float* lse_x, const float* lse_y, float w_row, float w_col, float inv_bg,
+                                       const float* upstream, float* dX, float* dscale_partial,
+                                       void* workspace, size_t workspace_bytes, void* stream);
 extern "C" int clipk_simce_grad(const float* X, int Mx, const float* Y, int Ny, const float* Yc, int Nc,
                                 int P, const float* scale, int label_offset,
                                 const float* lse_x, const float* lse_y, float w_row, float w_col, float inv_bg,
                                 float* dX, float* dscale_partial,
                                 void* workspace, size_t workspace_bytes, void* stream) {
+  return clipk_simce_grad_scaled(X, Mx, Y, Ny, Yc, Nc, P, scale, label_offset, lse_x, lse_y, w_row, w_col, inv_bg, nullptr,
+                                 dX, dscale_partial, workspace, workspace_bytes, stream);
+}
+
+extern "C" int clipk_simce_grad_scaled(const float* X, int Mx, const float* Y, int Ny, const float* Yc, int Nc,
+                                       int P, const float* scale, int label_offset,
+                                       const float* lse_x, const float* lse_y, float w_row, float w_col, float inv_bg,
+                                       const float* upstream, float* dX, float* dscale_partial,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
   if (!X || !Y || !scale || !lse_x || !lse_y || !dX || !workspace || Nc < 0 || (Nc > 0 && !Yc))
     return CLIPK_ERR_BAD_ARG;
   Plan pl;
@@ -446,7 +498,7 @@ extern "C" int clipk_simce_grad(const float* X, int Mx, const float* Y, int Ny, 
     float* slab = (float*)workspace;
     float* dscp = slab + (size_t)ks3 * Mx * P;
     int rc = clipk_simce_grad_tiled_launch(X, Mx, Y, Ny, Yc, Nc, P, scale, label_offset, lse_x, lse_y, w_row, w_col,
-                                           inv_bg, slab, dscp, stream);
+                                           inv_bg, upstream, slab, dscp, stream);
     if (rc) return rc;
     long n4 = (long)Mx * P / 4;
     int blocks = (int)((n4 + 63) / 64); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
@@ -460,7 +512,7 @@ extern "C" int clipk_simce_grad(const float* X, int Mx, const float* Y, int Ny, 
   SP sp{};
   sp.X = X; sp.Mx = Mx; sp.Y = Y; sp.Ny = Ny; sp.Yc = Yc ? Yc : Y; sp.Nc = Nc;
   sp.P = P; sp.Pw = pl.Pw; sp.NW = pl.NW; sp.scale = scale; sp.label_offset = label_offset;
-  sp.lse_x = lse_x; sp.lse_y = lse_y; sp.w_row = w_row; sp.w_col = w_col; sp.inv_bg = inv_bg;
+  sp.lse_x = lse_x; sp.lse_y = lse_y; sp.w_row = w_row; sp.w_col = w_col; sp.inv_bg = inv_bg; sp.upstream = upstream;
   sp.slab = (float*)workspace; sp.dsc_part = (float*)workspace + (size_t)pl.ksplit * Mx * P;
   sp.ksplit = pl.ksplit; sp.tiles_per_split = pl.tps; sp.ntiles = pl.ntiles;
   int rc = launch<MODE_GRAD>(sp, pl, (hipStream_t)stream);

@@ -190,6 +190,7 @@ struct GP2 {
   const float* scale; int label_offset;
   const float* lse_x; const float* lse_y;
   float w_row, w_col, inv_bg;
+  const float* upstream;   // device scalar multiplied into inv_bg, or null
   float* slab;         // [ksplit][Mx][P]
   float* dsc_part;     // [ksplit][Mx]
   int tiles_per_split, ntiles;
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(256, 2) void simce_grad_tiled_kernel(const GP2 p) {
   const int qg = q0 + wn * 32 + li;
   const int label = p.label_offset + qg;
   const float lse_xi = p.lse_x[qg < p.Mx ? qg : p.Mx - 1];
+  const float ibg = p.upstream ? p.inv_bg * p.upstream[0] : p.inv_bg;
   const int npt = (P + 127) / 128;                                        // 32-row p tiles per wave: P/4 / 32
   const int pw = npt * 32;                                                // p rows per wave
   f32x16 dx[4][2];
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void simce_grad_tiled_kernel(const GP2 p) {
           gv += p.w_col * expf(sv - p.lse_y[key]);
           if (key == label) gv -= (p.w_row + p.w_col);
         }
-        gv *= p.inv_bg;
+        gv *= ibg;
       }
       dsc += gv * acc[r];
       gl[kl * TQ + wn * 32 + li] = gv;
@@ -352,13 +354,13 @@ extern "C" void clipk_simce_grad_tiled_plan(int Mx, int Nkeys, int* nqb, int* ks
 
 extern "C" int clipk_simce_grad_tiled_launch(const float* X, int Mx, const float* Y, int Ny, const float* Yc, int Nc,
                                              int P, const float* scale, int label_offset, const float* lse_x,
-                                             const float* lse_y, float w_row, float w_col, float inv_bg, float* slab,
-                                             float* dsc_part, void* stream) {
+                                             const float* lse_y, float w_row, float w_col, float inv_bg,
+                                             const float* upstream, float* slab, float* dsc_part, void* stream) {
   if (P > GPMAX) return CLIPK_ERR_UNSUPPORTED;
   GP2 p;
   p.X = X; p.Mx = Mx; p.Y = Y; p.Ny = Ny; p.Yc = Yc ? Yc : Y; p.Nc = Nc; p.P = P;
   p.scale = scale; p.label_offset = label_offset; p.lse_x = lse_x; p.lse_y = lse_y;
-  p.w_row = w_row; p.w_col = w_col; p.inv_bg = inv_bg; p.slab = slab; p.dsc_part = dsc_part;
+  p.w_row = w_row; p.w_col = w_col; p.inv_bg = inv_bg; p.upstream = upstream; p.slab = slab; p.dsc_part = dsc_part;
   int nqb, ksplit;
   clipk_simce_grad_tiled_plan(Mx, Ny + Nc, &nqb, &ksplit, &p.tiles_per_split, &p.ntiles);
   const size_t lds = (size_t)GRAD_LDS_FLOATS * sizeof(float);

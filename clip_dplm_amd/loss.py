@@ -34,6 +34,18 @@ def _gather_cat(t: torch.Tensor, group) -> torch.Tensor:
     return out.view((world,) + tuple(t.shape))
 
 
+_INF = {}
+
+
+def _inf_like(t: torch.Tensor) -> torch.Tensor:
+    """A read-only +inf vector of t's shape, made once per (device, length): the one-sided loss's unused direction."""
+    key = (str(t.device), t.numel())
+    v = _INF.get(key)
+    if v is None:
+        v = _INF[key] = torch.full((t.numel(),), float("inf"), dtype=torch.float32, device=t.device)
+    return v.view(t.shape)
+
+
 class ClipLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, scale, w_row, w_col, cache, group):
@@ -50,12 +62,19 @@ class ClipLossFn(torch.autograd.Function):
         off = rank * bl
         bg = world * bl
         lse_r, pos_r = _kernels.simce_lse(a, b_g, scale, label_offset=off, cache=cache)
-        local = w_row * (lse_r - pos_r).sum()
+        pos_c = None
         if w_col != 0.0:
             lse_c, pos_c = _kernels.simce_lse(b, a_g, scale, label_offset=off)
-            local = local + w_col * (lse_c - pos_c).sum()
         else:
-            lse_c = torch.full_like(lse_r, float("inf"))   # exp(s - inf) = 0: the unused direction contributes nothing
+            lse_c = _inf_like(lse_r)                       # exp(s - inf) = 0: the unused direction contributes nothing
+        if group is None:                                  # single process: sums, weights and the mean in one launch
+            out = _kernels.ce_combine(lse_r, pos_r, lse_c if pos_c is not None else None, pos_c, w_row, w_col, bg)
+            ctx.meta = (w_row, w_col, off, bg, cache)
+            ctx.save_for_backward(a, b, a_g, b_g, scale, lse_r, lse_c, lse_r, lse_c)
+            return out
+        local = w_row * (lse_r - pos_r).sum()
+        if pos_c is not None:
+            local = local + w_col * (lse_c - pos_c).sum()
         if group is not None:
             lses = _gather_cat(torch.stack([lse_r, lse_c]), group)          # [W, 2, Bl]
             lse_r_g = lses[:, 0].reshape(-1).contiguous()
@@ -72,13 +91,13 @@ class ClipLossFn(torch.autograd.Function):
         a, b, a_g, b_g, scale, lse_r, lse_c, lse_r_g, lse_c_g = ctx.saved_tensors
         w_row, w_col, off, bg, cache = ctx.meta
         # rows of a: row-direction softmax uses their own LSE, column direction the keys' LSE
-        da, dsa = _kernels.simce_grad(a, b_g, scale, lse_r, lse_c_g, w_row, w_col, 1.0 / bg, label_offset=off, cache=cache)
+        # the incoming gradient (1.0 from loss.backward()) is folded into the kernels' 1 / Bg factor: no `grad * g` launches
+        g = dloss.reshape(1).contiguous() if dloss.numel() == 1 else None
+        da, dsa = _kernels.simce_grad(a, b_g, scale, lse_r, lse_c_g, w_row, w_col, 1.0 / bg, label_offset=off, cache=cache,
+                                      upstream=g)
         # rows of b are the queries of the column direction
-        db, _ = _kernels.simce_grad(b, a_g, scale, lse_c, lse_r_g, w_col, w_row, 1.0 / bg, label_offset=off)
+        db, _ = _kernels.simce_grad(b, a_g, scale, lse_c, lse_r_g, w_col, w_row, 1.0 / bg, label_offset=off, upstream=g)
         dscale = dsa.sum().reshape(1)          # this rank's rows only; the optimiser sums parameter grads over ranks
-        if dloss.numel() == 1:
-            g = dloss.reshape(())
-            da, db, dscale = da * g, db * g, dscale * g
         return da, db, dscale, None, None, None, None
 
 

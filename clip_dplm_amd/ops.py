@@ -249,8 +249,19 @@ def simce_lse(x, y, scale, label_offset=0, cache=None):
     return lse, pos
 
 
-def simce_grad(x, y, scale, lse_x, lse_y, w_row, w_col, inv_bg, label_offset=0, cache=None):
-    _need_cuda(x, y, scale, lse_x, lse_y, cache)
+def ce_combine(lse_r, pos_r, lse_c, pos_c, w_row, w_col, bg):
+    """(w_row * sum(lse_r - pos_r) + w_col * sum(lse_c - pos_c)) / bg as a 0-d device tensor, one launch
+    (lse_c = pos_c = None: the one-sided loss)."""
+    _need_cuda(lse_r, pos_r, lse_c, pos_c)
+    out = torch.empty((), dtype=torch.float32, device=lse_r.device)
+    check(_lib().clipk_ce_combine(lse_r.data_ptr(), pos_r.data_ptr(), ptr(lse_c), ptr(pos_c), lse_r.numel(), float(w_row),
+                                  float(w_col), float(bg), out.data_ptr(), _stream()), "clipk_ce_combine")
+    return out
+
+
+def simce_grad(x, y, scale, lse_x, lse_y, w_row, w_col, inv_bg, label_offset=0, cache=None, upstream=None):
+    """upstream: 1-element device tensor multiplied into the gradient inside the kernel (the loss' grad_output)."""
+    _need_cuda(x, y, scale, lse_x, lse_y, cache, upstream)
     Mx, P = x.shape
     Ny = y.shape[0]
     Nc = 0 if cache is None else cache.shape[0]
@@ -259,9 +270,10 @@ def simce_grad(x, y, scale, lse_x, lse_y, w_row, w_col, inv_bg, label_offset=0, 
     lib = _lib()
     nbytes = lib.clipk_simce_workspace(Mx, Ny + Nc, P)
     ws = workspace(nbytes, x.device, "simce")
-    check(lib.clipk_simce_grad(x.data_ptr(), Mx, y.data_ptr(), Ny, ptr(cache), Nc, P, scale.data_ptr(), label_offset,
-                               lse_x.data_ptr(), lse_y.data_ptr(), float(w_row), float(w_col), float(inv_bg),
-                               dx.data_ptr(), dsc.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "clipk_simce_grad")
+    check(lib.clipk_simce_grad_scaled(x.data_ptr(), Mx, y.data_ptr(), Ny, ptr(cache), Nc, P, scale.data_ptr(), label_offset,
+                                      lse_x.data_ptr(), lse_y.data_ptr(), float(w_row), float(w_col), float(inv_bg),
+                                      ptr(upstream), dx.data_ptr(), dsc.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+          "clipk_simce_grad_scaled")
     return dx, dsc
 
 

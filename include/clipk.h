@@ -152,6 +152,19 @@ int clipk_simce_grad(const float* X, int Mx, const float* Y, int Ny, const float
                      const float* lse_x, const float* lse_y, float w_row, float w_col, float inv_bg,
                      float* dX /*[Mx,P]*/, float* dscale_partial /*[Mx]*/,
                      void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the loss' incoming gradient folded in: `upstream` (device scalar, or NULL = 1) multiplies inv_bg inside the
+ * kernel - autograd's `grad_output * dX` after the fact was three more launches on [B, P] / [1] tensors per step
+ * (loss.backward() hands 1.0; upstream = 1 gives clipk_simce_grad's bits). */
+int clipk_simce_grad_scaled(const float* X, int Mx, const float* Y, int Ny, const float* Yc, int Nc,
+                            int P, const float* scale, int label_offset,
+                            const float* lse_x, const float* lse_y, float w_row, float w_col, float inv_bg,
+                            const float* upstream, float* dX /*[Mx,P]*/, float* dscale_partial /*[Mx]*/,
+                            void* workspace, size_t workspace_bytes, void* stream);
+/* loss[0] = (w_row * sum_i (lse_r[i] - pos_r[i]) + w_col * sum_i (lse_c[i] - pos_c[i])) / bg from the two clipk_simce_lse
+ * results in one launch, fixed summation order (the two F.cross_entropy means and their average of
+ * rna_clip_codes.ipynb:1952-1953; old/ablation.py:16 with w_col = 0 and lse_c = pos_c = NULL). */
+int clipk_ce_combine(const float* lse_r, const float* pos_r, const float* lse_c, const float* pos_c, int n,
+                     float w_row, float w_col, float bg, float* loss, void* stream);
 
 /* Batched form for several same-shape contrastive problems on one logit scale — the tri-modal ContrastiveModel of
  * current/tf_clip_codes (1).ipynb:13150-13163 (cell x pert, cell x protein, pert x protein, each symmetric) is six

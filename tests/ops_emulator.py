@@ -156,7 +156,16 @@ def simce_lse(x, y, scale, label_offset=0, cache=None):
     return torch.logsumexp(s, 1).float(), s[torch.arange(x.shape[0]), idx].float()
 
 
-def simce_grad(x, y, scale, lse_x, lse_y, w_row, w_col, inv_bg, label_offset=0, cache=None):
+def ce_combine(lse_r, pos_r, lse_c, pos_c, w_row, w_col, bg):
+    local = w_row * (lse_r - pos_r).sum()
+    if lse_c is not None:
+        local = local + w_col * (lse_c - pos_c).sum()
+    return local / bg
+
+
+def simce_grad(x, y, scale, lse_x, lse_y, w_row, w_col, inv_bg, label_offset=0, cache=None, upstream=None):
+    if upstream is not None:
+        inv_bg = inv_bg * float(upstream.reshape(-1)[0])
     s = _scores(x, y, scale, cache)
     ny = y.shape[0]
     g = w_row * torch.exp(s - lse_x.double()[:, None])
