@@ -1094,8 +1094,31 @@ def test_simce_tiled_grad_pass(dev, kopt, Mx, Ny, Nc, P, off, wr, wc):
         assert torch.allclose(dx.double(), ref_dx, rtol=1e-4, atol=1e-7), (mode, (dx.double() - ref_dx).abs().max())
         assert torch.allclose(dsc.double(), ref_dsc, rtol=1e-4, atol=1e-7), mode
         assert torch.equal(dx, ops.simce_grad(x, y, sc, lse_x, lse_y, wr, wc, inv_bg, label_offset=off, cache=cache)[0])
+        # clipk_simce_grad_scaled: the loss' grad_output as a device scalar inside the kernel; 1.0 gives the same bits
+        one, g = torch.ones(1, device=dev), torch.tensor([-2.5], device=dev)
+        d1, s1 = ops.simce_grad(x, y, sc, lse_x, lse_y, wr, wc, inv_bg, label_offset=off, cache=cache, upstream=one)
+        assert torch.equal(d1, dx) and torch.equal(s1, dsc)
+        dg, sg = ops.simce_grad(x, y, sc, lse_x, lse_y, wr, wc, inv_bg, label_offset=off, cache=cache, upstream=g)
+        assert torch.allclose(dg.double(), -2.5 * ref_dx, rtol=1e-4, atol=1e-7)
+        assert torch.allclose(sg.double(), -2.5 * ref_dsc, rtol=1e-4, atol=1e-7)
         out[mode] = dx
     assert torch.allclose(out[1], out[2], rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("n", [1, 32, 256, 1000, 4099])
+def test_ce_combine_is_the_weighted_mean_of_the_two_directions(dev, n):
+    """clipk_ce_combine: (w_row sum(lse_r - pos_r) + w_col sum(lse_c - pos_c)) / bg in one launch (the average of the two
+    F.cross_entropy means, rna_clip_codes.ipynb:1952-1953) against f64; the one-sided form (old/ablation.py:16) with the
+    column vectors absent."""
+    ops = _ops()
+    lr, pr, lc, pc = (_rand((n,), dev, 120 + i, 3.0) for i in range(4))
+    got = ops.ce_combine(lr, pr, lc, pc, 0.5, 0.5, float(n))
+    ref = (0.5 * (lr.double() - pr.double()).sum() + 0.5 * (lc.double() - pc.double()).sum()) / n
+    assert got.shape == () and abs(got.item() - ref.item()) <= 1e-6 * max(1.0, (lr - pr).abs().double().sum().item() / n)
+    one = ops.ce_combine(lr, pr, None, None, 1.0, 0.0, float(2 * n))
+    ref1 = (lr.double() - pr.double()).sum() / (2 * n)
+    assert abs(one.item() - ref1.item()) <= 1e-6 * max(1.0, (lr - pr).abs().double().sum().item() / n)
+    assert torch.equal(got, ops.ce_combine(lr, pr, lc, pc, 0.5, 0.5, float(n)))
 
 
 @pytest.mark.parametrize("rows,cols,act", [(64, 512, "celu"), (100, 256, "celu"), (33, 512, "softplus"), (257, 512, None),
