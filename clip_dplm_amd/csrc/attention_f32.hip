@@ -88,6 +88,48 @@ __device__ __forceinline__ void stage_rows(float* dst, const float* src, long ld
     for (int d = tx; d < S; d += (1 << lpr_log)) dst[j * S + d] = 0.f;
 }
 
+// two tensors with the same row range staged together (K and V; Q and dO): their loads are in flight at once - one memory
+// round trip per 4 rows instead of two
+__device__ __forceinline__ void stage_rows2(float* dstA, const float* srcA, long ldA, float mulA, float* dstB, const float* srcB,
+                                            long ldB, float mulB, long row0, int r0, int nrows, int L, int D, int S, int tid) {
+  const int lpr_log = D <= 16 ? 4 : (D <= 32 ? 5 : 6);
+  const int tx = tid & ((1 << lpr_log) - 1), ty = tid >> lpr_log, rows_per_pass = 256 >> lpr_log;
+  constexpr int U = 4, C = 4;
+  const float* baseA = srcA + row0 * ldA;
+  const float* baseB = srcB + row0 * ldB;
+  const int live = L - r0 < nrows ? (L - r0 > 0 ? L - r0 : 0) : nrows;
+  for (int j0 = ty; j0 < live; j0 += rows_per_pass * U) {
+    float va[U][C], vb[U][C];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = r0 + j0 + u * rows_per_pass;
+      const unsigned rc = (unsigned)(r < L ? r : 0);
+      const unsigned roA = rc * (unsigned)ldA, roB = rc * (unsigned)ldB;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const int d = tx + (c << lpr_log);
+        const unsigned dc = (unsigned)(d < D ? d : 0);
+        va[u][c] = baseA[roA + dc];
+        vb[u][c] = baseB[roB + dc];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u * rows_per_pass;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const int d = tx + (c << lpr_log);
+        if (j < live && d < S) {
+          dstA[j * S + d] = d < D ? va[u][c] * mulA : 0.f;
+          dstB[j * S + d] = d < D ? vb[u][c] * mulB : 0.f;
+        }
+      }
+    }
+  }
+  for (int j = live + ty; j < nrows; j += rows_per_pass)
+    for (int d = tx; d < S; d += (1 << lpr_log)) { dstA[j * S + d] = 0.f; dstB[j * S + d] = 0.f; }
+}
+
 // acc[r] += <rowsA[r] (wave-uniform rows, broadcast reads), rowB (this lane's row)> over the padded head dim, d ascending
 template <int RW>
 __device__ __forceinline__ void dot4(const float* rowsA, const float* rowB, int S, int D4, float (&acc)[RW]) {
@@ -129,8 +171,7 @@ __global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const AF p) {
   }
   for (int k0 = 0; k0 < L; k0 += KB) {
     __syncthreads();                                        // previous block's readers are done (and Qs is written)
-    stage_rows(Ks, p.qkv + (long)(H + h) * D, ld, row0, k0, KB, L, D, S, 1.f, tid);
-    stage_rows(Vs, p.qkv + (long)(2 * H + h) * D, ld, row0, k0, KB, L, D, S, 1.f, tid);
+    stage_rows2(Ks, p.qkv + (long)(H + h) * D, ld, 1.f, Vs, p.qkv + (long)(2 * H + h) * D, ld, 1.f, row0, k0, KB, L, D, S, tid);
     __syncthreads();
     const int key = k0 + lane;
     const bool valid = key < L && (!p.key_mask || p.key_mask[row0 + key]);
@@ -202,8 +243,7 @@ __global__ __launch_bounds__(256) void attn_f32_bwd_dq_kernel(const AF p) {
   float* Qs = Vs + KB * S;                 // [RB][S] q * q_scale
   float* Gs = Qs + RB * S;                 // [RB][S] dO
   float* Ds = Gs + RB * S;                 // [NW][KB][RW] dS
-  stage_rows(Qs, p.qkv + (long)h * D, ld, row0, q0, RB, L, D, S, p.scale, tid);
-  stage_rows(Gs, p.dout + (long)h * D, ldo, row0, q0, RB, L, D, S, 1.f, tid);
+  stage_rows2(Qs, p.qkv + (long)h * D, ld, p.scale, Gs, p.dout + (long)h * D, ldo, 1.f, row0, q0, RB, L, D, S, tid);
   float lse[RW], delta[RW], dq[RW][DT];
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
@@ -227,8 +267,7 @@ __global__ __launch_bounds__(256) void attn_f32_bwd_dq_kernel(const AF p) {
   }
   for (int k0 = 0; k0 < L; k0 += KB) {
     __syncthreads();
-    stage_rows(Ks, p.qkv + (long)(H + h) * D, ld, row0, k0, KB, L, D, S, 1.f, tid);
-    stage_rows(Vs, p.qkv + (long)(2 * H + h) * D, ld, row0, k0, KB, L, D, S, 1.f, tid);
+    stage_rows2(Ks, p.qkv + (long)(H + h) * D, ld, 1.f, Vs, p.qkv + (long)(2 * H + h) * D, ld, 1.f, row0, k0, KB, L, D, S, tid);
     __syncthreads();
     const int key = k0 + lane;
     const bool valid = key < L && (!p.key_mask || p.key_mask[row0 + key]);
@@ -290,8 +329,7 @@ __global__ __launch_bounds__(256) void attn_f32_bwd_dkv_kernel(const AF p) {
   float* Vr = Kr + RB * S;                 // [RB][S]
   float* Ps = Vr + RB * S;                 // [NW][KB][RW] P~
   float* Ds = Ps + NW * KB * RW;           // [NW][KB][RW] dS
-  stage_rows(Kr, p.qkv + (long)(H + h) * D, ld, row0, k0, RB, L, D, S, 1.f, tid);
-  stage_rows(Vr, p.qkv + (long)(2 * H + h) * D, ld, row0, k0, RB, L, D, S, 1.f, tid);
+  stage_rows2(Kr, p.qkv + (long)(H + h) * D, ld, 1.f, Vr, p.qkv + (long)(2 * H + h) * D, ld, 1.f, row0, k0, RB, L, D, S, tid);
   bool kvalid[RW];
   float dk[RW][DT], dv[RW][DT];
 #pragma unroll
@@ -303,8 +341,7 @@ __global__ __launch_bounds__(256) void attn_f32_bwd_dkv_kernel(const AF p) {
   }
   for (int q0 = 0; q0 < L; q0 += KB) {
     __syncthreads();
-    stage_rows(Qs, p.qkv + (long)h * D, ld, row0, q0, KB, L, D, S, p.scale, tid);
-    stage_rows(Gs, p.dout + (long)h * D, ldo, row0, q0, KB, L, D, S, 1.f, tid);
+    stage_rows2(Qs, p.qkv + (long)h * D, ld, p.scale, Gs, p.dout + (long)h * D, ldo, 1.f, row0, q0, KB, L, D, S, tid);
     __syncthreads();
     const int q = q0 + lane;
     const float lse = q < L ? p.lse[((long)b * H + h) * L + q] : -INFINITY;
