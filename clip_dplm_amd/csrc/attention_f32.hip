@@ -88,13 +88,13 @@ __device__ __forceinline__ void stage_rows(float* dst, const float* src, long ld
     for (int d = tx; d < S; d += (1 << lpr_log)) dst[j * S + d] = 0.f;
 }
 
-// two tensors with the same row range staged together (K and V; Q and dO): their loads are in flight at once - one memory
-// round trip per 4 rows instead of two
+// two tensors with the same row range staged together (K and V; Q and dO): their loads are in flight at once, 8 rows x 4
+// column strides each - 32 rows of K and V in ONE memory round trip (the sliced models attend over 32 samples)
 __device__ __forceinline__ void stage_rows2(float* dstA, const float* srcA, long ldA, float mulA, float* dstB, const float* srcB,
                                             long ldB, float mulB, long row0, int r0, int nrows, int L, int D, int S, int tid) {
   const int lpr_log = D <= 16 ? 4 : (D <= 32 ? 5 : 6);
   const int tx = tid & ((1 << lpr_log) - 1), ty = tid >> lpr_log, rows_per_pass = 256 >> lpr_log;
-  constexpr int U = 4, C = 4;
+  constexpr int U = 8, C = 4;
   const float* baseA = srcA + row0 * ldA;
   const float* baseB = srcB + row0 * ldB;
   const int live = L - r0 < nrows ? (L - r0 > 0 ? L - r0 : 0) : nrows;

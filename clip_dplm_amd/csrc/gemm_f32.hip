@@ -309,8 +309,14 @@ __global__ __launch_bounds__(1024) void gemm_f32_skinny_reduce_kernel(const GP p
 #pragma unroll
   for (int i = 0; i < MB; ++i) {
     const int e = tid + i * 1024;
+    // all S <= 8 partial tiles requested at once (a run-time loop of dependent adds was S memory round trips); summed in
+    // split order as before
+    float part[8];
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) part[s2] = p.parts[((long)(s2 < p.S ? s2 : 0) * njb + blockIdx.x) * tile + e];
     float v = 0.f;
-    for (int s2 = 0; s2 < p.S; ++s2) v += p.parts[((long)s2 * njb + blockIdx.x) * tile + e];
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) v += s2 < p.S ? part[s2] : 0.f;
     const int m = e >> 5, j = j0 + (e & 31);
     if (m < p.M && j < p.N) {
       v = alpha * v + (p.bias ? p.bias[j] : 0.f);

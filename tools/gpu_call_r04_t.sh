@@ -1,7 +1,7 @@
 #!/bin/bash
 set -e
 mkdir -p gpurun_out/r04_t
-timeout -k 10 600 python3 -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "attention_f32 or attn_f32 or dropout" > gpurun_out/r04_t/t_kernels.log 2>&1 || { tail -40 gpurun_out/r04_t/t_kernels.log; exit 1; }
+timeout -k 10 600 python3 -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "attention_f32 or attn_f32 or dropout or gemm_f32" > gpurun_out/r04_t/t_kernels.log 2>&1 || { tail -40 gpurun_out/r04_t/t_kernels.log; exit 1; }
 tail -3 gpurun_out/r04_t/t_kernels.log
 timeout -k 10 900 python3 -m pytest tests/test_gpu_models.py -x -q -m gpu -k "notebook or trimodal or f32" > gpurun_out/r04_t/t_models.log 2>&1 || { tail -60 gpurun_out/r04_t/t_models.log; exit 1; }
 tail -3 gpurun_out/r04_t/t_models.log
