@@ -243,24 +243,34 @@ __global__ __launch_bounds__(256) void attn_f32_bwd_dq_kernel(const AF p) {
   float* Qs = Vs + KB * S;                 // [RB][S] q * q_scale
   float* Gs = Qs + RB * S;                 // [RB][S] dO
   float* Ds = Gs + RB * S;                 // [NW][KB][RW] dS
+  // the rows' own loads (dO and O for delta, lse) are REQUESTED first and consumed after the staging below: one memory
+  // round trip for all of it (clamped addresses, masked at use: no branch around a load)
+  float lse[RW], delta[RW], dq[RW][DT], gv[RW][DT], ov[RW][DT];
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int q = q0 + w * RW + r;
+    const int qc = q < L ? q : 0;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      const int d = lane + 64 * t;
+      const long o = (row0 + qc) * ldo + (long)h * D + (d < D ? d : 0);
+      gv[r][t] = p.dout[o];
+      ov[r][t] = p.out[o];
+    }
+    lse[r] = p.lse[((long)b * H + h) * L + qc];
+  }
   stage_rows2(Qs, p.qkv + (long)h * D, ld, p.scale, Gs, p.dout + (long)h * D, ldo, 1.f, row0, q0, RB, L, D, S, tid);
-  float lse[RW], delta[RW], dq[RW][DT];
 #pragma unroll
   for (int r = 0; r < RW; ++r) {
     const int q = q0 + w * RW + r;
     float part = 0.f;
-    if (q < L) {
 #pragma unroll
-      for (int t = 0; t < DT; ++t) {
-        const int d = lane + 64 * t;
-        if (d < D) {
-          const long o = (row0 + q) * ldo + (long)h * D + d;
-          part = fmaf(p.dout[o], p.out[o], part);
-        }
-      }
+    for (int t = 0; t < DT; ++t) {
+      const int d = lane + 64 * t;
+      if (q < L && d < D) part = fmaf(gv[r][t], ov[r][t], part);
     }
     delta[r] = wave_sum(part);
-    lse[r] = q < L ? p.lse[((long)b * H + h) * L + q] : -INFINITY;
+    if (q >= L) lse[r] = -INFINITY;
     if (lane == 0 && q < L) p.delta[((long)b * H + h) * L + q] = delta[r];
 #pragma unroll
     for (int t = 0; t < DT; ++t) dq[r][t] = 0.f;
@@ -340,12 +350,12 @@ __global__ __launch_bounds__(256) void attn_f32_bwd_dkv_kernel(const AF p) {
     for (int t = 0; t < DT; ++t) { dk[r][t] = 0.f; dv[r][t] = 0.f; }
   }
   for (int q0 = 0; q0 < L; q0 += KB) {
+    const int q = q0 + lane;                                 // (requested before the staging: one round trip, not two)
+    const float lse = q < L ? p.lse[((long)b * H + h) * L + q] : -INFINITY;
+    const float delta = q < L ? p.delta[((long)b * H + h) * L + q] : 0.f;
     __syncthreads();
     stage_rows2(Qs, p.qkv + (long)h * D, ld, p.scale, Gs, p.dout + (long)h * D, ldo, 1.f, row0, q0, KB, L, D, S, tid);
     __syncthreads();
-    const int q = q0 + lane;
-    const float lse = q < L ? p.lse[((long)b * H + h) * L + q] : -INFINITY;
-    const float delta = q < L ? p.delta[((long)b * H + h) * L + q] : 0.f;
     float s[RW], dp[RW];
 #pragma unroll
     for (int r = 0; r < RW; ++r) { s[r] = 0.f; dp[r] = 0.f; }
