@@ -314,13 +314,17 @@ __global__ __launch_bounds__(1024) void gemm_f32_skinny_reduce_kernel(const GP p
     float part[8];
 #pragma unroll
     for (int s2 = 0; s2 < 8; ++s2) part[s2] = p.parts[((long)(s2 < p.S ? s2 : 0) * njb + blockIdx.x) * tile + e];
+    const int m = e >> 5, j = j0 + (e & 31);
+    const bool ok = m < p.M && j < p.N;
+    // (bias / addend requested with the partial tiles: clamped addresses, used under `ok`)
+    const float bv = p.bias ? p.bias[ok ? j : 0] : 0.f;
+    const float av = p.addend ? p.addend[ok ? (long)m * p.ldadd + j : 0] : 0.f;
     float v = 0.f;
 #pragma unroll
     for (int s2 = 0; s2 < 8; ++s2) v += s2 < p.S ? part[s2] : 0.f;
-    const int m = e >> 5, j = j0 + (e & 31);
-    if (m < p.M && j < p.N) {
-      v = alpha * v + (p.bias ? p.bias[j] : 0.f);
-      if (p.addend) v += asc * p.addend[(long)m * p.ldadd + j];
+    if (ok) {
+      v = alpha * v + bv;
+      if (p.addend) v += asc * av;
       p.out[(long)m * p.ldo + j] = v;
     }
   }
