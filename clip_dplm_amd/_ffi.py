@@ -100,6 +100,7 @@ SIGNATURES = {
     "clipk_attn_f32_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, C.c_uint32, _vp]),
     "clipk_dropout_f32": (_i, [_vp, _vp, _vp, _i64, _f, C.c_uint32, _vp]),
     "clipk_colsum_f32": (_i, [_vp, _i, _i, _vp, _i, _vp]),
+    "clipk_colreduce_batched": (_i, [_vp, _i, _i, _vp]),
     "clipk_set_dropout_epoch": (_i, [_vp]),
     "clipk_gemm_wgrad_f32": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _vp]),
     "clipk_embed_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),

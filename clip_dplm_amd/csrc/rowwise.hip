@@ -614,6 +614,43 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* part, int n
   }
 }
 
+// Several column reduces in ONE launch (blockIdx.y = problem): the dgamma / dbeta partial rows of every LayerNorm whose
+// backward ran in this pass, reduced when the pass is over (functional.LayerNormFn defers them: one launch instead of one
+// per LayerNorm - 20 per step of the sliced notebook model, each a 4-us launch on the critical chain).  desc: 6 int64 per
+// problem {part, nparts, cols, out0 (dgamma), out1 (dbeta), accumulate}; same block shape and summation order as
+// colreduce_kernel.
+__global__ __launch_bounds__(256) void colreduce_batched_kernel(const long long* desc) {
+  const long long* d = desc + 6 * (long)blockIdx.y;
+  const float* part = reinterpret_cast<const float*>(d[0]);
+  const int nparts = (int)d[1], cols = (int)d[2], ncols = 2 * cols, accumulate = (int)d[5];
+  float* out0 = reinterpret_cast<float*>(d[3]);
+  float* out1 = reinterpret_cast<float*>(d[4]);
+  if ((int)blockIdx.x * 16 >= ncols) return;                 // (block-uniform)
+  __shared__ float sm[16][17];
+  const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + c;
+  float a = 0.f;
+  if (i < ncols) {
+    int s = rg;
+    for (; s + 7 * 16 < nparts; s += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(long)(s + 16 * u) * ncols + i];
+      a += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; s < nparts; s += 16) a += part[(long)s * ncols + i];
+  }
+  sm[rg][c] = a;
+  __syncthreads();
+  if (rg == 0 && i < ncols) {
+    a = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a += sm[r][c];
+    float* o = (i < cols) ? (out0 ? out0 + i : nullptr) : (out1 ? out1 + (i - cols) : nullptr);
+    if (o) *o = accumulate ? (*o + a) : a;
+  }
+}
+
 // ---- L2 normalise -------------------------------------------------------------------------------
 template <int VPL>
 __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* x, float* y, float* norm, int rows, int cols,
@@ -798,6 +835,16 @@ extern "C" int clipk_colsum_f32(const float* x, int rows, int cols, float* out, 
   if (!x || !out || rows <= 0 || cols <= 0) return CLIPK_ERR_BAD_ARG;
   hipLaunchKernelGGL(colreduce_kernel, dim3((cols + 15) / 16), dim3(256), 0, (hipStream_t)stream, x, rows, cols, out,
                      (float*)nullptr, cols, accumulate);
+  return clipk_check_launch();
+}
+
+// The deferred form of clipk_layernorm_bwd's parameter gradients: call it with dgamma = dbeta = NULL and a workspace of your
+// own per LayerNorm (it keeps the [blocks][2][cols] partial rows, blocks = workspace bytes / (2 cols 4)), then reduce all of
+// them here in one launch.  desc_dev: n x 6 int64 in device memory {partial rows, blocks, cols, dgamma, dbeta, accumulate}.
+extern "C" int clipk_colreduce_batched(const int64_t* desc_dev, int n, int max_cols, void* stream) {
+  if (!desc_dev || n <= 0 || max_cols <= 0 || n > 65535) return CLIPK_ERR_BAD_ARG;
+  hipLaunchKernelGGL(colreduce_batched_kernel, dim3((2 * max_cols + 15) / 16, n), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const long long*>(desc_dev));
   return clipk_check_launch();
 }
 

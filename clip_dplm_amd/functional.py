@@ -5,6 +5,7 @@ the f32 master weights (W and W^T) are cached per parameter and refreshed when t
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import weakref
@@ -434,12 +435,71 @@ class LayerNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, gamma, beta, mean, rstd = ctx.saved_tensors
         if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and _grad_in_place(gamma) and _grad_in_place(beta):
-            # the column reduce adds straight into the parameters' .grad (no AccumulateGrad add launch per parameter)
+            # the column reduce adds straight into the parameters' .grad (no AccumulateGrad add launch per parameter) ...
+            part = _ln_defer_buffer(gamma, x) if DEFER_LN_PARAM_GRADS else None
+            if part is not None:
+                # ... and it is DEFERRED: this LayerNorm's partial rows stay in a buffer of their own, one launch reduces
+                # every LayerNorm of the pass when the pass is over
+                dx = ops.layernorm_bwd(dy.contiguous(), x, gamma, beta, mean, rstd, act=ctx.act, want_f32=True,
+                                       part_out=part[0])[0]
+                _ln_defer(part, gamma, beta)
+                return dx, None, None, None, None
             dx = ops.layernorm_bwd(dy.contiguous(), x, gamma, beta, mean, rstd, act=ctx.act, want_f32=True,
                                    dgamma=gamma.grad, dbeta=beta.grad, accumulate=True)[0]
             return dx, None, None, None, None
         dx, _, dg, db = ops.layernorm_bwd(dy.contiguous(), x, gamma, beta, mean, rstd, act=ctx.act, want_f32=True)
         return dx, dg, db, None, None
+
+
+# Deferred LayerNorm parameter gradients.  The backward of a LayerNorm is two launches - the row pass, which leaves one
+# [dgamma | dbeta] partial row per workgroup, and a column reduce over them - and in the models that pool one position the
+# second is a 4-us launch on the critical chain, 20 times per step.  With `.grad` buffers in place (FusedAdamW) the row pass
+# writes its partial rows to a buffer that belongs to this LayerNorm, and ONE batched launch reduces all of them when the
+# backward pass is over (autograd-engine callback; after JoinStreamsFn's, so side-stream branches have been joined).
+# MEASURED AND LEFT OFF (profiles/r04/ln_deferred_param_grads_ab_v1.txt): -3 % on config 1's one-stream captured step, nothing on
+# the notebook step (1.891 vs 1.878 ms) and on the two-branch config-1 step - with the towers as parallel branches the
+# reduces were already off the path that bounds the step.  CLIPK_DEFER_LN_GRADS=1 switches it on.
+DEFER_LN_PARAM_GRADS = os.environ.get("CLIPK_DEFER_LN_GRADS", "0") == "1"
+_LN_PART = {}          # (gamma storage ptr, rows, cols) -> (partial rows buffer, blocks, cols)
+_LN_PENDING = []       # (partial rows buffer, blocks, cols, dgamma, dbeta)
+_LN_PENDING_KEYS = set()
+
+
+def _ln_defer_buffer(gamma, x):
+    rows, cols = x.shape
+    key = (gamma.data_ptr(), rows, cols)
+    if key in _LN_PENDING_KEYS:            # the same LayerNorm twice in one pass (shared module): reduce this use right away
+        return None
+    part = _LN_PART.get(key)
+    if part is None:
+        if len(_LN_PART) > 256:
+            _LN_PART.clear()
+        blocks, nfloat = ops.layernorm_bwd_partial_shape(rows, cols)
+        part = _LN_PART[key] = (torch.empty(nfloat, dtype=torch.float32, device=x.device), blocks, cols, key)
+    return part
+
+
+def _ln_defer(part, gamma, beta) -> None:
+    buf, blocks, cols, key = part
+    _LN_PENDING.append((buf, blocks, cols, gamma.grad, beta.grad))
+    _LN_PENDING_KEYS.add(key)
+    torch.autograd.Variable._execution_engine.queue_callback(flush_ln_param_grads)    # (later ones find nothing to do)
+
+
+def flush_ln_param_grads() -> None:
+    """Reduce every deferred LayerNorm parameter gradient of this backward pass (one launch per device)."""
+    if not _LN_PENDING:
+        return
+    entries = list(_LN_PENDING)
+    _LN_PENDING.clear()
+    _LN_PENDING_KEYS.clear()
+    ops.colreduce_entries(entries)
+
+
+def discard_deferred_ln_param_grads() -> None:
+    """Forget partial rows that were never reduced (a backward pass that raised): called by FusedAdamW.zero_grad()."""
+    _LN_PENDING.clear()
+    _LN_PENDING_KEYS.clear()
 
 
 def layer_norm(x, gamma, beta, eps, act=None):

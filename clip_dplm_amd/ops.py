@@ -496,12 +496,51 @@ def layernorm_fwd(x, gamma, beta, eps, act=None, want_f32=True, want_bf16=False,
     return y32, y16, mean, rstd
 
 
+def layernorm_bwd_partial_shape(rows: int, cols: int):
+    """(blocks, floats) of the per-block dgamma / dbeta partial rows clipk_layernorm_bwd leaves in its workspace."""
+    nbytes = _lib().clipk_layernorm_bwd_workspace(rows, cols)
+    return nbytes // (2 * cols * 4), nbytes // 4
+
+
+def colreduce_batched(desc: torch.Tensor, n: int, max_cols: int) -> None:
+    """Reduce the partial rows of n LayerNorm backwards in one launch (clipk_colreduce_batched; desc int64 [n, 6] on the
+    device: partial rows, blocks, cols, dgamma, dbeta, accumulate)."""
+    _need_cuda(desc)
+    assert desc.dtype == torch.int64 and desc.is_contiguous() and desc.numel() >= 6 * n
+    check(_lib().clipk_colreduce_batched(desc.data_ptr(), int(n), int(max_cols), _stream()), "clipk_colreduce_batched")
+
+
+_COLRED_DESC = {}
+
+
+def colreduce_entries(entries) -> None:
+    """entries: (partial rows tensor, blocks, cols, dgamma, dbeta) per LayerNorm; dgamma / dbeta += column sums, one launch per
+    device.  The descriptor table lives on the device and is cached by the pointers it holds (a captured step finds the table
+    its warm-up built)."""
+    by_dev = {}
+    for e in entries:
+        by_dev.setdefault(e[0].device, []).append(e)
+    for dev, es in by_dev.items():
+        rows = tuple((p.data_ptr(), int(b), int(c), g.data_ptr(), bt.data_ptr(), 1) for p, b, c, g, bt in es)
+        desc = _COLRED_DESC.get((dev, rows))
+        if desc is None:
+            if len(_COLRED_DESC) > 32:
+                _COLRED_DESC.clear()
+            desc = _COLRED_DESC[(dev, rows)] = torch.tensor(rows, dtype=torch.int64).to(dev)
+        with torch.cuda.device(dev):
+            colreduce_batched(desc, len(es), max(int(c) for _, _, c, _, _ in es))
+
+
 def layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=None, dx_add=None, want_f32=True, want_bf16=False,
-                  dgamma=None, dbeta=None, accumulate=False, want_param_grads=True, dropout_bf16=None):
-    _need_cuda(dy, x, gamma, mean, rstd)
+                  dgamma=None, dbeta=None, accumulate=False, want_param_grads=True, dropout_bf16=None, part_out=None):
+    """part_out (f32, >= layernorm_bwd_partial_shape(rows, cols)[1] elements): the kernel's workspace is THIS buffer and no
+    parameter gradient is reduced - the caller reduces the partial rows left in it later (colreduce_batched)."""
+    _need_cuda(dy, x, gamma, mean, rstd, part_out)
     rows, cols = x.shape
     dx32 = torch.empty((rows, cols), dtype=torch.float32, device=x.device) if want_f32 else None
     dx16 = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    if part_out is not None:
+        want_param_grads = False
     if not want_param_grads:                               # input gradient only (transport maps in eval mode)
         dgamma = dbeta = None
     elif dgamma is None:
@@ -510,7 +549,11 @@ def layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=None, dx_add=None, want_f3
         accumulate = False
     lib = _lib()
     nbytes = lib.clipk_layernorm_bwd_workspace(rows, cols)
-    ws = workspace(nbytes, x.device, "ln")
+    if part_out is not None:
+        assert part_out.dtype == torch.float32 and part_out.is_contiguous() and part_out.numel() * 4 >= nbytes
+        ws = part_out.view(torch.uint8) if part_out.dim() == 1 else part_out.reshape(-1).view(torch.uint8)
+    else:
+        ws = workspace(nbytes, x.device, "ln")
     nb = rows * cols * (dy.element_size() + x.element_size() + (dx_add.element_size() if dx_add is not None else 0) +
                         (4 if want_f32 else 0) + (2 if want_bf16 else 0))
     check(_timed("layernorm_bwd", nb,

@@ -162,6 +162,7 @@ class FusedAdamW:
 
     def zero_grad(self):
         self.flat.zero_grad()
+        KF.discard_deferred_ln_param_grads()
         self._reduced = [False] * len(self.flat.buckets)
         # (the stacks' count of outstanding backwards is NOT reset here: with the common order forward -> zero_grad() ->
         # backward a stack applied twice would fire its reduce-scatter after the first of its two backwards, ADVICE r03;

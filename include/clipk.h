@@ -239,6 +239,12 @@ int clipk_gemm_f32(const float* A, int64_t lda, int transA, const float* B, int6
 /* out[c] (+)= sum_r x[r][c] (x f32 [rows, cols] contiguous): the bias gradient dY.sum(0) of the exact-f32 Linear layers
  * (old/clip.py:11,27,31 under autograd), accumulated straight into the parameter's .grad; fixed summation order. */
 int clipk_colsum_f32(const float* x, int rows, int cols, float* out, int accumulate, void* stream);
+/* Deferred parameter gradients of several LayerNorms in one launch.  clipk_layernorm_bwd called with dgamma = dbeta = NULL
+ * leaves its per-block partial rows [blocks][2][cols] (blocks = clipk_layernorm_bwd_workspace(rows, cols) / (2 cols 4)) in the
+ * workspace it was given; with one such buffer per LayerNorm, this reduces all of them - what nn.LayerNorm's weight.grad /
+ * bias.grad receive from autograd (old/clip.py:12,28,32; rna_clip_codes.ipynb:1911-1923) - when the backward pass is over:
+ * desc_dev = n x 6 int64 in device memory {partial rows, blocks, cols, dgamma, dbeta, accumulate}; max_cols = the widest. */
+int clipk_colreduce_batched(const int64_t* desc_dev, int n, int max_cols, void* stream);
 
 /* Both parameter gradients of an exact-f32 Linear in one call: dW[N, K] (+)= dY[M, N]^T X[M, K], dbias[N] (+)= dY.sum(0)
  * (what autograd computes for nn.Linear under the reference's fp32 callers: old/clip.py:11,27,31; the Linear layers of

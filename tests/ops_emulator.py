@@ -279,8 +279,19 @@ def layernorm_fwd(x, gamma, beta, eps, act=None, want_f32=True, want_bf16=False,
     return (y if want_f32 else None), (y.to(BF) if want_bf16 else None), mean, rstd
 
 
+def layernorm_bwd_partial_shape(rows, cols):
+    return 1, 2 * cols
+
+
+def colreduce_entries(entries):
+    for part, blocks, cols, dg, db in entries:
+        p = part.view(-1)[:blocks * 2 * cols].view(blocks, 2 * cols).sum(0)
+        dg.add_(p[:cols])
+        db.add_(p[cols:])
+
+
 def layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=None, dx_add=None, want_f32=True, want_bf16=False, want_param_grads=True,
-                  dgamma=None, dbeta=None, accumulate=False, dropout_bf16=None):
+                  dgamma=None, dbeta=None, accumulate=False, dropout_bf16=None, part_out=None):
     xf, dyf = x.float(), dy.float()
     xh = (xf - mean[:, None]) * rstd[:, None]
     if act is not None:
@@ -292,6 +303,9 @@ def layernorm_bwd(dy, x, gamma, beta, mean, rstd, act=None, dx_add=None, want_f3
     if dx_add is not None:
         dx = dx + dx_add.float()
     dg, db = (dyf * xh).sum(0), dyf.sum(0)
+    if part_out is not None:                               # one partial row [dgamma | dbeta], reduced later
+        part_out.view(-1)[:2 * dg.numel()].copy_(torch.cat([dg, db]))
+        dg = db = None
     if dgamma is not None:
         dgamma.copy_(dgamma + dg if accumulate else dg)
         dbeta.copy_(dbeta + db if accumulate else db)

@@ -369,6 +369,30 @@ def test_layernorm(dev, rows, cols, xdt):
         assert torch.allclose(dx16.float(), gx + add, rtol=2e-2, atol=2e-2)
 
 
+def test_layernorm_bwd_deferred_parameter_gradients_equal_the_immediate_ones(dev):
+    """clipk_layernorm_bwd with dgamma = dbeta = NULL leaves its partial rows in the caller's workspace; clipk_colreduce_batched
+    reduces several LayerNorms' rows in one launch (`ops.colreduce_entries`): same dgamma / dbeta bits as the immediate form
+    (same summation order), accumulate semantics, widths 120 .. 2560 (narrow and one-workgroup-per-row kernels) in one batch."""
+    ops = _ops()
+    entries, want = [], []
+    for i, (rows, cols) in enumerate([(32, 1280), (32, 120), (256, 128), (32, 2560), (1000, 480)]):
+        x, dy = _rand((rows, cols), dev, 130 + i, 1.5), _rand((rows, cols), dev, 140 + i)
+        g, b = _rand((cols,), dev, 150 + i) * 0.2 + 1.0, _rand((cols,), dev, 160 + i) * 0.1
+        _, _, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-5)
+        dg0, db0 = _rand((cols,), dev, 170 + i), _rand((cols,), dev, 180 + i)
+        dg_ref, db_ref = dg0.clone(), db0.clone()
+        dx_ref = ops.layernorm_bwd(dy, x, g, b, mean, rstd, dgamma=dg_ref, dbeta=db_ref, accumulate=True)[0]
+        blocks, nfloat = ops.layernorm_bwd_partial_shape(rows, cols)
+        part = torch.empty(nfloat, device=dev)
+        dx = ops.layernorm_bwd(dy, x, g, b, mean, rstd, part_out=part)[0]
+        assert torch.equal(dx, dx_ref)
+        entries.append((part, blocks, cols, dg0, db0))
+        want.append((dg_ref, db_ref))
+    ops.colreduce_entries(entries)
+    for (_, _, _, dg, db), (rg, rb) in zip(entries, want):
+        assert torch.equal(dg, rg) and torch.equal(db, rb)
+
+
 @pytest.mark.parametrize("rows,cols", [(256, 128), (512, 512), (10, 32), (64, 768)])
 def test_l2norm(dev, rows, cols):
     ops = _ops()

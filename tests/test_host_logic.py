@@ -690,3 +690,46 @@ def test_weight_cache_never_refreshes_from_a_per_call_copy(monkeypatch):
     assert not c2.derived
     KF.mark_weights_dirty()
     assert any(c is c2 for c, _, _ in KF._stale_caches(require_cuda=False))
+
+
+def test_deferred_layernorm_parameter_gradients(monkeypatch):
+    """functional.LayerNormFn with `.grad` buffers in place: the row pass leaves partial rows in a buffer of the LayerNorm's own
+    and ONE batched reduce runs when the backward pass is over (nn.LayerNorm's weight.grad / bias.grad, old/clip.py:12,28,32).
+    Host logic: gradients equal torch's, also when one LayerNorm is applied twice in a pass (the second use reduces at once),
+    over two accumulating passes, and partial rows of a pass that never finished are discarded by zero_grad()."""
+    ops_emulator.install(monkeypatch)
+    import torch.nn.functional as F
+    from clip_dplm_amd import functional as KF
+    monkeypatch.setattr(KF, "DEFER_LN_PARAM_GRADS", True)
+    calls = []
+    real = KF.ops.colreduce_entries
+    monkeypatch.setattr(KF.ops, "colreduce_entries", lambda e: (calls.append(len(e)), real(e))[1])
+    torch.manual_seed(0)
+    g1, b1 = torch.randn(24).requires_grad_(True), torch.randn(24).requires_grad_(True)
+    g2, b2 = torch.randn(24).requires_grad_(True), torch.randn(24).requires_grad_(True)
+    x = torch.randn(10, 24)
+
+    def loss_of(ln):
+        h = ln(x, g1, b1)
+        h = ln(h * 1.5, g2, b2)
+        return (ln(h + 0.3, g1, b1) ** 2).sum()             # g1 / b1 used twice
+    ref = torch.autograd.grad(loss_of(lambda t, g, b: F.layer_norm(t, (24,), g, b, 1e-5)), (g1, b1, g2, b2))
+    for p in (g1, b1, g2, b2):
+        p.grad = torch.zeros_like(p)                         # FusedAdamW's situation: buffers exist
+    loss_of(lambda t, g, b: KF.layer_norm(t, g, b, 1e-5)).backward()
+    assert calls == [2]                                      # one batched reduce for the two deferred LayerNorms
+    for p, r in zip((g1, b1, g2, b2), ref):
+        assert torch.allclose(p.grad, r, rtol=1e-4, atol=1e-5)
+    loss_of(lambda t, g, b: KF.layer_norm(t, g, b, 1e-5)).backward()      # a second pass accumulates
+    assert calls == [2, 2]
+    for p, r in zip((g1, b1, g2, b2), ref):
+        assert torch.allclose(p.grad, 2 * r, rtol=1e-4, atol=1e-5)
+    # a pass that raised leaves pending partial rows behind: zero_grad()'s discard forgets them
+    KF._LN_PENDING.append((torch.ones(48), 1, 24, g1.grad, b1.grad))
+    KF._LN_PENDING_KEYS.add(("stale",))
+    KF.discard_deferred_ln_param_grads()
+    for p in (g1, b1, g2, b2):
+        p.grad.zero_()
+    loss_of(lambda t, g, b: KF.layer_norm(t, g, b, 1e-5)).backward()
+    for p, r in zip((g1, b1, g2, b2), ref):
+        assert torch.allclose(p.grad, r, rtol=1e-4, atol=1e-5)
