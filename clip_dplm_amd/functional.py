@@ -256,6 +256,12 @@ class JoinStreamsFn(torch.autograd.Function):
         return (None,) + grads
 
 
+def branch_streams(n: int):
+    """n HIP streams for parallel_branches (CLIPK_BRANCH_PRIORITY=high: created with high priority - experiment switch)."""
+    pr = -1 if os.environ.get("CLIPK_BRANCH_PRIORITY") == "high" else 0
+    return tuple(torch.cuda.Stream(priority=pr) for _ in range(n))
+
+
 def parallel_branches(streams, thunks, inputs=()):
     """Run independent branches of a model (the towers of a contrastive model up to the loss) on HIP streams of their own:
     thunks[i]() is enqueued on streams[i] and returns ONE tensor; inputs[i] are the tensors it reads that the calling

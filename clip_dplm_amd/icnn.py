@@ -408,7 +408,7 @@ class TripleTransportMaps(nn.Module):
             # on three streams; replayed from a hipGraph (GraphedTransport) they are three branches of it
             from . import functional as KF
             if self._streams is None:
-                self._streams = tuple(torch.cuda.Stream() for _ in range(3))
+                self._streams = KF.branch_streams(3)
             a, b, c = KF.parallel_branches(
                 self._streams,
                 (lambda: self.cell_to_pert(cell_states, pert_states), lambda: self.cell_to_protein(cell_states, protein_states),

@@ -119,7 +119,7 @@ class _PairCLIPModule(nn.Module):
             # each tower is a chain of microsecond kernels on 256 rows: side by side (in a captured step: two branches of
             # the hipGraph) one hides under the other, forward and backward
             if self._streams is None:
-                self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
+                self._streams = KF.branch_streams(2)
             return KF.parallel_branches(self._streams, (ta, tb), ((a_values,), (b_values,)))
         return ta(), tb()
 

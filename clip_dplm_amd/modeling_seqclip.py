@@ -95,7 +95,7 @@ class RNARBPCLIPModel(nn.Module):
     def forward(self, rna_emb, rbp_emb):
         if self.dual_stream and rna_emb.is_cuda:
             if self._streams is None:
-                self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
+                self._streams = KF.branch_streams(2)
             rna_embed, rbp_embed = KF.parallel_branches(
                 self._streams,
                 (lambda: KF.l2_normalize(self.rna_projection(self._encode(self.rna_encoder, rna_emb))),

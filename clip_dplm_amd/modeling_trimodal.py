@@ -190,7 +190,7 @@ class ContrastiveModel(nn.Module):
         prot = lambda: KF.l2_normalize(self.protein_projection(self._first(self.protein_encoder(self._sl(protein_emb)))))
         if self.multi_stream and cell_state.is_cuda:       # opt-in: the three towers on three HIP streams (RNARBPCLIPModel)
             if self._streams is None:
-                self._streams = tuple(torch.cuda.Stream() for _ in range(3))
+                self._streams = KF.branch_streams(3)
             cell_embed, pert_embed, protein_embed = KF.parallel_branches(
                 self._streams, (cell, pert, prot),
                 ((cell_state, connectivity), (gene_esm_embeddings, gene_values), (protein_emb,)))
