@@ -41,10 +41,14 @@ for name, N, K in (("esm qkv            N=1440 K= 480", 1440, 480), ("esm out_pr
     f2 = lambda: torch.matmul(a, bt, out=out)
     for _ in range(30):
         f1(); f2()
-    t1, t2 = [], []
+    t1, t2, t3 = [], [], []
     for _ in range(5):
         t1.append(timeit(f1)); t2.append(timeit(f2))
-    m1, m2 = statistics.median(t1), statistics.median(t2)
+        ops.set_option("epi_nt", 1)                      # non-temporal output stores (off by default: nothing in the step)
+        t3.append(timeit(f1))
+        ops.set_option("epi_nt", 0)
+    m1, m2, m3 = statistics.median(t1), statistics.median(t2), statistics.median(t3)
     fl = 2.0 * M * N * K
-    print(f"{name:34s} {m1:9.1f} {fl / m1 / 1e6:6.0f} {m2:11.1f} {fl / m2 / 1e6:6.0f}   {m1 / m2:5.2f}", flush=True)
+    print(f"{name:34s} {m1:9.1f} {fl / m1 / 1e6:6.0f} {m2:11.1f} {fl / m2 / 1e6:6.0f}   {m1 / m2:5.2f}   "
+          f"clipk with streaming stores {m3:7.1f} us {fl / m3 / 1e6:5.0f} TF/s ({m3 / m2:4.2f})", flush=True)
     del a, b, bt, out
